@@ -1,0 +1,295 @@
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE's own arithmetic.
+
+TEST INFRASTRUCTURE ONLY; runs in the build container only (needs /root/reference, which
+does not exist on the GPU box).  Nothing here is imported by the product.
+
+How the reference is imported: its files are imported unmodified from
+/root/reference.  Third-party packages that are absent from this image and contribute no
+forward arithmetic on this path get minimal stand-ins in ``sys.modules`` (timm: identity
+DropPath, to_2tuple, trunc_normal_ -> torch.nn.init.trunc_normal_, registry decorator;
+torchvision / pytorch_lightning / sacred / nltk: import-time names only).  ``vilt`` and
+``vilt.modules`` are registered as namespace packages so ``vilt/modules/__init__.py`` (which
+drags in the Lightning module, nltk and a weight download) is never executed.
+``ViLTransformerSS`` itself cannot be built offline (vilt_module.py:78-80 downloads weights),
+so a small holder module owns the reference's sub-modules and exposes the attributes that
+``objectives.compute_moco_contrastive`` / ``compute_itm_wpa`` read.  ``infer`` / ``infer_k`` are
+served by the reference's ``PGDAttack.infer`` (attack/pgd_attack_vilt.py:29-106, a twin of
+vilt_module.py:275-351) pointed at the q-modules, resp. k-modules + q-pooler (:405).
+
+Weights: ``oracle.rmcl_oracle.init_params(cfg, seed)`` loaded into the reference modules via
+their state-dict names, so a fixture is reproducible from (cfg, seed) without the reference.
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz, ~1 min)
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+from copy import deepcopy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import rmcl_oracle as O  # noqa: E402
+
+
+def _install_standins():
+    import transformers.models.bert.modeling_bert  # noqa: F401  (must precede the stand-ins)
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class DropPath(nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            assert p == 0.0
+
+        def forward(self, x):
+            return x
+
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    def no_fetch(*a, **k):
+        raise RuntimeError("no weight download offline")
+
+    mod("timm")
+    mod("timm.data", IMAGENET_DEFAULT_MEAN=(0.485, 0.456, 0.406), IMAGENET_DEFAULT_STD=(0.229, 0.224, 0.225))
+    mod("timm.models")
+    mod("timm.models.helpers", load_pretrained=no_fetch)
+    mod("timm.models.layers", StdConv2dSame=nn.Conv2d, DropPath=DropPath, to_2tuple=to_2tuple,
+        trunc_normal_=torch.nn.init.trunc_normal_)
+    mod("timm.models.resnet", resnet26d=None, resnet50d=None)
+    mod("timm.models.resnetv2", ResNetV2=None)
+    mod("timm.models.registry", register_model=lambda f: f)
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms", Compose=lambda x: x)
+    pl = mod("pytorch_lightning", LightningModule=nn.Module)
+    pl.metrics = mod("pytorch_lightning.metrics", Metric=object)
+    mod("TSNE_vizualisation", TSNE_projection=None)
+    for pkg in ("vilt", "vilt.modules"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules[pkg] = m
+    sys.path.insert(0, REF)
+
+
+_install_standins()
+import vilt.modules.vision_transformer as vit  # noqa: E402  (reference, unmodified)
+import vilt.modules.heads as heads  # noqa: E402
+import vilt.modules.objectives as objectives  # noqa: E402
+from attack.pgd_attack_vilt import PGDAttack, PGDAttack_moco  # noqa: E402
+from transformers.models.bert.modeling_bert import BertConfig, BertEmbeddings  # noqa: E402
+
+
+class Holder(nn.Module):
+    """Owns the reference sub-modules; mirrors the attributes of ViLTransformerSS read on the path."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.hparams = types.SimpleNamespace(config=dict(cfg, vit="vit_base_patch32_384"))
+        bc = BertConfig(vocab_size=cfg["vocab_size"], hidden_size=cfg["hidden_size"],
+                        num_hidden_layers=cfg["num_layers"], num_attention_heads=cfg["num_heads"],
+                        intermediate_size=cfg["hidden_size"] * cfg["mlp_ratio"],
+                        max_position_embeddings=cfg["max_text_len"],
+                        hidden_dropout_prob=cfg["drop_rate"], attention_probs_dropout_prob=cfg["drop_rate"])
+
+        def mk_vit():
+            return vit.VisionTransformer(img_size=cfg["image_size"], patch_size=cfg["patch_size"],
+                                         embed_dim=cfg["hidden_size"], depth=cfg["num_layers"],
+                                         num_heads=cfg["num_heads"], config=cfg)
+
+        D = cfg["hidden_size"]
+        self.text_embeddings = BertEmbeddings(bc)
+        self.token_type_embeddings = nn.Embedding(2, D)
+        self.transformer = mk_vit()
+        self.pooler = heads.Pooler(D)
+        self.itm_score = heads.ITMHead(D)
+        self.k_text_embeddings = BertEmbeddings(bc)
+        self.k_token_type_embeddings = nn.Embedding(2, D)
+        self.k_transformer = mk_vit()
+        self.moco_head = heads.MOCOHead(D, D, cfg["proj_dim"])
+        self.k_moco_head = heads.MOCOHead(D, D, cfg["proj_dim"])
+        self.momentum = cfg["momentum"]
+        self.temperature = cfg["temperature"]
+        self.text_view, self.image_view, self.augmentation = cfg["text_view"], cfg["image_view"], cfg["augmentation"]
+        self.num_negative = cfg["num_negative"]
+        self.per_step_bs = cfg["num_gpus"] * cfg["num_nodes"] * cfg["per_gpu_batchsize"]
+        self.cosine = nn.CosineSimilarity(dim=1, eps=1e-6)
+        self.register_buffer("proj_queue", torch.zeros(cfg["proj_dim"], self.num_negative))
+        self.register_buffer("proj_queue_ptr", torch.zeros(1, dtype=torch.long))
+        self.pgd_attacker = PGDAttack_moco(cfg)
+        self.logged = {}
+        self._q = PGDAttack(cfg, "q")
+        self._k = PGDAttack(cfg, "k")
+        for name in ("train", "val"):
+            for met in ("moco_loss", "itm_loss", "itm_wpa_loss"):
+                setattr(self, f"{name}_{met}", lambda x: x)
+            setattr(self, f"{name}_itm_accuracy", lambda lg, lb: (lg.argmax(-1) == lb).float().mean())
+
+    @property
+    def device(self):
+        return torch.device("cpu")
+
+    def log(self, name, value):
+        self.logged[name] = float(value)
+
+    def infer(self, batch, **kw):
+        a = self._q
+        a.text_embeddings, a.token_type_embeddings = self.text_embeddings, self.token_type_embeddings
+        a.transformer, a.pooler = self.transformer, self.pooler
+        return a.infer(batch, **kw)
+
+    def infer_k(self, batch, **kw):
+        a = self._k
+        a.text_embeddings, a.token_type_embeddings = self.k_text_embeddings, self.k_token_type_embeddings
+        a.transformer, a.pooler = self.k_transformer, self.pooler
+        return a.infer(batch, **kw)
+
+    def load_oracle_params(self, p):
+        sd = self.state_dict()
+        for n, t in p.items():
+            assert n in sd, n
+            assert sd[n].shape == t.shape, (n, sd[n].shape, t.shape)
+            sd[n].copy_(t)
+        for n, prm in self.named_parameters():
+            if n.startswith("k_"):
+                prm.requires_grad = False
+
+
+def tensor_digest(t: torch.Tensor) -> np.ndarray:
+    """[sum, l2, abs-max, first 8 values] of a tensor, as float64."""
+    f = t.detach().double().flatten()
+    head = torch.zeros(8, dtype=torch.float64)
+    head[: min(8, f.numel())] = f[:8]
+    return torch.cat([torch.stack([f.sum(), f.norm(), f.abs().max()]), head]).numpy()
+
+
+def run_moco(tag, cfg, B, seed_w, seed_b, ragged):
+    torch.manual_seed(1234)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+    cfg = dict(cfg, per_gpu_batchsize=B)
+    p = O.init_params(cfg, seed_w)
+    h = Holder(cfg)
+    h.load_oracle_params({n: t for n, t in p.items()})
+    h.proj_queue.copy_(O.init_queue(cfg, 0))
+    h.train()
+    batch = O.synthetic_batch(cfg, B, seed_b, ragged_text=ragged)
+    out = {}
+
+    # (1) plain infer, both encoders
+    with torch.no_grad():
+        r = h.infer(deepcopy(batch))
+        out["cls_feats"] = r["cls_feats"].numpy()
+        out["raw_cls_feats"] = r["raw_cls_feats"].numpy()
+        out["text_feats"] = r["text_feats"].numpy()
+        # image_feats come back in a random patch order (vision_transformer.py:633-636): un-permute
+        pi = r["patch_index"][0]                               # [B, n, 2] (row, col)
+        G = cfg["image_size"] // cfg["patch_size"]
+        flat = pi[..., 0] * G + pi[..., 1]
+        img_f = r["image_feats"]
+        dense = torch.zeros_like(img_f)
+        dense[:, 0] = img_f[:, 0]
+        for b in range(B):
+            dense[b, 1 + flat[b]] = img_f[b, 1:]
+        out["image_feats"] = dense.numpy()
+
+    # (2) PGD alone (K steps and 1 step), momentum copies == query weights here, k from infer_k
+    with torch.no_grad():
+        rk = h.infer_k(deepcopy(batch))
+        k0 = nn.functional.normalize(h.k_moco_head(rk["cls_feats"]), dim=1)
+    out["pgd_k_input"] = k0.numpy()
+    for K in (1, cfg["adv_steps_img"]):
+        att = PGDAttack_moco(dict(cfg, adv_steps_img=K))
+        d = att.pgd_attack(h, deepcopy(batch), k_modality=k0)
+        out[f"pgd_delta_K{K}_sub"] = d[:, :, ::8, ::8].contiguous().numpy()
+        out[f"pgd_delta_K{K}_digest"] = tensor_digest(d)
+        out[f"pgd_delta_K{K}_persample_l2"] = d.flatten(1).norm(dim=1).numpy()
+        out[f"pgd_delta_K{K}_patch00"] = d[:, :, :32, :32].contiguous().numpy()
+
+    # (3) the full step: objectives.compute_moco_contrastive + backward
+    h.zero_grad()
+    ret = objectives.compute_moco_contrastive(h, deepcopy(batch))
+    loss = sum(v for kk, v in ret.items() if "loss" in kk)     # vilt_module.py:475
+    loss.backward()
+    out["moco_loss"] = np.float64(loss.item())
+    for kk, v in ret.items():
+        if kk != "moco_loss":
+            out["ret_" + kk] = np.float64(float(v))
+    for kk, v in h.logged.items():
+        out["log_" + kk.replace("/", "__")] = np.float64(v)
+    out["queue_ptr_after"] = np.int64(int(h.proj_queue_ptr))
+    out["queue_head_after"] = h.proj_queue[:, : 2 * B].numpy().copy()
+    names, gd, kd = [], [], []
+    for n, prm in h.named_parameters():
+        if n.startswith("k_"):
+            kd.append(tensor_digest(prm))
+            names.append(n)
+    out["ema_names"] = np.array(names)
+    out["ema_digest"] = np.stack(kd)
+    gnames = []
+    for n, prm in h.named_parameters():
+        if not n.startswith("k_") and prm.grad is not None:
+            gnames.append(n)
+            gd.append(tensor_digest(prm.grad))
+    out["grad_names"] = np.array(gnames)
+    out["grad_digest"] = np.stack(gd)
+    out["grad_pooler_w"] = h.pooler.dense.weight.grad[:8, :64].numpy().copy()
+    out["grad_qkv0_w"] = h.transformer.blocks[0].attn.qkv.weight.grad[:8, :64].numpy().copy()
+    out["grad_patch_w"] = h.transformer.patch_embed.proj.weight.grad[:4, :, :4, :8].numpy().copy()
+    out["grad_pos_embed"] = h.transformer.pos_embed.grad[0, :4, :64].numpy().copy()
+    we = h.text_embeddings.word_embeddings.weight.grad
+    ids = batch["text_ids"]
+    out["grad_word_rows"] = we[ids[0, :4]][:, :64].numpy().copy()
+    out["meta"] = np.array([B, seed_w, seed_b, int(ragged), cfg["num_layers"], cfg["num_negative"], cfg["adv_steps_img"]])
+    path = os.path.join(ROOT, "tests", "golden", f"moco_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(tag, "moco_loss", out["moco_loss"], "bytes", os.path.getsize(path))
+
+
+def run_itm(tag, cfg, B, seed_w, seed_b, ragged):
+    torch.manual_seed(4321)
+    cfg = dict(cfg, per_gpu_batchsize=B)
+    p = O.init_params(cfg, seed_w)
+    h = Holder(cfg)
+    h.load_oracle_params(p)
+    h.train()
+    batch = O.synthetic_batch(cfg, B, seed_b, ragged_text=ragged)
+    h.zero_grad()
+    ret = objectives.compute_itm_wpa(h, batch)
+    loss = sum(v for kk, v in ret.items() if "loss" in kk)
+    loss.backward()
+    out = {"itm_loss": np.float64(ret["itm_loss"].item()), "itm_wpa_loss": np.float64(ret["itm_wpa_loss"].item()),
+           "itm_logits": ret["itm_logits"].detach().numpy(), "itm_labels": ret["itm_labels"].numpy()}
+    gnames, gd = [], []
+    for n, prm in h.named_parameters():
+        if not n.startswith("k_") and prm.grad is not None:
+            gnames.append(n)
+            gd.append(tensor_digest(prm.grad))
+    out["grad_names"] = np.array(gnames)
+    out["grad_digest"] = np.stack(gd)
+    out["meta"] = np.array([B, seed_w, seed_b, int(ragged), cfg["num_layers"]])
+    path = os.path.join(ROOT, "tests", "golden", f"itm_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(tag, "itm", out["itm_loss"], out["itm_wpa_loss"], "bytes", os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    small = O.default_config(num_layers=2, num_negative=1024)
+    full = O.default_config()
+    run_moco("L2_B4_ragged", small, 4, 11, 21, True)
+    run_moco("L12_B2", full, 2, 12, 22, False)
+    run_itm("L2_B4_ragged", small, 4, 11, 21, True)
+    run_itm("L12_B2", full, 2, 12, 22, False)

@@ -1,0 +1,469 @@
+"""CPU oracle for the RMCL hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The product path (``rmcl_amd``) never imports anything under ``oracle/`` and fails
+loudly when the HIP library is missing.
+
+It is a restatement, in plain PyTorch CPU tensor math (float32, or float64 when
+``dtype=torch.float64`` is passed), of the reference's algorithm for the path named by
+BASELINE.json.  Every function cites the reference file:line it follows (paths relative
+to the reference checkout).  Parity of this oracle with the reference itself is pinned
+by ``tests/golden/*.npz`` which ``oracle/gen_golden.py`` produced by importing the
+reference's own modules in the build container (see DESIGN.md "Oracle").
+
+Parameters live in a flat ``dict[str, Tensor]`` keyed by the reference's state-dict
+names, e.g. ``transformer.blocks.3.attn.qkv.weight`` and the momentum
+copies ``k_transformer...``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+# --------------------------------------------------------------------------------------
+# configuration defaults (vilt/config.py:24-116 and task_moco :128-164)
+# --------------------------------------------------------------------------------------
+
+def default_config(**over) -> dict:
+    cfg = dict(
+        vocab_size=30522, hidden_size=768, num_heads=12, num_layers=12, mlp_ratio=4,
+        max_text_len=40, drop_rate=0.0, image_size=384, patch_size=32, max_image_len=200,
+        num_negative=65536, momentum=0.999, temperature=0.07,
+        text_view=False, image_view=True, augmentation=False,
+        adv_steps_img=3, adv_lr_img=0.05, adv_max_norm_img=0.005,
+        num_gpus=1, num_nodes=1, per_gpu_batchsize=64, proj_dim=128,
+        loss_names={"moco": 1, "itm": 0},
+    )
+    cfg.update(over)
+    return cfg
+
+
+# groups that receive the momentum (EMA) update, in the reference's call order
+# (vilt/modules/objectives.py:257-260).  The pooler is NOT copied (vilt_module.py:405).
+EMA_GROUPS = ("text_embeddings", "token_type_embeddings", "transformer", "moco_head")
+
+
+def param_shapes(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Query-side parameter names and shapes in the reference's registration order
+    (vilt_module.py:26-85; vision_transformer.py:470-506; heads.py:10-20,129-143,173-180)."""
+    D = cfg["hidden_size"]
+    P = cfg["patch_size"]
+    G = cfg["image_size"] // P
+    Hm = D * cfg["mlp_ratio"]
+    s: List[Tuple[str, Tuple[int, ...]]] = [
+        ("text_embeddings.word_embeddings.weight", (cfg["vocab_size"], D)),
+        ("text_embeddings.position_embeddings.weight", (cfg["max_text_len"], D)),
+        ("text_embeddings.token_type_embeddings.weight", (2, D)),
+        ("text_embeddings.LayerNorm.weight", (D,)),
+        ("text_embeddings.LayerNorm.bias", (D,)),
+        ("token_type_embeddings.weight", (2, D)),
+        ("transformer.cls_token", (1, 1, D)),
+        ("transformer.pos_embed", (1, G * G + 1, D)),
+        ("transformer.patch_embed.proj.weight", (D, 3, P, P)),
+        ("transformer.patch_embed.proj.bias", (D,)),
+    ]
+    for i in range(cfg["num_layers"]):
+        b = f"transformer.blocks.{i}."
+        s += [
+            (b + "norm1.weight", (D,)), (b + "norm1.bias", (D,)),
+            (b + "attn.qkv.weight", (3 * D, D)), (b + "attn.qkv.bias", (3 * D,)),
+            (b + "attn.proj.weight", (D, D)), (b + "attn.proj.bias", (D,)),
+            (b + "norm2.weight", (D,)), (b + "norm2.bias", (D,)),
+            (b + "mlp.fc1.weight", (Hm, D)), (b + "mlp.fc1.bias", (Hm,)),
+            (b + "mlp.fc2.weight", (D, Hm)), (b + "mlp.fc2.bias", (D,)),
+        ]
+    s += [
+        ("transformer.norm.weight", (D,)), ("transformer.norm.bias", (D,)),
+        ("moco_head.projector.0.weight", (D, D)), ("moco_head.projector.0.bias", (D,)),
+        ("moco_head.projector.1.weight", (D,)), ("moco_head.projector.1.bias", (D,)),
+        ("moco_head.projector.3.weight", (cfg["proj_dim"], D)),
+        ("pooler.dense.weight", (D, D)), ("pooler.dense.bias", (D,)),
+        ("itm_score.fc.weight", (2, D)), ("itm_score.fc.bias", (2,)),
+    ]
+    return s
+
+
+def init_params(cfg: dict, seed: int, dtype=torch.float32) -> Params:
+    """Seeded, machine-independent synthetic weights (CPU generator).
+
+    NOT the reference's initialiser (objectives.py:1505-1516 zeroes every bias and sets
+    LayerNorm to (1,0), which would hide bias/affine bugs): weights ~ N(0, 0.02) like the
+    reference, but biases ~ N(0, 0.02) and LayerNorm weights ~ 1 + N(0, 0.05).  The golden
+    generator loads exactly these tensors into the reference modules, so fixtures are
+    reproducible from (cfg, seed) alone.  Momentum copies start equal to the query
+    weights (vilt_module.py:270-273)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    p: Params = {}
+    for name, shape in param_shapes(cfg):
+        t = torch.randn(shape, generator=g, dtype=torch.float32) * 0.02
+        if name.endswith("norm1.weight") or name.endswith("norm2.weight") or name.endswith(
+            "norm.weight") or name.endswith("LayerNorm.weight") or name.endswith("projector.1.weight"):
+            t = 1.0 + 2.5 * t
+        p[name] = t.to(dtype)
+    for name in list(p.keys()):
+        if name.split(".")[0] in EMA_GROUPS:
+            p["k_" + name] = p[name].clone()
+    return p
+
+
+def init_queue(cfg: dict, seed: int = 0, dtype=torch.float32) -> Tensor:
+    """Un-normalised randn queue (vilt_module.py:92-94; the normalise line is commented out)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randn(cfg["proj_dim"], cfg["num_negative"], generator=g, dtype=torch.float32).to(dtype)
+
+
+def synthetic_batch(cfg: dict, B: int, seed: int, ragged_text: bool = False, dtype=torch.float32) -> dict:
+    """Synthetic batch in the layout of BaseDataset.collate (vilt/datasets/base_dataset.py:167-245):
+    image = list of views, view 0 = [B,3,H,W] in [-1,1] (transforms/utils.py:48-50)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    S = cfg["image_size"]
+    L = cfg["max_text_len"]
+    img = (torch.rand(B, 3, S, S, generator=g, dtype=torch.float32) * 2 - 1).to(dtype)
+    ids = torch.randint(1000, cfg["vocab_size"], (B, L), generator=g, dtype=torch.int64)
+    masks = torch.ones(B, L, dtype=torch.int64)
+    if ragged_text:
+        lens = torch.randint(8, L + 1, (B,), generator=g)
+        for b in range(B):
+            n = int(lens[b])
+            masks[b, n:] = 0
+            ids[b, n:] = 0
+            ids[b, n - 1] = 102
+    else:
+        ids[:, -1] = 102
+    ids[:, 0] = 101
+    false_img = torch.roll(img, shifts=1, dims=0)
+    return {
+        "image": [img], "false_image_0": [false_img],
+        "text": ["synthetic"] * B,
+        "text_ids": ids, "text_masks": masks,
+        "text_labels": torch.full((B, L), -100, dtype=torch.int64),
+    }
+
+
+# --------------------------------------------------------------------------------------
+# model ops
+# --------------------------------------------------------------------------------------
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def gelu_erf(x: Tensor) -> Tensor:
+    """nn.GELU() exact form (vision_transformer.py:268,275)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def text_embed(p: Params, pre: str, ids: Tensor) -> Tensor:
+    """HF BertEmbeddings (vilt_module.py:26-38,293): LN_{1e-12}(word[id] + type[0] + pos[0:L])."""
+    L = ids.shape[1]
+    e = (p[pre + "text_embeddings.word_embeddings.weight"][ids]
+         + p[pre + "text_embeddings.token_type_embeddings.weight"][0]
+         + p[pre + "text_embeddings.position_embeddings.weight"][:L][None])
+    return layer_norm(e, p[pre + "text_embeddings.LayerNorm.weight"],
+                      p[pre + "text_embeddings.LayerNorm.bias"], 1e-12)
+
+
+def patchify(img: Tensor, P: int) -> Tensor:
+    """[B,3,H,W] -> [B, (H/P)*(W/P), 3*P*P], K ordered (c, ky, kx), patches row-major over
+    the grid: the GEMM view of Conv2d(3,D,P,P) (vision_transformer.py:397-409,589)."""
+    B, C, H, W = img.shape
+    x = img.reshape(B, C, H // P, P, W // P, P).permute(0, 2, 4, 1, 3, 5)
+    return x.reshape(B, (H // P) * (W // P), C * P * P)
+
+
+def patch_mask(img: Tensor, P: int) -> Tensor:
+    """Pixel mask -> patch mask (vision_transformer.py:564-565): (sum_c img != 0) sampled by
+    nearest-neighbour resize, i.e. at the top-left pixel of every patch."""
+    m = (img.sum(dim=1) != 0)
+    return m[:, ::P, ::P].reshape(img.shape[0], -1).to(torch.int64)
+
+
+def visual_embed_dense(p: Params, pre: str, img: Tensor, cfg: dict) -> Tuple[Tensor, Tensor]:
+    """Dense fixed-order visual_embed (vision_transformer.py:559-677) for full-size images
+    (every patch valid, G*G <= max_image_len).  The reference permutes patch order with a
+    CPU multinomial (:633-636); the encoder is permutation-equivariant so cls/logits are
+    unchanged up to rounding."""
+    P = cfg["patch_size"]
+    W = p[pre + "transformer.patch_embed.proj.weight"]
+    D = W.shape[0]
+    x = patchify(img, P) @ W.reshape(D, -1).t() + p[pre + "transformer.patch_embed.proj.bias"]
+    B = img.shape[0]
+    cls = p[pre + "transformer.cls_token"].expand(B, -1, -1)
+    x = torch.cat([cls, x], dim=1) + p[pre + "transformer.pos_embed"]
+    m = torch.cat([torch.ones(B, 1, dtype=torch.int64), patch_mask(img, P)], dim=1)
+    return x, m
+
+
+def attention(p: Params, b: str, x: Tensor, mask: Tensor, H: int) -> Tensor:
+    """Attention.forward (vision_transformer.py:309-332): qkv features ordered (which, head, d)."""
+    B, N, C = x.shape
+    d = C // H
+    qkv = x @ p[b + "attn.qkv.weight"].t() + p[b + "attn.qkv.bias"]
+    qkv = qkv.reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    s = (q @ k.transpose(-2, -1)) * (d ** -0.5)
+    s = s.masked_fill(~mask.bool()[:, None, None, :], float("-inf"))
+    a = torch.softmax(s, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(B, N, C)
+    return o @ p[b + "attn.proj.weight"].t() + p[b + "attn.proj.bias"]
+
+
+def block(p: Params, b: str, x: Tensor, mask: Tensor, H: int) -> Tensor:
+    """Block.forward (vision_transformer.py:371-375), drop_path=0, eps 1e-6 (:466)."""
+    x = x + attention(p, b, layer_norm(x, p[b + "norm1.weight"], p[b + "norm1.bias"], 1e-6), mask, H)
+    h = layer_norm(x, p[b + "norm2.weight"], p[b + "norm2.bias"], 1e-6)
+    h = gelu_erf(h @ p[b + "mlp.fc1.weight"].t() + p[b + "mlp.fc1.bias"])
+    return x + h @ p[b + "mlp.fc2.weight"].t() + p[b + "mlp.fc2.bias"]
+
+
+def infer(p: Params, cfg: dict, ids: Tensor, text_masks: Tensor, img: Tensor, key: bool = False,
+          image_token_type_idx: int = 1) -> dict:
+    """ViLTransformerSS.infer (vilt_module.py:275-351) / infer_k (:353-418).
+    ``key=True`` uses the k_* momentum copies but the *query* pooler (:405)."""
+    pre = "k_" if key else ""
+    te = text_embed(p, pre, ids) + p[pre + "token_type_embeddings.weight"][0]
+    ie, im = visual_embed_dense(p, pre, img, cfg)
+    ie = ie + p[pre + "token_type_embeddings.weight"][image_token_type_idx]
+    x = torch.cat([te, ie], dim=1)
+    m = torch.cat([text_masks, im], dim=1)
+    for i in range(cfg["num_layers"]):
+        x = block(p, f"{pre}transformer.blocks.{i}.", x, m, cfg["num_heads"])
+    x = layer_norm(x, p[pre + "transformer.norm.weight"], p[pre + "transformer.norm.bias"], 1e-6)
+    L = ids.shape[1]
+    cls = torch.tanh(x[:, 0] @ p["pooler.dense.weight"].t() + p["pooler.dense.bias"])  # heads.py:16-20
+    return {"text_feats": x[:, :L], "image_feats": x[:, L:], "cls_feats": cls, "raw_cls_feats": x[:, 0],
+            "image_masks": im, "text_masks": text_masks, "text_ids": ids}
+
+
+def moco_head(p: Params, pre: str, cls: Tensor) -> Tensor:
+    """MOCOHead (heads.py:129-143): Linear -> LN(1e-5) -> ReLU -> Linear(no bias)."""
+    h = cls @ p[pre + "moco_head.projector.0.weight"].t() + p[pre + "moco_head.projector.0.bias"]
+    h = layer_norm(h, p[pre + "moco_head.projector.1.weight"], p[pre + "moco_head.projector.1.bias"], 1e-5)
+    return torch.relu(h) @ p[pre + "moco_head.projector.3.weight"].t()
+
+
+def l2_normalize(x: Tensor) -> Tensor:
+    """F.normalize(dim=1), eps 1e-12 (objectives.py:265,269,326)."""
+    return x / x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+
+
+def infonce_logits(q: Tensor, k: Tensor, queue: Tensor, T: float) -> Tensor:
+    """objectives.py:328-331: cat([q.k, q @ queue], 1) / T."""
+    return torch.cat([(q * k).sum(1, keepdim=True), q @ queue], dim=1) / T
+
+
+def infonce_loss(logits: Tensor) -> Tensor:
+    """CrossEntropyLoss(logits.float(), zeros) mean over batch (objectives.py:333,351)."""
+    return (torch.logsumexp(logits, dim=1) - logits[:, 0]).mean()
+
+
+def queue_metrics(q: Tensor, k: Tensor, queue: Tensor) -> dict:
+    """objectives.py:337-349 without the per-query Python loop (same values)."""
+    qt = queue.t()                                    # [Kq, P]
+    q2 = (q * q).sum(1, keepdim=True)
+    c2 = (qt * qt).sum(1)[None]
+    dots = q @ queue
+    dist = torch.sqrt((q2 + c2 - 2 * dots).clamp_min(0))
+    cos = dots / (q.norm(dim=1, keepdim=True) * qt.norm(dim=1)[None]).clamp_min(1e-6)
+    return {
+        "pos_dist": (q - k).norm(dim=1).mean(),
+        "pos_cosine": F.cosine_similarity(q, k, dim=1, eps=1e-6).mean(),
+        "pos_dot": (q * k).sum(1).mean(),
+        "neg_dist": dist.mean(), "neg_cosine": cos.mean(), "neg_dot": dots.mean(),
+    }
+
+
+def encode_q(p: Params, cfg: dict, ids, masks, img) -> Tuple[Tensor, dict]:
+    out = infer(p, cfg, ids, masks, img)
+    return l2_normalize(moco_head(p, "", out["cls_feats"])), out
+
+
+def pgd_attack(p: Params, cfg: dict, batch: dict, k: Tensor, queue: Tensor,
+               return_steps: bool = False):
+    """PGDAttack_moco.pgd_attack (attack/pgd_attack_vilt.py:130-175): K steps of
+    delta <- clamp(delta + lr * g / max(|g|_inf per sample, 1e-8), +-eps), g = d(CE/K)/d(delta)."""
+    K, lr, eps = cfg["adv_steps_img"], cfg["adv_lr_img"], cfg["adv_max_norm_img"]
+    img0 = batch["image"][0]
+    delta = torch.zeros_like(img0)
+    steps = []
+    for _ in range(K):
+        d = delta.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            q, _ = encode_q(p, cfg, batch["text_ids"], batch["text_masks"], img0 + d)
+            loss = infonce_loss(infonce_logits(q, k, queue, cfg["temperature"])) / float(K)
+            (g,) = torch.autograd.grad(loss, d)
+        den = g.abs().flatten(1).max(dim=1).values.clamp_min(1e-8).view(-1, 1, 1, 1)
+        delta = delta + lr * g / den
+        if eps > 0:
+            delta = delta.clamp(-eps, eps)
+        delta = delta.detach()
+        steps.append(delta.clone())
+    return (delta, steps) if return_steps else delta
+
+
+def ema_update(p: Params, m: float) -> None:
+    """_momentum_update_key_layer (objectives.py:219-224,257-260)."""
+    for name in list(p.keys()):
+        if name.startswith("k_"):
+            p[name] = p[name] * m + p[name[2:]] * (1.0 - m)
+
+
+def enqueue(queue: Tensor, ptr: int, keys_all: Tensor, per_step_bs: int) -> int:
+    """_dequeue_and_enqueue (objectives.py:238-248); keys_all = rank-major concat of every rank's keys."""
+    n = keys_all.shape[0]
+    if n != per_step_bs:
+        return ptr
+    queue[:, ptr:ptr + n] = keys_all.t()
+    return (ptr + n) % queue.shape[1]
+
+
+def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, ptr: int,
+                             training: bool = True, gathered_keys=None) -> dict:
+    """objectives.compute_moco_contrastive (objectives.py:217-447), image view.
+
+    Mutates ``p`` (EMA of k_*) and ``queue``.  Returns the loss (with autograd graph onto the
+    query params that have requires_grad), logits, delta, metrics and the new queue pointer."""
+    if not (cfg["image_view"] or cfg["text_view"]):
+        raise ZeroDivisionError("loss / loss_num with both views off (objectives.py:250-251,397)")
+    ema_update(p, cfg["momentum"])
+    ids, masks, img = batch["text_ids"], batch["text_masks"], batch["image"][0]
+    with torch.no_grad():
+        out_k = infer(p, cfg, ids, masks, img, key=True)
+        k = l2_normalize(moco_head(p, "k_", out_k["cls_feats"]))
+    q0, _ = encode_q(p, cfg, ids, masks, img)
+    T = cfg["temperature"]
+    neg = queue.clone().detach()
+    logits0 = infonce_logits(q0, k, neg, T)
+    pred0 = logits0.argmax(-1)
+    ret = {"k": k, "q_original": q0.detach(), "logits_original": logits0.detach()}
+    loss, n = 0.0, 0
+    if cfg["image_view"]:
+        pd = {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in p.items()}
+        delta, steps = pgd_attack(pd, cfg, batch, k, neg, return_steps=True)
+        # Reference quirk: pgd_attack overwrites the (deep-copied) batch image in place with
+        # img_init + delta_{K-1} on its last iteration (pgd_attack_vilt.py:144) and compute_pgd then
+        # adds the returned delta_K on top (objectives.py:176), so the attacked view is
+        # img + delta_{K-1} + delta_K (delta_0 = 0), i.e. up to 2*eps away from the clean image.
+        prev = steps[-2] if len(steps) >= 2 else torch.zeros_like(delta)
+        attacked = img + prev + delta
+        qa, _ = encode_q(p, cfg, ids, masks, attacked)
+        la = infonce_logits(qa, k, neg, T)
+        li = infonce_loss(la)
+        loss, n = loss + li, n + 1
+        m = queue_metrics(qa.detach(), k, neg)
+        ret.update({f"{a}_attacked_img": b for a, b in m.items()})
+        ret.update({"delta": delta, "attacked_image": attacked, "q_img_attack": qa.detach(), "logits_img_attack": la.detach(),
+                    "pgd_success_rate": (la.argmax(-1) != pred0).float().mean(),
+                    "delta_range": delta.norm(dim=1).mean()})          # objectives.py:184
+    if training:
+        keys_all = k if gathered_keys is None else gathered_keys
+        ptr = enqueue(queue, ptr, keys_all, cfg["num_gpus"] * cfg["num_nodes"] * cfg["per_gpu_batchsize"])
+    ret["moco_loss"] = loss / n
+    ret["ptr"] = ptr
+    return ret
+
+
+# --------------------------------------------------------------------------------------
+# ITM + word-patch alignment (BASELINE configs 1-2)
+# --------------------------------------------------------------------------------------
+
+def ipot(C, x_len, x_pad, y_len, y_pad, joint_pad, beta: float, iteration: int, k: int) -> Tensor:
+    """IPOT (objectives.py:46-76). C [B,M,N]; returns T [B,N,M]."""
+    b, m, n = C.shape
+    sigma = torch.ones(b, m, dtype=C.dtype) / x_len[:, None]
+    T = torch.ones(b, n, m, dtype=C.dtype)
+    A = torch.exp(-C.transpose(1, 2) / beta)
+    sigma = sigma.masked_fill(x_pad, 0)
+    jp = joint_pad.transpose(1, 2)
+    T = T.masked_fill(jp, 0)
+    A = A.masked_fill(jp, 0)
+    xl, yl = x_len[:, None, None], y_len[:, None, None]
+    xm = (x_pad.to(C.dtype) * 1e4)[:, None]
+    ym = (y_pad.to(C.dtype) * 1e4)[:, None]
+    for _ in range(iteration):
+        Q = A * T
+        sigma = sigma.view(b, m, 1)
+        for _ in range(k):
+            delta = 1 / (yl * Q.matmul(sigma).view(b, 1, n) + ym)
+            sigma = 1 / (xl * delta.matmul(Q) + xm)
+        T = delta.view(b, n, 1) * Q * sigma
+    return T.masked_fill(jp, 0)
+
+
+def compute_itm_wpa(p: Params, cfg: dict, batch: dict, itm_labels: Tensor) -> dict:
+    """compute_itm_wpa (objectives.py:714-787) with the random 50/50 labels supplied by the caller
+    (the reference draws them with randperm :715-720)."""
+    imgs = torch.stack([batch["image"][0][i] if itm_labels[i] == 1 else batch["false_image_0"][0][i]
+                        for i in range(itm_labels.shape[0])])
+    out = infer(p, cfg, batch["text_ids"], batch["text_masks"], imgs)
+    txt_emb, img_emb = out["text_feats"], out["image_feats"]
+    txt_mask, img_mask = out["text_masks"].bool().clone(), out["image_masks"].bool().clone()
+    for i, n in enumerate(txt_mask.sum(dim=1)):
+        txt_mask[i, n - 1] = False
+    txt_mask[:, 0] = False
+    img_mask[:, 0] = False
+    txt_pad, img_pad = ~txt_mask, ~img_mask
+    xn = txt_emb / txt_emb.norm(dim=-1, keepdim=True).clamp_min(1e-5)       # objectives.py:24-34
+    yn = img_emb / img_emb.norm(dim=-1, keepdim=True).clamp_min(1e-5)
+    cost = 1 - xn @ yn.transpose(1, 2)
+    joint_pad = txt_pad[:, :, None] | img_pad[:, None, :]
+    cost = cost.masked_fill(joint_pad, 0)
+    txt_len = (txt_pad.shape[1] - txt_pad.sum(1)).to(cost.dtype)
+    img_len = (img_pad.shape[1] - img_pad.sum(1)).to(cost.dtype)
+    T = ipot(cost.detach(), txt_len, txt_pad, img_len, img_pad, joint_pad, 0.5, 50, 1)
+    distance = torch.einsum("bmn,bnm->b", cost, T.detach())                  # trace(cost @ T) :37-43,761
+    pos, neg = distance[itm_labels == 1], distance[itm_labels == 0]
+    ot_loss = (pos.sum() - neg.sum()) / (pos.shape[0] + neg.shape[0])
+    logits = out["cls_feats"] @ p["itm_score.fc.weight"].t() + p["itm_score.fc.bias"]
+    lab = itm_labels.long()
+    itm_loss = (torch.logsumexp(logits, 1) - logits.gather(1, lab[:, None])[:, 0]).mean()
+    return {"itm_loss": itm_loss, "itm_wpa_loss": 0.1 * ot_loss, "itm_logits": logits,
+            "itm_labels": itm_labels, "ot_T": T, "ot_cost": cost.detach(), "cls_feats": out["cls_feats"]}
+
+
+# --------------------------------------------------------------------------------------
+# optimiser ("next" row f1): HF AdamW as used by vilt_utils.set_schedule (:331-437)
+# --------------------------------------------------------------------------------------
+
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight",
+            "norm1.bias", "norm1.weight", "norm2.bias", "norm2.weight")
+HEAD_NAMES = ("vqa_classifier", "nlvr2_classifier", "moco_head", "barlowtwinshead")
+
+
+def param_group(name: str) -> Tuple[bool, bool]:
+    """(decay?, head?) group membership by substring match (vilt_utils.py:335-393)."""
+    return (not any(nd in name for nd in NO_DECAY)), any(h in name for h in HEAD_NAMES)
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, wd: float,
+               b1: float = 0.9, b2: float = 0.98, eps: float = 1e-8) -> None:
+    """transformers.AdamW (pinned 4.2.1, requirements.txt:2) single-tensor step: bias-corrected
+    Adam update, then decoupled decay p -= lr*wd*p applied AFTER the update."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+    p.addcdiv_(m, v.sqrt().add_(eps), value=-step_size)
+    if wd > 0:
+        p.add_(p, alpha=-lr * wd)
+
+
+def poly_lr(step: int, base_lr: float, warmup: int, total: int, end_lr: float, power: float) -> float:
+    """get_polynomial_decay_schedule_with_warmup (HF optimization.py) as called at vilt_utils.py:423-430."""
+    if step < warmup:
+        return base_lr * step / max(1, warmup)
+    if step > total:
+        return end_lr
+    rem = 1 - (step - warmup) / (total - warmup)
+    return (base_lr - end_lr) * rem ** power + end_lr
