@@ -1,0 +1,159 @@
+/* rmcl.h - C ABI of librmcl_hip.so: the MI355X (gfx950) hot path of the RMCL training step.
+ *
+ * The reference (stanFurrer/Robust-Multimodal-Contrastive-Learning) is 100 % Python and has no
+ * FFI; its boundary for this path is the Python protocol `vilt.modules.ViLTransformerSS`
+ * (vilt/modules/vilt_module.py:20-507) + the free functions in vilt/modules/objectives.py and
+ * attack/pgd_attack_vilt.py.  This header is the C boundary a maintainer binds underneath that
+ * protocol (ctypes stub: INTEGRATION.md).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless noted; no entry point allocates, frees or synchronises;
+ *    work is enqueued on `stream` (a hipStream_t passed as void*); the caller keeps buffers alive
+ *    until the stream has drained.
+ *  - return value: 0 on success, otherwise a hipError_t value or -1 (argument check);
+ *    rmcl_last_error() returns the message (thread-local, host string).
+ *  - dtype codes: RMCL_F32 = 0, RMCL_BF16 = 1 (raw bfloat16 bits in uint16_t).
+ *  - "arena": all parameters of one encoder live in ONE flat fp32 buffer whose element offsets are
+ *    given by rmcl_param_layout(); the optional low-precision shadow arena has the same offsets.
+ */
+#ifndef RMCL_H
+#define RMCL_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMCL_F32 0
+#define RMCL_BF16 1
+
+#define RMCL_MODE_INFER 0 /* no activations kept (momentum encoder, clean query) */
+#define RMCL_MODE_DATA 1  /* keep what the data-gradient (PGD) backward needs     */
+#define RMCL_MODE_FULL 2  /* keep what the weight-gradient backward needs too     */
+
+typedef struct rmcl_dims {
+  int B;        /* samples in this pass                                              */
+  int L;        /* text tokens per sample (max_text_len, 40)                         */
+  int P;        /* image patches per sample ((384/32)^2 = 144)                       */
+  int D;        /* hidden size 768                                                   */
+  int H;        /* heads 12 (head dim D/H must be 64)                                */
+  int layers;   /* 12                                                                */
+  int mlp;      /* 3072                                                              */
+  int patch_k;  /* 3*32*32 = 3072 (K of the patch-embedding GEMM)                    */
+  int proj;     /* MoCo projection dim 128                                           */
+  int vocab;    /* 30522                                                             */
+  int dtype;    /* RMCL_F32 or RMCL_BF16: operand type of the encoder GEMMs          */
+  int exact;    /* 1: force the exact-f32 matrix-core GEMM (bf16 operands widened)   */
+} rmcl_dims;
+
+/* Element offsets into a parameter arena.  Names follow the reference state dict. */
+typedef struct rmcl_layout {
+  int64_t word, pos, btype, eln_w, eln_b;      /* text_embeddings.{word,position,token_type}_embeddings, LayerNorm */
+  int64_t vtype;                               /* token_type_embeddings.weight [2,D]                               */
+  int64_t cls, pos_img, patch_w, patch_b;      /* transformer.{cls_token,pos_embed,patch_embed.proj.*}             */
+  int64_t layer0, layer_stride;                /* transformer.blocks.<i> base = layer0 + i*layer_stride            */
+  int64_t ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b; /* rel. to block */
+  int64_t norm_w, norm_b;                      /* transformer.norm                                                 */
+  int64_t mh0_w, mh0_b, mh1_w, mh1_b, mh3_w;   /* moco_head.projector.{0,1,3}                                      */
+  int64_t ema_end;                             /* [0, ema_end) is the range the momentum update covers             */
+  int64_t pool_w, pool_b;                      /* pooler.dense (query side only; vilt_module.py:405)               */
+  int64_t itm_w, itm_b;                        /* itm_score.fc                                                     */
+  int64_t total;
+} rmcl_layout;
+
+const char* rmcl_last_error(void);
+int rmcl_version(void);
+
+void rmcl_param_layout(const rmcl_dims* d, rmcl_layout* out);
+int64_t rmcl_stash_bytes(const rmcl_dims* d, int mode);
+int64_t rmcl_workspace_bytes(const rmcl_dims* d);
+int64_t rmcl_heads_stash_bytes(const rmcl_dims* d);
+
+/* ---- path-level entry points --------------------------------------------------------------- */
+
+/* image [B,3,Hh,Ww] f32 -> patch rows [B*(Hh/ps)*(Ww/ps), 3*ps*ps] f32 (to_image=0) or back (1).
+ * GEMM view of PatchEmbed's Conv2d (vilt/modules/vision_transformer.py:397-409).                */
+int rmcl_im2patch_f32(const float* img, float* patches, int B, int C, int Hh, int Ww, int ps, int to_image, void* stream);
+
+/* out[dtype] = a + d1 + d2 (d1/d2 may be NULL): `img_init + img_delta` (attack/pgd_attack_vilt.py:144)
+ * and the attacked view of objectives.py:176, fused with the cast to the GEMM operand type.      */
+int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* out, int dtype, int64_t n, void* stream);
+
+/* One joint text+image encoder forward up to transformer.norm: replaces ViLTransformerSS.infer /
+ * infer_k (vilt_module.py:275-418) minus the pooler.  params32: fp32 arena; params_lp: bf16
+ * shadow arena (NULL when dtype is F32).  text_ids/text_mask [B,L] int64; patches [B*P,patch_k]
+ * in `dtype`; co_mask out [B,N] int32 (N = L+1+P); xn out [B*N, D] f32.                          */
+int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
+                         const int64_t* text_ids, const int64_t* text_mask, const void* patches,
+                         int32_t* co_mask, void* stash, void* workspace, float* xn, void* stream);
+
+/* Backward of the above.  dxn: gradient wrt xn, [B*N,D] f32, or [B,D] (row 0 of every sample)
+ * when cls_only=1.  dpatches (optional) receives d loss/d patches [B*P,patch_k] in `dtype`
+ * (the PGD data gradient, attack/pgd_attack_vilt.py:160-162).  grads32 (mode FULL): gradient
+ * arena, accumulated into (+=), same layout as the parameter arena.                              */
+int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
+                          const int64_t* text_ids, const void* patches, const int32_t* co_mask,
+                          void* stash, void* workspace, const float* dxn, int cls_only,
+                          void* dpatches, float* grads32, void* stream);
+
+/* Pooler + MoCo head + L2 normalise (vilt/modules/heads.py:10-20,129-143; objectives.py:264-269).
+ * pool32: arena that owns the pooler (always the query arena); head32: arena that owns the
+ * moco head (query or momentum).  Outputs cls_feats [B,D] and q [B,proj] (f32).                  */
+int rmcl_heads_forward(const rmcl_dims* d, const float* pool32, const float* head32, const float* xn,
+                       void* hstash, float* cls_feats, float* q, void* stream);
+/* dq [B,proj] (may be NULL) and dcls_extra [B,D] (may be NULL, e.g. from the ITM head) -> dcls [B,D];
+ * grads32 (may be NULL) accumulates pooler and moco-head weight gradients.                       */
+int rmcl_heads_backward(const rmcl_dims* d, const float* pool32, const float* head32, void* hstash,
+                        const float* dq, const float* dcls_extra, float* dcls, float* grads32, void* workspace, void* stream);
+
+/* Fused InfoNCE forward + dq + queue metrics (objectives.py:328-351, pgd_attack_vilt.py:152-158).
+ * rows_out [B,10]: loss_i, argmax, l_pos, pos_dist, pos_cos, pos_dot, neg_dist, neg_cos, neg_dot, lse.
+ * loss_sum (optional, 1 float, += mean loss).  workspace: rmcl_infonce_ws_bytes(B,Kq) bytes.      */
+int64_t rmcl_infonce_ws_bytes(int B, int64_t Kq);
+int rmcl_infonce_f32(const float* q, const float* k, const float* queue, int B, int proj, int64_t Kq, float temperature,
+                     float grad_scale, float* dq, float* rows_out, float* loss_sum, void* workspace, void* stream);
+
+/* PGD ascent step in patch layout (attack/pgd_attack_vilt.py:162-173).  amax_scratch: B uint32.  */
+int rmcl_pgd_step(const void* grad, int dtype, float* delta, uint32_t* amax_scratch, int B, int64_t per_sample,
+                  float lr, float eps, void* stream);
+/* sum over (row, pixel) of the channel-wise L2 norm of delta (objectives.py:184); out += sum     */
+int rmcl_delta_channel_norm(const float* delta, float* out, int64_t rows, int C, int pp, void* stream);
+
+/* Momentum update k = m*k + (1-m)*q over n arena elements (objectives.py:219-224,257-260);
+ * k_lp (optional) refreshed bf16 shadow.                                                         */
+int rmcl_ema_f32(float* k, const float* q, void* k_lp, float m, int64_t n, void* stream);
+/* queue[:, ptr:ptr+n] = keys^T (objectives.py:244-246); queue [proj,Kq] f32, keys [n,proj] f32.  */
+int rmcl_enqueue_f32(float* queue, const float* keys, int n, int proj, int64_t Kq, int64_t ptr, void* stream);
+/* f32 -> dtype cast of n elements (bf16 weight shadow refresh).                                  */
+int rmcl_cast_f32(const float* in, void* out, int dtype, int64_t n, void* stream);
+
+/* Fused AdamW over flat arenas ("next" row f1; vilt/modules/vilt_utils.py:395-398, HF AdamW).    */
+int rmcl_adamw_f32(float* p, const float* g, float* m, float* v, void* p_lp, const int64_t* seg_end,
+                   const float* seg_lr_mult, const float* seg_wd, int nseg, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, int64_t n, void* stream);
+
+/* ITM + word-patch alignment (objectives.py:24-76,714-787): masked cosine cost and IPOT.          */
+int rmcl_ipot_f32(const float* cost, const int32_t* txt_valid, const int32_t* img_valid, float* T, int B, int Lt, int Li,
+                  float beta, int iters, void* stream);
+
+/* ---- kernel-level entry points (unit parity tests) ----------------------------------------- */
+/* C = epilogue(alpha * op(A) op(B)); layout kinds and epilogue flags: csrc/gemm.h                 */
+int rmcl_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K,
+              int64_t lda, int64_t ldb, int ldc, int ld_aux, float alpha, int epi, int splitk, int dt_in, int dt_out,
+              int a_kc, int b_kc, int exact, void* stream);
+int rmcl_layernorm_fwd(const float* x, const float* w, const float* b, float eps, void* y, int dt_out, float* mean,
+                       float* rstd, int M, int D, int relu, void* stream);
+int rmcl_layernorm_bwd(const void* dy, int dt_dy, const float* x, const float* mean, const float* rstd, const float* w,
+                       const float* b, float* dx, int add, float* dgamma, float* dbeta, int M, int D, int relu, void* stream);
+/* Masked multi-head self-attention on a packed qkv [B*N, 3*H*64] (Attention.forward,
+ * vision_transformer.py:309-332).  out [B*N, H*64]; probs (stash) and scores (scratch) sized by
+ * rmcl_attention_scratch_elems.                                                                  */
+int64_t rmcl_attention_scratch_elems(int B, int H, int N);
+int rmcl_attention_fwd(const void* qkv, const int32_t* mask, void* out, void* probs, float* scores, int B, int N, int H,
+                       int dtype, int exact, void* stream);
+int rmcl_attention_bwd(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dscores,
+                       int B, int N, int H, int dtype, int exact, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMCL_H */

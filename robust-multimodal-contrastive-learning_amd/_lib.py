@@ -1,0 +1,75 @@
+"""ctypes binding of librmcl_hip.so (C ABI: include/rmcl.h).  No fallback: a missing or stale
+library raises immediately."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librmcl_hip.so")
+
+F32, BF16 = 0, 1
+MODE_INFER, MODE_DATA, MODE_FULL = 0, 1, 2
+EPI_BIAS, EPI_GELU, EPI_SAVE_PREACT, EPI_RESIDUAL, EPI_DGELU, EPI_ATOMIC, EPI_ACCUM, EPI_TANH = 1, 2, 4, 8, 16, 32, 64, 128
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("B", "L", "P", "D", "H", "layers", "mlp", "patch_k", "proj", "vocab", "dtype", "exact")]
+
+
+LAYOUT_FIELDS = ("word", "pos", "btype", "eln_w", "eln_b", "vtype", "cls", "pos_img", "patch_w", "patch_b",
+                 "layer0", "layer_stride", "ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b",
+                 "fc1_w", "fc1_b", "fc2_w", "fc2_b", "norm_w", "norm_b", "mh0_w", "mh0_b", "mh1_w", "mh1_b", "mh3_w",
+                 "ema_end", "pool_w", "pool_b", "itm_w", "itm_b", "total")
+
+
+class Layout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in LAYOUT_FIELDS]
+
+
+class RmclError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RmclError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  rmcl_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.rmcl_last_error.restype = C.c_char_p
+    for name in ("rmcl_stash_bytes", "rmcl_workspace_bytes", "rmcl_heads_stash_bytes", "rmcl_infonce_ws_bytes",
+                 "rmcl_attention_scratch_elems"):
+        getattr(lib, name).restype = C.c_int64
+    return lib
+
+
+lib = _load()
+
+# every symbol include/rmcl.h declares (checked by tests/test_abi.py against the header text)
+EXPORTS = (
+    "rmcl_last_error", "rmcl_version", "rmcl_param_layout", "rmcl_stash_bytes", "rmcl_workspace_bytes",
+    "rmcl_heads_stash_bytes", "rmcl_im2patch_f32", "rmcl_add_cast_f32", "rmcl_encoder_forward", "rmcl_encoder_backward",
+    "rmcl_heads_forward", "rmcl_heads_backward", "rmcl_infonce_ws_bytes", "rmcl_infonce_f32", "rmcl_pgd_step",
+    "rmcl_delta_channel_norm", "rmcl_ema_f32", "rmcl_enqueue_f32", "rmcl_cast_f32", "rmcl_adamw_f32", "rmcl_ipot_f32",
+    "rmcl_gemm", "rmcl_layernorm_fwd", "rmcl_layernorm_bwd", "rmcl_attention_scratch_elems", "rmcl_attention_fwd",
+    "rmcl_attention_bwd",
+)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.rmcl_last_error()
+        raise RmclError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def P(t):
+    """device pointer of a torch tensor (or NULL)"""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def I64(v):
+    return C.c_int64(int(v))
+
+
+def F(v):
+    return C.c_float(float(v))

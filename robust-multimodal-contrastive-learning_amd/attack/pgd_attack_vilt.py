@@ -1,0 +1,58 @@
+"""PGD image attack on the MoCo objective.  Mirrors attack/pgd_attack_vilt.py:7-175 of the
+reference (class names, constructor keys, ``pgd_attack(pl_module, batch, k_modality)`` -> delta),
+but runs K x (encoder forward, InfoNCE, data-gradient backward, L-inf-normalised ascent step,
+eps-projection) as HIP kernels with no deepcopy of the encoder and no weight-gradient work."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+
+
+class PGDAttack:
+    def __init__(self, config, contrastive_framework):
+        self.contrastive_framework = contrastive_framework
+        self.adv_steps_img = config["adv_steps_img"]
+        self.adv_lr_img = config["adv_lr_img"]
+        self.adv_max_norm_img = config["adv_max_norm_img"]
+        self.max_image_len = config["max_image_len"]
+
+    def pgd_attack(self, pl_module, batch, k_image):
+        raise NotImplementedError(f"pgd_attack of {self.contrastive_framework} isn't implemented.")
+
+
+class PGDAttack_moco(PGDAttack):
+    def __init__(self, config):
+        super().__init__(config, "moco")
+
+    def attack_patches(self, pl_module, pb, k: torch.Tensor):
+        """K-step attack in patch layout.  Leaves delta_K in ``pb.delta`` and delta_{K-1} in
+        ``pb.delta_prev`` (needed for the reference's attacked view, see compute_pgd)."""
+        eng = pl_module.engine
+        K = self.adv_steps_img
+        pb.delta.zero_()                                      # pgd_attack_vilt.py:136
+        pb.delta_prev.zero_()
+        if k.data_ptr() != pb.k.data_ptr():
+            pb.k.copy_(k)
+        for step in range(K):
+            if step == K - 1 and K > 1:
+                pb.delta_prev.copy_(pb.delta)
+            op = eng.make_operand(pb, pb.delta)               # img_init + img_delta (:144)
+            eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+            eng.heads_forward(pb, key=False)
+            # CE(label 0) / K, mean over the batch (:152-158); gradient wrt q only
+            eng.infonce(pb, grad_scale=1.0 / (pb.B * K), want_dq=True)
+            eng.heads_backward(pb, pb.dq, None, with_grads=False)
+            eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=pb.gpatch)
+            eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img)   # :162-173
+        return pb.delta
+
+    def pgd_attack(self, pl_module, batch, k_modality=None):
+        eng = pl_module.engine
+        img_init = batch["image"][0]
+        pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], img_init)
+        delta_p = self.attack_patches(pl_module, pb, k_modality)
+        B = img_init.shape[0]
+        # the reference leaves batch['image'][0] = img_init + delta_{K-1} behind (:144)
+        batch["image"][0] = img_init.to(eng.device) + eng.patches_to_image(pb.delta_prev, B)
+        return eng.patches_to_image(delta_p, B)

@@ -1,0 +1,219 @@
+// extern "C" surface of librmcl_hip.so (declared in include/rmcl.h) + the heads (pooler / MoCo head)
+// forward and backward, which are tiny [B,768] problems run on the exact-f32 GEMM.
+#include "rmcl_common.h"
+#include "kernels.h"
+#include "../../include/rmcl.h"
+#include <string>
+
+static thread_local std::string g_err;
+extern "C" void rmcl_set_error(const char* msg) { g_err = msg ? msg : ""; }
+
+int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* probs, float* scores, int B, int N, int H, int dt,
+                            int exact, hipStream_t s);
+int rmcl_attention_bwd_impl(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dS, int B,
+                            int N, int H, int dt, int exact, hipStream_t s);
+
+int rmcl_launch_gemm(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc, int exact, hipStream_t stream) {
+  if (!exact && rmcl_gemm_fast_supported(g, dt_in, dt_out, a_kc, b_kc)) return rmcl_launch_gemm_fast(g, dt_out, a_kc, b_kc, stream);
+  return rmcl_launch_gemm_exact(g, dt_in, dt_out, a_kc, b_kc, stream);
+}
+
+namespace {
+struct HeadStash {
+  float *cls_in, *pooled, *h1, *mean, *rstd, *h2r, *z, *q, *nrm;
+};
+size_t carve_heads(const rmcl_dims& d, void* base, HeadStash* hs) {
+  char* b = reinterpret_cast<char*>(base);
+  size_t off = 0;
+  auto take = [&](size_t n) { off = (off + 255) & ~(size_t)255; float* p = b ? reinterpret_cast<float*>(b + off) : nullptr; off += n * 4; return p; };
+  HeadStash h;
+  const size_t B = d.B, D = d.D;
+  h.cls_in = take(B * D); h.pooled = take(B * D); h.h1 = take(B * D);
+  h.mean = take(B); h.rstd = take(B); h.h2r = take(B * D);
+  h.z = take(B * d.proj); h.q = take(B * d.proj); h.nrm = take(B);
+  if (hs) *hs = h;
+  return off;
+}
+GemmArgs ga(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, int ldc) {
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = 1.f; g.splitk = 1; g.nb1 = 1; g.nb2 = 1;
+  return g;
+}
+}  // namespace
+
+extern "C" {
+
+const char* rmcl_last_error(void) { return g_err.c_str(); }
+int rmcl_version(void) { return 1; }
+
+int64_t rmcl_heads_stash_bytes(const rmcl_dims* d) { return (int64_t)carve_heads(*d, nullptr, nullptr) + 256; }
+
+int rmcl_heads_forward(const rmcl_dims* d, const float* pool32, const float* head32, const float* xn, void* hstash,
+                       float* cls_feats, float* q, void* stream) {
+  RMCL_REQUIRE(d && pool32 && xn && hstash && cls_feats, "heads_forward: NULL argument");
+  rmcl_layout y;
+  rmcl_param_layout(d, &y);
+  HeadStash h;
+  carve_heads(*d, hstash, &h);
+  hipStream_t s = (hipStream_t)stream;
+  const int B = d->B, D = d->D, N = d->L + 1 + d->P;
+  RMCL_TRY(rmcl_gather_rows(xn, h.cls_in, B, D, 1, N, 0, s));                      // hidden_states[:, 0] (heads.py:17)
+  {
+    GemmArgs g = ga(h.cls_in, pool32 + y.pool_w, h.pooled, B, D, D, D, D, D);
+    g.epi = EPI_BIAS | EPI_TANH; g.bias = pool32 + y.pool_b;
+    RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
+  }
+  hipError_t e = hipMemcpyAsync(cls_feats, h.pooled, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+  if (!q) return 0;
+  RMCL_REQUIRE(head32, "heads_forward: head arena is NULL");
+  {
+    GemmArgs g = ga(h.pooled, head32 + y.mh0_w, h.h1, B, D, D, D, D, D);
+    g.epi = EPI_BIAS; g.bias = head32 + y.mh0_b;
+    RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
+  }
+  RMCL_TRY(rmcl_ln_fwd(h.h1, D, head32 + y.mh1_w, head32 + y.mh1_b, 1e-5f, h.h2r, D, RMCL_F32, h.mean, h.rstd, B, D, 1, s));
+  {
+    GemmArgs g = ga(h.h2r, head32 + y.mh3_w, h.z, B, d->proj, D, D, D, d->proj);
+    RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
+  }
+  RMCL_TRY(rmcl_l2norm_fwd(h.z, h.q, h.nrm, B, d->proj, 1e-12f, s));
+  e = hipMemcpyAsync(q, h.q, (size_t)B * d->proj * 4, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+int rmcl_heads_backward(const rmcl_dims* d, const float* pool32, const float* head32, void* hstash, const float* dq,
+                        const float* dcls_extra, float* dcls, float* G, void* workspace, void* stream) {
+  RMCL_REQUIRE(d && pool32 && hstash && dcls && workspace, "heads_backward: NULL argument");
+  rmcl_layout y;
+  rmcl_param_layout(d, &y);
+  HeadStash h;
+  carve_heads(*d, hstash, &h);
+  hipStream_t s = (hipStream_t)stream;
+  const int B = d->B, D = d->D, Pd = d->proj;
+  // scratch (all [B,D] f32) carved from the start of the encoder workspace
+  float* t0 = reinterpret_cast<float*>(workspace);
+  float* t1 = t0 + (size_t)B * D;
+  float* t2 = t1 + (size_t)B * D;
+  hipError_t e;
+  if (dq) {
+    RMCL_REQUIRE(head32, "heads_backward: head arena is NULL");
+    RMCL_TRY(rmcl_l2norm_bwd(dq, h.q, h.nrm, t0, B, Pd, s));                            // dz
+    if (G) {
+      GemmArgs g = ga(t0, h.h2r, G + y.mh3_w, Pd, D, B, Pd, D, D);                       // dW3 += dz^T h2r
+      g.epi = EPI_ACCUM;
+      RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
+    }
+    {
+      GemmArgs g = ga(t0, head32 + y.mh3_w, t1, B, D, Pd, Pd, D, D);                     // dh2r = dz W3
+      RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 0, s));
+    }
+    RMCL_TRY(rmcl_ln_bwd(t1, D, RMCL_F32, h.h1, D, h.mean, h.rstd, head32 + y.mh1_w, head32 + y.mh1_b, t2, D, 0,
+                         G ? G + y.mh1_w : nullptr, G ? G + y.mh1_b : nullptr, B, D, 1, s));   // dh1 (ReLU mask inside)
+    if (G) {
+      GemmArgs g = ga(t2, h.pooled, G + y.mh0_w, D, D, B, D, D, D);                      // dW0 += dh1^T pooled
+      g.epi = EPI_ACCUM;
+      RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
+      RMCL_TRY(rmcl_colsum(t2, D, RMCL_F32, G + y.mh0_b, B, D, s));
+    }
+    {
+      GemmArgs g = ga(t2, head32 + y.mh0_w, t0, B, D, D, D, D, D);                       // dpooled = dh1 W0
+      RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 0, s));
+    }
+    if (dcls_extra) RMCL_TRY(rmcl_scatter_rows(dcls_extra, t0, B, D, B, 0, 0, 1, s));    // += gradient from other heads
+  } else {
+    RMCL_REQUIRE(dcls_extra, "heads_backward: neither dq nor dcls_extra given");
+    e = hipMemcpyAsync(t0, dcls_extra, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+  }
+  RMCL_TRY(rmcl_tanh_bwd(t0, h.pooled, (long)B * D, s));                                  // through tanh
+  if (G) {
+    GemmArgs g = ga(t0, h.cls_in, G + y.pool_w, D, D, B, D, D, D);                        // dWp += dpre^T cls_in
+    g.epi = EPI_ACCUM;
+    RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
+    RMCL_TRY(rmcl_colsum(t0, D, RMCL_F32, G + y.pool_b, B, D, s));
+  }
+  {
+    GemmArgs g = ga(t0, pool32 + y.pool_w, dcls, B, D, D, D, D, D);                       // dcls = dpre Wp
+    RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 0, s));
+  }
+  return 0;
+}
+
+int rmcl_im2patch_f32(const float* img, float* patches, int B, int C, int Hh, int Ww, int ps, int to_image, void* stream) {
+  return rmcl_im2patch(img, patches, B, C, Hh, Ww, ps, to_image, (hipStream_t)stream);
+}
+int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* out, int dtype, int64_t n, void* stream) {
+  RMCL_REQUIRE(a && out, "add_cast: NULL argument");
+  return rmcl_k_add_cast(a, d1, d2, out, dtype, n, (hipStream_t)stream);
+}
+int64_t rmcl_infonce_ws_bytes(int B, int64_t Kq) { return rmcl_infonce_workspace_bytes(B, Kq) + 256; }
+int rmcl_infonce_f32(const float* q, const float* k, const float* queue, int B, int proj, int64_t Kq, float temperature,
+                     float grad_scale, float* dq, float* rows_out, float* loss_sum, void* workspace, void* stream) {
+  RMCL_REQUIRE(q && k && queue && rows_out && workspace, "infonce: NULL argument");
+  return rmcl_infonce(q, k, queue, B, proj, Kq, temperature, grad_scale, dq, rows_out, loss_sum, workspace, (hipStream_t)stream);
+}
+int rmcl_pgd_step(const void* grad, int dtype, float* delta, uint32_t* amax_scratch, int B, int64_t per_sample, float lr,
+                  float eps, void* stream) {
+  RMCL_REQUIRE(grad && delta && amax_scratch, "pgd_step: NULL argument");
+  return rmcl_pgd_update(grad, dtype, delta, amax_scratch, B, per_sample, lr, eps, (hipStream_t)stream);
+}
+int rmcl_delta_channel_norm(const float* delta, float* out, int64_t rows, int C, int pp, void* stream) {
+  return rmcl_delta_chan_norm(delta, out, rows, C, pp, (hipStream_t)stream);
+}
+int rmcl_ema_f32(float* k, const float* q, void* k_lp, float m, int64_t n, void* stream) {
+  RMCL_REQUIRE(k && q, "ema: NULL argument");
+  return rmcl_ema(k, q, k_lp, m, n, (hipStream_t)stream);
+}
+int rmcl_enqueue_f32(float* queue, const float* keys, int n, int proj, int64_t Kq, int64_t ptr, void* stream) {
+  RMCL_REQUIRE(queue && keys, "enqueue: NULL argument");
+  return rmcl_enqueue(queue, keys, n, proj, Kq, ptr, (hipStream_t)stream);
+}
+int rmcl_cast_f32(const float* in, void* out, int dtype, int64_t n, void* stream) {
+  return rmcl_cast(in, out, dtype, n, (hipStream_t)stream);
+}
+int rmcl_adamw_f32(float* p, const float* g, float* m, float* v, void* p_lp, const int64_t* seg_end, const float* seg_lr_mult,
+                   const float* seg_wd, int nseg, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                   int64_t n, void* stream) {
+  RMCL_REQUIRE(p && g && m && v && seg_end && seg_lr_mult && seg_wd, "adamw: NULL argument");
+  return rmcl_adamw(p, g, m, v, p_lp, (const long*)seg_end, seg_lr_mult, seg_wd, nseg, lr, beta1, beta2, eps, step, grad_scale, n,
+                    (hipStream_t)stream);
+}
+int rmcl_ipot_f32(const float* cost, const int32_t* txt_valid, const int32_t* img_valid, float* T, int B, int Lt, int Li,
+                  float beta, int iters, void* stream) {
+  return rmcl_ipot(cost, txt_valid, img_valid, T, B, Lt, Li, beta, iters, (hipStream_t)stream);
+}
+
+int rmcl_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K,
+              int64_t lda, int64_t ldb, int ldc, int ld_aux, float alpha, int epi, int splitk, int dt_in, int dt_out, int a_kc,
+              int b_kc, int exact, void* stream) {
+  RMCL_REQUIRE(A && B && C, "gemm: NULL operand");
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.aux = aux;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ld_aux = ld_aux;
+  g.alpha = alpha; g.epi = epi; g.splitk = splitk < 1 ? 1 : splitk; g.nb1 = 1; g.nb2 = 1;
+  return rmcl_launch_gemm(g, dt_in, dt_out, a_kc, b_kc, exact, (hipStream_t)stream);
+}
+int rmcl_layernorm_fwd(const float* x, const float* w, const float* b, float eps, void* y, int dt_out, float* mean, float* rstd,
+                       int M, int D, int relu, void* stream) {
+  return rmcl_ln_fwd(x, D, w, b, eps, y, D, dt_out, mean, rstd, M, D, relu, (hipStream_t)stream);
+}
+int rmcl_layernorm_bwd(const void* dy, int dt_dy, const float* x, const float* mean, const float* rstd, const float* w,
+                       const float* b, float* dx, int add, float* dgamma, float* dbeta, int M, int D, int relu, void* stream) {
+  return rmcl_ln_bwd(dy, D, dt_dy, x, D, mean, rstd, w, b, dx, D, add, dgamma, dbeta, M, D, relu, (hipStream_t)stream);
+}
+int64_t rmcl_attention_scratch_elems(int B, int H, int N) { return (int64_t)B * H * N * ((N + 7) / 8 * 8); }
+int rmcl_attention_fwd(const void* qkv, const int32_t* mask, void* out, void* probs, float* scores, int B, int N, int H, int dtype,
+                       int exact, void* stream) {
+  RMCL_REQUIRE(qkv && mask && out && probs && scores, "attention_fwd: NULL argument");
+  return rmcl_attention_fwd_impl(qkv, mask, out, probs, scores, B, N, H, dtype, exact, (hipStream_t)stream);
+}
+int rmcl_attention_bwd(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dscores, int B, int N,
+                       int H, int dtype, int exact, void* stream) {
+  RMCL_REQUIRE(qkv && probs && dout && dqkv && scores && dscores, "attention_bwd: NULL argument");
+  return rmcl_attention_bwd_impl(qkv, probs, dout, dqkv, scores, dscores, B, N, H, dtype, exact, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds librmcl_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [-j N]
+set -e
+cd "$(dirname "$0")"
+OUT=../lib
+mkdir -p "$OUT" obj
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast"
+pids=()
+for f in gemm_exact.hip gemm_fast.hip norm_softmax.hip embed_misc.hip infonce.hip ipot.hip attention.hip encoder.cpp api.cpp; do
+  [ -f "$f" ] || continue
+  o=obj/${f%.*}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o")" ] || [ ../../include/rmcl.h -nt "$o" ]; then
+    ( hipcc $FLAGS -x hip -c "$f" -o "$o" ) &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC obj/*.o -o "$OUT/librmcl_hip.so"
+echo "built $OUT/librmcl_hip.so"

@@ -1,0 +1,472 @@
+// Embedding, patch layout, PGD update, EMA, queue and optimiser kernels (all HBM-bound, f32 math).
+#include "rmcl_common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// Text embedding (HF BertEmbeddings + ViLT token type, vilt_module.py:293,315-321):
+//   e = word[id] + pos[t] + btype[0];  x[b*N + t] = LN_{eps}(e) * g + beta + vtype[0]
+// one wave per token row.  Optionally saves e / mean / rstd for the backward.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_embed_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ word,
+                                                             const float* __restrict__ pos, const float* __restrict__ btype0,
+                                                             const float* __restrict__ g, const float* __restrict__ beta,
+                                                             const float* __restrict__ vtype0, float eps, float* __restrict__ x,
+                                                             float* __restrict__ e_save, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int B, int L, int N, int D) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= B * L) return;
+  const int b = r / L, t = r % L;
+  const long id = ids[r];
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) {
+      const float4 a = *reinterpret_cast<const float4*>(word + id * D + c);
+      const float4 p = *reinterpret_cast<const float4*>(pos + (long)t * D + c);
+      const float4 q = *reinterpret_cast<const float4*>(btype0 + c);
+      v[i] = make_float4(a.x + q.x + p.x, a.y + q.y + p.y, a.z + q.z + p.z, a.w + q.w + p.w);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+      if (e_save) *reinterpret_cast<float4*>(e_save + (long)r * D + c) = v[i];
+    }
+  }
+  const float mu = wave_sum(s) / D;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) {
+      const float a = v[i].x - mu, bb = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+      q2 += a * a + bb * bb + cc * cc + d * d;
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q2) / D + eps);
+  if (lane == 0 && mean) { mean[r] = mu; rstd[r] = rs; }
+  float* xr = x + ((long)b * N + t) * D;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) {
+      const float4 ww = *reinterpret_cast<const float4*>(g + c), bb = *reinterpret_cast<const float4*>(beta + c);
+      const float4 tt = *reinterpret_cast<const float4*>(vtype0 + c);
+      *reinterpret_cast<float4*>(xr + c) =
+          make_float4((v[i].x - mu) * rs * ww.x + bb.x + tt.x, (v[i].y - mu) * rs * ww.y + bb.y + tt.y,
+                      (v[i].z - mu) * rs * ww.z + bb.z + tt.z, (v[i].w - mu) * rs * ww.w + bb.w + tt.w);
+    }
+  }
+}
+
+int rmcl_text_embed_fwd(const long* ids, const float* word, const float* pos, const float* btype0, const float* g,
+                        const float* beta, const float* vtype0, float eps, float* x, float* e_save, float* mean, float* rstd,
+                        int B, int L, int N, int D, hipStream_t s) {
+  RMCL_REQUIRE(D % 4 == 0 && D <= 1024, "text_embed: D must be a multiple of 4 and <= 1024");
+  hipLaunchKernelGGL(text_embed_fwd_kernel, dim3(cdiv((long)B * L, 4)), dim3(256), 0, s, ids, word, pos, btype0, g, beta, vtype0,
+                     eps, x, e_save, mean, rstd, B, L, N, D);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// Scatter-add of the embedding-sum gradient de [B*L, D] into the word / position / bert-type tables.
+// Index `pad_id` receives no gradient (nn.Embedding padding_idx of HF BertEmbeddings).
+__global__ __launch_bounds__(256) void text_embed_scatter_kernel(const long* __restrict__ ids, const float* __restrict__ de,
+                                                                 float* __restrict__ dword, float* __restrict__ dpos,
+                                                                 float* __restrict__ dbtype0, int B, int L, int D, long pad_id) {
+  const int r = blockIdx.x, t = r % L;
+  const long id = ids[r];
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float v = de[(long)r * D + c];
+    if (id != pad_id) atomicAdd(dword + id * D + c, v);
+    atomicAdd(dpos + (long)t * D + c, v);
+    atomicAdd(dbtype0 + c, v);
+  }
+}
+
+int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, float* dpos, float* dbtype0, int B, int L, int D,
+                            long pad_id, hipStream_t s) {
+  hipLaunchKernelGGL(text_embed_scatter_kernel, dim3(B * L), dim3(256), 0, s, ids, de, dword, dpos, dbtype0, B, L, D, pad_id);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// gather rows: out[r, :] = in[(r/rows_per)*stride_outer + (r%rows_per) + off, :]   (f32, D%4==0)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int D,
+                                                          int rows_per, long stride_outer, long off) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int dv = D / 4;
+  if (i >= (long)R * dv) return;
+  const int r = (int)(i / dv), c = (int)(i % dv) * 4;
+  const long src = (long)(r / rows_per) * stride_outer + (r % rows_per) + off;
+  *reinterpret_cast<float4*>(out + (long)r * D + c) = *reinterpret_cast<const float4*>(in + src * D + c);
+}
+int rmcl_gather_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, hipStream_t s) {
+  RMCL_REQUIRE(D % 4 == 0, "gather_rows: D%4");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)R * (D / 4), 256)), dim3(256), 0, s, in, out, R, D, rows_per, stride_outer, off);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+// scatter rows (inverse of gather_rows): out[src(r), :] (=|+=) in[r, :]
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int D,
+                                                           int rows_per, long stride_outer, long off, int add) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int dv = D / 4;
+  if (i >= (long)R * dv) return;
+  const int r = (int)(i / dv), c = (int)(i % dv) * 4;
+  const long dst = (long)(r / rows_per) * stride_outer + (r % rows_per) + off;
+  float4 v = *reinterpret_cast<const float4*>(in + (long)r * D + c);
+  float* p = out + dst * D + c;
+  if (add) {
+    const float4 o = *reinterpret_cast<const float4*>(p);
+    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+  }
+  *reinterpret_cast<float4*>(p) = v;
+}
+int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, int add, hipStream_t s) {
+  RMCL_REQUIRE(D % 4 == 0, "scatter_rows: D%4");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((long)R * (D / 4), 256)), dim3(256), 0, s, in, out, R, D, rows_per, stride_outer, off, add);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Image token assembly (vision_transformer.py:661-667 + vilt_module.py:315-321):
+//   x[b*N + L]         = cls + pos[0] + vtype[1]
+//   x[b*N + L + 1 + p] = pe[b*P + p] + pos[1+p] + vtype[1]      (pe already holds conv bias)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void image_assemble_fwd_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
+                                                                 const float* __restrict__ pos, const float* __restrict__ vtype1,
+                                                                 float* __restrict__ x, int B, int P, int L, int N, int D) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int dv = D / 4;
+  if (i >= (long)B * (P + 1) * dv) return;
+  const int c = (int)(i % dv) * 4;
+  const int tok = (int)((i / dv) % (P + 1)), b = (int)(i / ((long)dv * (P + 1)));
+  const float4 a = tok == 0 ? *reinterpret_cast<const float4*>(cls + c)
+                            : *reinterpret_cast<const float4*>(pe + ((long)b * P + tok - 1) * D + c);
+  const float4 p = *reinterpret_cast<const float4*>(pos + (long)tok * D + c);
+  const float4 t = *reinterpret_cast<const float4*>(vtype1 + c);
+  *reinterpret_cast<float4*>(x + ((long)b * N + L + tok) * D + c) = make_float4(a.x + p.x + t.x, a.y + p.y + t.y, a.z + p.z + t.z, a.w + p.w + t.w);
+}
+int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos, const float* vtype1, float* x, int B, int P,
+                            int L, int N, int D, hipStream_t s) {
+  RMCL_REQUIRE(D % 4 == 0, "image_assemble: D%4");
+  hipLaunchKernelGGL(image_assemble_fwd_kernel, dim3(cdiv((long)B * (P + 1) * (D / 4), 256)), dim3(256), 0, s, pe, cls, pos, vtype1, x, B, P, L, N, D);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward: dpe[b*P+p] = dx[b*N+L+1+p] (as T);  optional param grads:
+//   dpos[tok] += sum_b dx[b, L+tok];  dcls += sum_b dx[b, L];  dvtype1 += sum over all image tokens
+template <typename T>
+__global__ __launch_bounds__(256) void image_assemble_bwd_kernel(const float* __restrict__ dx, T* __restrict__ dpe,
+                                                                 float* __restrict__ dpos, float* __restrict__ dcls,
+                                                                 float* __restrict__ dvtype1, int B, int P, int L, int N, int D) {
+  const int tok = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= D) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float v = dx[((long)b * N + L + tok) * D + c];
+    acc += v;
+    if (tok > 0) dpe[((long)b * P + tok - 1) * D + c] = from_f32<T>(v);
+  }
+  if (dpos) {
+    atomicAdd(dpos + (long)tok * D + c, acc);
+    atomicAdd(dvtype1 + c, acc);
+    if (tok == 0) atomicAdd(dcls + c, acc);
+  }
+}
+int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,
+                            int N, int D, hipStream_t s) {
+  dim3 grid(P + 1, cdiv(D, 256));
+  if (dt == RMCL_F32) hipLaunchKernelGGL(image_assemble_bwd_kernel<float>, grid, dim3(256), 0, s, dx, (float*)dpe, dpos, dcls, dvtype1, B, P, L, N, D);
+  else hipLaunchKernelGGL(image_assemble_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dx, (bf16_t*)dpe, dpos, dcls, dvtype1, B, P, L, N, D);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patch layout: image [B,C,Hh,Ww] f32 <-> patches [B*gh*gw, C*ps*ps] f32, K ordered (c,ky,kx)
+// (the GEMM view of Conv2d(3,D,ps,ps,stride ps), vision_transformer.py:397-409).  ps % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2patch_kernel(const float* __restrict__ img, float* __restrict__ pat, int B, int C, int Hh,
+                                                       int Ww, int ps, int to_image) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of the image
+  const long total = (long)B * C * Hh * Ww / 4;
+  if (i >= total) return;
+  const long e = i * 4;
+  const int xw = (int)(e % Ww), y = (int)((e / Ww) % Hh), c = (int)((e / ((long)Ww * Hh)) % C), b = (int)(e / ((long)Ww * Hh * C));
+  const int gw = Ww / ps, gh = Hh / ps;
+  const int px = xw / ps, kx = xw % ps, py = y / ps, ky = y % ps;
+  const long prow = ((long)b * gh + py) * gw + px;
+  const long pidx = prow * ((long)C * ps * ps) + ((long)c * ps + ky) * ps + kx;
+  if (to_image) *reinterpret_cast<float4*>(const_cast<float*>(img) + e) = *reinterpret_cast<const float4*>(pat + pidx);
+  else *reinterpret_cast<float4*>(pat + pidx) = *reinterpret_cast<const float4*>(img + e);
+}
+int rmcl_im2patch(const float* img, float* pat, int B, int C, int Hh, int Ww, int ps, int to_image, hipStream_t s) {
+  RMCL_REQUIRE(ps % 4 == 0 && Hh % ps == 0 && Ww % ps == 0, "im2patch: image sides must be multiples of the patch size");
+  hipLaunchKernelGGL(im2patch_kernel, dim3(cdiv((long)B * C * Hh * Ww / 4, 256)), dim3(256), 0, s, img, pat, B, C, Hh, Ww, ps, to_image);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// out_T = a + d1 + d2 (d1, d2 optional), n % 4 == 0: the "img_init + delta" of pgd_attack_vilt.py:144
+// fused with the cast to the GEMM operand type.
+template <typename T>
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ d1,
+                                                       const float* __restrict__ d2, T* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = reinterpret_cast<const float4*>(a)[i];
+    if (d1) { const float4 w = reinterpret_cast<const float4*>(d1)[i]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    if (d2) { const float4 w = reinterpret_cast<const float4*>(d2)[i]; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+    if constexpr (sizeof(T) == 4) reinterpret_cast<float4*>(out)[i] = v;
+    else {
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+      pk.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+      reinterpret_cast<uint2*>(out)[i] = pk;
+    }
+  }
+}
+int rmcl_k_add_cast(const float* a, const float* d1, const float* d2, void* out, int dt, long n, hipStream_t s) {
+  RMCL_REQUIRE(n % 4 == 0, "add_cast: n%4");
+  const int grid = (int)std::min<long>(cdiv(n / 4, 256), 8192);
+  if (dt == RMCL_F32) hipLaunchKernelGGL(add_cast_kernel<float>, dim3(grid), dim3(256), 0, s, a, d1, d2, (float*)out, n / 4);
+  else hipLaunchKernelGGL(add_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, d1, d2, (bf16_t*)out, n / 4);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// co_mask[b, 0:L] = text_mask[b,:] != 0; co_mask[b, L] = 1; co_mask[b, L+1+p] = (sum_c patch[b*P+p][c*ps*ps] != 0)
+// (pixel mask sampled at every patch's top-left pixel: vision_transformer.py:564-565,672; vilt_module.py:324)
+template <typename T>
+__global__ __launch_bounds__(256) void co_mask_kernel(const long* __restrict__ text_mask, const T* __restrict__ pat, int* __restrict__ co,
+                                                      int B, int L, int P, int C, int pp) {
+  const int i = blockIdx.x * 256 + threadIdx.x, N = L + 1 + P;
+  if (i >= B * N) return;
+  const int b = i / N, t = i % N;
+  int m;
+  if (t < L) m = text_mask[(long)b * L + t] != 0;
+  else if (t == L) m = 1;
+  else {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += to_f32<T>(pat[((long)b * P + (t - L - 1)) * ((long)C * pp) + (long)c * pp]);
+    m = s != 0.f;
+  }
+  co[i] = m;
+}
+int rmcl_co_mask(const long* text_mask, const void* pat, int dt, int* co, int B, int L, int P, int C, int pp, hipStream_t s) {
+  dim3 grid(cdiv((long)B * (L + 1 + P), 256));
+  if (dt == RMCL_F32) hipLaunchKernelGGL(co_mask_kernel<float>, grid, dim3(256), 0, s, text_mask, (const float*)pat, co, B, L, P, C, pp);
+  else hipLaunchKernelGGL(co_mask_kernel<bf16_t>, grid, dim3(256), 0, s, text_mask, (const bf16_t*)pat, co, B, L, P, C, pp);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PGD step (attack/pgd_attack_vilt.py:162-173), in patch layout (a per-sample permutation of the
+// image layout, so the per-sample inf-norm is unchanged):
+//   amax[b] = max |g_b|;  delta <- clamp(delta + lr * g / max(amax[b], 1e-8), +-eps)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ g, unsigned* __restrict__ amax_bits, long per_sample) {
+  const int b = blockIdx.y;
+  const T* p = g + (long)b * per_sample;
+  float m = 0.f;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 1024) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(to_f32<T>(p[i + j])));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits + b, __float_as_uint(m));  // non-negative floats order like uints
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pgd_update_kernel(const T* __restrict__ g, const unsigned* __restrict__ amax_bits,
+                                                         float* __restrict__ delta, long per_sample, float lr, float eps) {
+  const int b = blockIdx.y;
+  const float den = fmaxf(__uint_as_float(amax_bits[b]), 1e-8f);
+  const T* p = g + (long)b * per_sample;
+  float* d = delta + (long)b * per_sample;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 1024) {
+    float4 v = *reinterpret_cast<float4*>(d + i);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = o[j] + lr * to_f32<T>(p[i + j]) / den;
+      if (eps > 0.f) o[j] = fminf(fmaxf(o[j], -eps), eps);
+    }
+    *reinterpret_cast<float4*>(d + i) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+int rmcl_pgd_update(const void* g, int dt, float* delta, unsigned* amax_bits, int B, long per_sample, float lr, float eps, hipStream_t s) {
+  RMCL_REQUIRE(per_sample % 4 == 0, "pgd_update: per_sample%4");
+  hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned) * B, s);
+  if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+  dim3 grid(std::min<long>(cdiv(per_sample, 1024), 64), B);
+  if (dt == RMCL_F32) {
+    hipLaunchKernelGGL(absmax_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, per_sample);
+    hipLaunchKernelGGL(pgd_update_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, delta, per_sample, lr, eps);
+  } else {
+    hipLaunchKernelGGL(absmax_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, amax_bits, per_sample);
+    hipLaunchKernelGGL(pgd_update_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, amax_bits, delta, per_sample, lr, eps);
+  }
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// mean over (b, y, x) of the channel-wise L2 norm of delta (objectives.py:184), delta in patch layout
+// [B*P, C*pp]: out += sum_{row, i<pp} sqrt(sum_c delta[row][c*pp + i]^2)   (caller divides by B*P*pp)
+__global__ __launch_bounds__(256) void delta_chan_norm_kernel(const float* __restrict__ d, float* __restrict__ out, long rows, int C, int pp) {
+  float acc = 0.f;
+  const long total = rows * pp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / pp;
+    const int k = (int)(i % pp);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) { const float v = d[r * ((long)C * pp) + (long)c * pp + k]; s += v * v; }
+    acc += sqrtf(s);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+int rmcl_delta_chan_norm(const float* d, float* out, long rows, int C, int pp, hipStream_t s) {
+  hipLaunchKernelGGL(delta_chan_norm_kernel, dim3(std::min<long>(cdiv(rows * pp, 256), 2048)), dim3(256), 0, s, d, out, rows, C, pp);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EMA of the momentum encoder over a flat parameter arena (objectives.py:219-224,257-260):
+//   k = k*m + q*(1-m);  optionally refreshes the bf16 shadow of k in the same pass.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ k, const float* __restrict__ q, bf16_t* __restrict__ k_lp,
+                                                  float m, long n4) {
+  const float om = 1.0f - m;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 a = reinterpret_cast<float4*>(k)[i];
+    const float4 b = reinterpret_cast<const float4*>(q)[i];
+    a.x = a.x * m + b.x * om; a.y = a.y * m + b.y * om; a.z = a.z * m + b.z * om; a.w = a.w * m + b.w * om;
+    reinterpret_cast<float4*>(k)[i] = a;
+    if (k_lp) {
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16);
+      pk.y = (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16);
+      reinterpret_cast<uint2*>(k_lp)[i] = pk;
+    }
+  }
+}
+int rmcl_ema(float* k, const float* q, void* k_lp, float m, long n, hipStream_t s) {
+  RMCL_REQUIRE(n % 4 == 0, "ema: n%4");
+  hipLaunchKernelGGL(ema_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 4096)), dim3(256), 0, s, k, q, (bf16_t*)k_lp, m, n / 4);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// queue[:, ptr + i] = keys[i, :]  for i < n  (objectives.py:244-246); queue [Pd, Kq] row-major
+__global__ __launch_bounds__(256) void enqueue_kernel(float* __restrict__ queue, const float* __restrict__ keys, int n, int Pd, long Kq, long ptr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * Pd) return;
+  const int c = i / n, r = i % n;  // consecutive threads -> consecutive queue columns
+  queue[(long)c * Kq + ptr + r] = keys[(long)r * Pd + c];
+}
+int rmcl_enqueue(float* queue, const float* keys, int n, int Pd, long Kq, long ptr, hipStream_t s) {
+  RMCL_REQUIRE(ptr >= 0 && ptr + n <= Kq, "enqueue: block would run past the end of the queue (needs Kq % batch == 0)");
+  hipLaunchKernelGGL(enqueue_kernel, dim3(cdiv((long)n * Pd, 256)), dim3(256), 0, s, queue, keys, n, Pd, Kq, ptr);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row L2 normalise (F.normalize eps 1e-12) forward / backward, ReLU/tanh backward multiplies
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict__ z, float* __restrict__ q, float* __restrict__ nrm, int D, float eps) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) { const float v = z[(long)r * D + c]; s += v * v; }
+  const float n = fmaxf(sqrtf(wave_sum(s)), eps);
+  if (lane == 0 && nrm) nrm[r] = n;
+  for (int c = lane; c < D; c += 64) q[(long)r * D + c] = z[(long)r * D + c] / n;
+}
+int rmcl_l2norm_fwd(const float* z, float* q, float* nrm, int R, int D, float eps, hipStream_t s) {
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(R), dim3(64), 0, s, z, q, nrm, D, eps);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+// dz = (dq - q * (q . dq)) / nrm
+__global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict__ dq, const float* __restrict__ q,
+                                                        const float* __restrict__ nrm, float* __restrict__ dz, int D) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) s += q[(long)r * D + c] * dq[(long)r * D + c];
+  s = wave_sum(s);
+  const float inv = 1.0f / nrm[r];
+  for (int c = lane; c < D; c += 64) dz[(long)r * D + c] = (dq[(long)r * D + c] - q[(long)r * D + c] * s) * inv;
+}
+int rmcl_l2norm_bwd(const float* dq, const float* q, const float* nrm, float* dz, int R, int D, hipStream_t s) {
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(R), dim3(64), 0, s, dq, q, nrm, dz, D);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+// g *= (1 - y*y)   (tanh backward, y = tanh output)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(float* __restrict__ g, const float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) g[i] *= (1.0f - y[i] * y[i]);
+}
+int rmcl_tanh_bwd(float* g, const float* y, long n, hipStream_t s) {
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g, y, n);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// f32 -> T cast of a flat arena (bf16 weight shadow refresh)
+int rmcl_cast(const float* in, void* out, int dt, long n, hipStream_t s) { return rmcl_k_add_cast(in, nullptr, nullptr, out, dt, n, s); }
+
+// ---------------------------------------------------------------------------------------------
+// Fused multi-tensor AdamW over flat arenas (HF AdamW as used by vilt_utils.set_schedule :395-398):
+//   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps); p -= lr*wd*p
+// Per-element lr scale / weight-decay come from a per-segment table (segments are 64-element
+// aligned parameter tensors): seg_end[i] (exclusive element offset), seg_lr_mult[i], seg_wd[i].
+// Optionally refreshes the bf16 shadow of p.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ p_lp, const long* __restrict__ seg_end,
+                                                    const float* __restrict__ seg_lr_mult, const float* __restrict__ seg_wd, int nseg,
+                                                    float lr, float b1, float b2, float eps, float bc1, float bc2s, long n4,
+                                                    float grad_scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    int lo = 0, hi = nseg - 1;  // first segment with seg_end > e
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (seg_end[mid] > e) hi = mid; else lo = mid + 1; }
+    const float slr = lr * seg_lr_mult[lo], wd = seg_wd[lo];
+    const float step = slr * bc2s / bc1;
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float P[4] = {pp.x, pp.y, pp.z, pp.w}, G[4] = {gg.x, gg.y, gg.z, gg.w}, Mo[4] = {mm.x, mm.y, mm.z, mm.w}, V[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = G[j] * grad_scale;
+      Mo[j] = Mo[j] * b1 + gj * (1.0f - b1);
+      V[j] = V[j] * b2 + gj * gj * (1.0f - b2);
+      P[j] = P[j] - step * Mo[j] / (sqrtf(V[j]) + eps);
+      if (wd > 0.f) P[j] = P[j] - slr * wd * P[j];
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(P[0], P[1], P[2], P[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(Mo[0], Mo[1], Mo[2], Mo[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(V[0], V[1], V[2], V[3]);
+    if (p_lp) {
+      uint2 pk;
+      pk.x = (uint32_t)f2bf(P[0]) | ((uint32_t)f2bf(P[1]) << 16);
+      pk.y = (uint32_t)f2bf(P[2]) | ((uint32_t)f2bf(P[3]) << 16);
+      reinterpret_cast<uint2*>(p_lp)[i] = pk;
+    }
+  }
+}
+int rmcl_adamw(float* p, const float* g, float* m, float* v, void* p_lp, const long* seg_end, const float* seg_lr_mult,
+               const float* seg_wd, int nseg, float lr, float b1, float b2, float eps, int step, float grad_scale, long n,
+               hipStream_t s) {
+  RMCL_REQUIRE(n % 4 == 0 && nseg > 0 && step >= 1, "adamw: bad args");
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 4096)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp, seg_end,
+                     seg_lr_mult, seg_wd, nseg, lr, b1, b2, eps, bc1, bc2s, n / 4, grad_scale);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}

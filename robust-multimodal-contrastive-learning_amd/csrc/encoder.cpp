@@ -1,0 +1,439 @@
+// Host-side orchestration of one ViLT encoder pass (forward, data-gradient backward, full backward)
+// as a fixed sequence of kernel launches on one HIP stream: no allocation, no synchronisation, so
+// the whole pass can be captured into a hipGraph by the caller.
+//
+// Reference being replaced: ViLTransformerSS.infer / infer_k (vilt/modules/vilt_module.py:275-418),
+// VisionTransformer.visual_embed dense case (vision_transformer.py:559-677), Block / Attention / Mlp
+// (vision_transformer.py:262-375) and their autograd backward.
+#include "rmcl_common.h"
+#include "kernels.h"
+#include "../../include/rmcl.h"
+
+namespace {
+
+struct Bump {
+  char* base;
+  size_t off = 0;
+  explicit Bump(void* b) : base(reinterpret_cast<char*>(b)) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+  void* take_bytes(size_t n) { return take<char>(n); }
+};
+
+inline size_t esz(int dt) { return dt == RMCL_F32 ? 4 : 2; }
+inline int ldp_of(int N) { return (N + 7) / 8 * 8; }
+
+struct LayerStash {
+  float *x_in, *x_mid, *mean1, *rstd1, *mean2, *rstd2;
+  void *qkv, *probs, *u;           // DATA+
+  void *ao, *ln1, *ln2, *h;        // FULL (workspace-aliased otherwise)
+};
+
+struct Stash {
+  LayerStash layer[64];
+  float *x_final, *meanF, *rstdF;
+  float *text_e, *text_mean, *text_rstd;
+};
+
+struct Work {
+  float *scores;      // [B,H,N,ldp] f32 (S and dP)
+  float *pe;          // [B*P, D] f32
+  void *ln, *ao, *h, *qkv, *probs, *u;   // INFER-mode per-layer temporaries
+  float *x_a, *x_b, *x_mid, *stat;       // INFER-mode residual ping-pong + stats
+  // backward
+  float *dx, *dln, *dxn_full, *de;
+  void *dxT, *du, *dqkv, *dao, *dS, *dpe;
+};
+
+// Stash carve.  INFER: nothing is stashed (everything aliases workspace).
+size_t carve_stash(const rmcl_dims& d, int mode, void* base, Stash* st) {
+  Bump b(base);
+  const size_t M = (size_t)d.B * (d.L + 1 + d.P), D = d.D, N = d.L + 1 + d.P;
+  const size_t e = esz(d.dtype);
+  if (mode == RMCL_MODE_INFER) return 0;
+  for (int l = 0; l < d.layers; ++l) {
+    LayerStash ls{};
+    ls.x_in = b.take<float>(M * D);
+    ls.x_mid = b.take<float>(M * D);
+    ls.mean1 = b.take<float>(M); ls.rstd1 = b.take<float>(M);
+    ls.mean2 = b.take<float>(M); ls.rstd2 = b.take<float>(M);
+    ls.qkv = b.take_bytes(M * 3 * D * e);
+    ls.probs = b.take_bytes((size_t)d.B * d.H * N * ldp_of((int)N) * e);
+    ls.u = b.take_bytes(M * d.mlp * e);
+    if (mode == RMCL_MODE_FULL) {
+      ls.ao = b.take_bytes(M * D * e);
+      ls.ln1 = b.take_bytes(M * D * e);
+      ls.ln2 = b.take_bytes(M * D * e);
+      ls.h = b.take_bytes(M * d.mlp * e);
+    }
+    if (st) st->layer[l] = ls;
+  }
+  float* xf = b.take<float>(M * D);
+  float* mf = b.take<float>(M);
+  float* rf = b.take<float>(M);
+  float *te = nullptr, *tm = nullptr, *tr = nullptr;
+  if (mode == RMCL_MODE_FULL) {
+    te = b.take<float>((size_t)d.B * d.L * D);
+    tm = b.take<float>((size_t)d.B * d.L);
+    tr = b.take<float>((size_t)d.B * d.L);
+  }
+  if (st) { st->x_final = xf; st->meanF = mf; st->rstdF = rf; st->text_e = te; st->text_mean = tm; st->text_rstd = tr; }
+  return b.off;
+}
+
+size_t carve_work(const rmcl_dims& d, void* base, Work* w) {
+  Bump b(base);
+  const size_t M = (size_t)d.B * (d.L + 1 + d.P), D = d.D, N = d.L + 1 + d.P;
+  const size_t e = esz(d.dtype);
+  const size_t zn = (size_t)d.B * d.H * N * ldp_of((int)N);
+  Work k{};
+  k.scores = b.take<float>(zn);
+  k.pe = b.take<float>((size_t)d.B * d.P * D);
+  k.ln = b.take_bytes(M * D * e);
+  k.ao = b.take_bytes(M * D * e);
+  k.h = b.take_bytes(M * d.mlp * e);
+  k.qkv = b.take_bytes(M * 3 * D * e);
+  k.probs = b.take_bytes(zn * e);
+  k.u = b.take_bytes(M * d.mlp * e);
+  k.x_a = b.take<float>(M * D);
+  k.x_b = b.take<float>(M * D);
+  k.x_mid = b.take<float>(M * D);
+  k.stat = b.take<float>(4 * M);
+  k.dx = b.take<float>(M * D);
+  k.dln = b.take<float>(M * D);
+  k.dxn_full = b.take<float>(M * D);
+  k.de = b.take<float>((size_t)d.B * d.L * D);
+  k.dxT = b.take_bytes(M * D * e);
+  k.du = b.take_bytes(M * d.mlp * e);
+  k.dqkv = b.take_bytes(M * 3 * D * e);
+  k.dao = b.take_bytes(M * D * e);
+  k.dS = b.take_bytes(zn * e);
+  k.dpe = b.take_bytes((size_t)d.B * d.P * D * e);
+  if (w) *w = k;
+  return b.off;
+}
+
+int check_dims(const rmcl_dims* d) {
+  RMCL_REQUIRE(d != nullptr, "dims is NULL");
+  RMCL_REQUIRE(d->B > 0 && d->L > 0 && d->P > 0 && d->layers > 0 && d->layers <= 64, "bad dims");
+  RMCL_REQUIRE(d->D == d->H * 64, "head dim must be 64");
+  RMCL_REQUIRE(d->D % 64 == 0 && d->D <= 1024 && d->mlp % 64 == 0 && d->patch_k % 64 == 0, "D/mlp/patch_k must be multiples of 64 (D <= 1024)");
+  RMCL_REQUIRE(d->dtype == RMCL_F32 || d->dtype == RMCL_BF16, "bad dtype");
+  RMCL_REQUIRE(d->L + 1 + d->P <= 512, "sequence too long (N <= 512)");
+  return 0;
+}
+
+GemmArgs gemm_args(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, int ldc) {
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = 1.0f; g.epi = 0; g.splitk = 1; g.nb1 = 1; g.nb2 = 1;
+  return g;
+}
+
+struct Ctx {
+  const rmcl_dims& d;
+  const float* P32;
+  const void* Plp;
+  rmcl_layout lay;
+  hipStream_t s;
+  int dt;
+  // weight matrix (GEMM operand type) and fp32 vector accessors
+  const void* W(int64_t off) const {
+    return d.dtype == RMCL_BF16 ? (const void*)((const bf16_t*)Plp + off) : (const void*)(P32 + off);
+  }
+  const float* V(int64_t off) const { return P32 + off; }
+  int64_t L(int l, int64_t rel) const { return lay.layer0 + (int64_t)l * lay.layer_stride + rel; }
+};
+
+int gemm(const Ctx& c, const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc) {
+  return rmcl_launch_gemm(g, dt_in, dt_out, a_kc, b_kc, c.d.exact, c.s);
+}
+
+// split-K factor for weight-gradient GEMMs (reduction over tokens): fill ~2 waves of 256 CUs.
+int dw_splitk(int Mout, int Nout, int K) {
+  const int tiles = cdiv(Mout, 128) * cdiv(Nout, 128);
+  int sk = std::max(1, 512 / tiles);
+  sk = std::min(sk, std::max(1, K / 256));
+  return std::min(sk, 64);
+}
+
+// dW[Nout, Kin] += dY[tokens, Nout]^T @ X[tokens, Kin]   (fp32 atomics into the gradient arena)
+int gemm_dw(const Ctx& c, const void* dY, long lddy, const void* X, long ldx, float* dW, int Nout, int Kin, int tokens, int dt_in) {
+  GemmArgs g = gemm_args(dY, X, dW, Nout, Kin, tokens, lddy, ldx, Kin);
+  g.epi = EPI_ATOMIC;
+  g.splitk = dw_splitk(Nout, Kin, tokens);
+  if (g.splitk == 1) g.epi = EPI_ACCUM;
+  return gemm(c, g, dt_in, RMCL_F32, 0, 0);
+}
+
+}  // namespace
+
+int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* probs, float* scores, int B, int N, int H, int dt,
+                            int exact, hipStream_t s) {
+  const int D = H * 64, ldp = ldp_of(N);
+  const size_t e = esz(dt);
+  // S = 0.125 * Q K^T   (batched over (b,h); Q/K rows are 3D apart, heads 64 apart)
+  GemmArgs g = gemm_args(qkv, (const char*)qkv + (size_t)D * e, scores, N, N, 64, 3 * D, 3 * D, ldp);
+  g.alpha = 0.125f;
+  g.nb1 = B; g.nb2 = H;
+  g.sA1 = (long)N * 3 * D; g.sA2 = 64; g.sB1 = g.sA1; g.sB2 = 64;
+  g.sC1 = (long)H * N * ldp; g.sC2 = (long)N * ldp;
+  RMCL_TRY(rmcl_launch_gemm(g, dt, RMCL_F32, 1, 1, exact, s));
+  RMCL_TRY(rmcl_softmax_fwd(scores, ldp, mask, probs, ldp, dt, B * H, N, H, s));
+  // out[b*N+i, h*64+d] = sum_j P[b,h,i,j] V[b*N+j, 2D + h*64 + d]
+  GemmArgs o = gemm_args(probs, (const char*)qkv + (size_t)2 * D * e, out, N, 64, N, ldp, 3 * D, D);
+  o.nb1 = B; o.nb2 = H;
+  o.sA1 = (long)H * N * ldp; o.sA2 = (long)N * ldp; o.sB1 = (long)N * 3 * D; o.sB2 = 64;
+  o.sC1 = (long)N * D; o.sC2 = 64;
+  RMCL_TRY(rmcl_launch_gemm(o, dt, dt, 1, 0, exact, s));
+  return 0;
+}
+
+int rmcl_attention_bwd_impl(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dS, int B,
+                            int N, int H, int dt, int exact, hipStream_t s) {
+  const int D = H * 64, ldp = ldp_of(N);
+  const size_t e = esz(dt);
+  const long sQ1 = (long)N * 3 * D, sP1 = (long)H * N * ldp, sP2 = (long)N * ldp;
+  // dP = dO V^T
+  GemmArgs g = gemm_args(dout, (const char*)qkv + (size_t)2 * D * e, scores, N, N, 64, D, 3 * D, ldp);
+  g.nb1 = B; g.nb2 = H;
+  g.sA1 = (long)N * D; g.sA2 = 64; g.sB1 = sQ1; g.sB2 = 64; g.sC1 = sP1; g.sC2 = sP2;
+  RMCL_TRY(rmcl_launch_gemm(g, dt, RMCL_F32, 1, 1, exact, s));
+  RMCL_TRY(rmcl_softmax_bwd(probs, ldp, scores, ldp, dS, ldp, dt, B * H, N, 0.125f, s));
+  // dQ = dS K
+  GemmArgs q = gemm_args(dS, (const char*)qkv + (size_t)D * e, dqkv, N, 64, N, ldp, 3 * D, 3 * D);
+  q.nb1 = B; q.nb2 = H;
+  q.sA1 = sP1; q.sA2 = sP2; q.sB1 = sQ1; q.sB2 = 64; q.sC1 = sQ1; q.sC2 = 64;
+  RMCL_TRY(rmcl_launch_gemm(q, dt, dt, 1, 0, exact, s));
+  // dK = dS^T Q
+  GemmArgs k = gemm_args(dS, qkv, (char*)dqkv + (size_t)D * e, N, 64, N, ldp, 3 * D, 3 * D);
+  k.nb1 = B; k.nb2 = H;
+  k.sA1 = sP1; k.sA2 = sP2; k.sB1 = sQ1; k.sB2 = 64; k.sC1 = sQ1; k.sC2 = 64;
+  RMCL_TRY(rmcl_launch_gemm(k, dt, dt, 0, 0, exact, s));
+  // dV = P^T dO
+  GemmArgs v = gemm_args(probs, dout, (char*)dqkv + (size_t)2 * D * e, N, 64, N, ldp, D, 3 * D);
+  v.nb1 = B; v.nb2 = H;
+  v.sA1 = sP1; v.sA2 = sP2; v.sB1 = (long)N * D; v.sB2 = 64; v.sC1 = sQ1; v.sC2 = 64;
+  RMCL_TRY(rmcl_launch_gemm(v, dt, dt, 0, 0, exact, s));
+  return 0;
+}
+
+extern "C" {
+
+void rmcl_param_layout(const rmcl_dims* d, rmcl_layout* o) {
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t p = off; off += (n + 63) / 64 * 64; return p; };
+  const int64_t D = d->D;
+  o->word = take((int64_t)d->vocab * D);
+  o->pos = take((int64_t)d->L * D);
+  o->btype = take(2 * D);
+  o->eln_w = take(D); o->eln_b = take(D);
+  o->vtype = take(2 * D);
+  o->cls = take(D);
+  o->pos_img = take((int64_t)(d->P + 1) * D);
+  o->patch_w = take(D * d->patch_k);
+  o->patch_b = take(D);
+  o->layer0 = off;
+  {
+    int64_t base = off;
+    o->ln1_w = take(D) - base; o->ln1_b = take(D) - base;
+    o->qkv_w = take(3 * D * D) - base; o->qkv_b = take(3 * D) - base;
+    o->proj_w = take(D * D) - base; o->proj_b = take(D) - base;
+    o->ln2_w = take(D) - base; o->ln2_b = take(D) - base;
+    o->fc1_w = take((int64_t)d->mlp * D) - base; o->fc1_b = take(d->mlp) - base;
+    o->fc2_w = take((int64_t)d->mlp * D) - base; o->fc2_b = take(D) - base;
+    o->layer_stride = off - base;
+    off = base + o->layer_stride * d->layers;
+  }
+  o->norm_w = take(D); o->norm_b = take(D);
+  o->mh0_w = take(D * D); o->mh0_b = take(D);
+  o->mh1_w = take(D); o->mh1_b = take(D);
+  o->mh3_w = take((int64_t)d->proj * D);
+  o->ema_end = off;
+  o->pool_w = take(D * D); o->pool_b = take(D);
+  o->itm_w = take(2 * D); o->itm_b = take(64);
+  o->total = off;
+}
+
+int64_t rmcl_stash_bytes(const rmcl_dims* d, int mode) { return (int64_t)carve_stash(*d, mode, nullptr, nullptr) + 256; }
+int64_t rmcl_workspace_bytes(const rmcl_dims* d) { return (int64_t)carve_work(*d, nullptr, nullptr) + 256; }
+
+int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
+                         const int64_t* text_mask, const void* patches, int32_t* co_mask, void* stash, void* workspace,
+                         float* xn, void* stream) {
+  RMCL_TRY(check_dims(d));
+  RMCL_REQUIRE(params32 && text_ids && text_mask && patches && co_mask && workspace && xn, "encoder_forward: NULL argument");
+  RMCL_REQUIRE(d->dtype == RMCL_F32 || params_lp, "encoder_forward: bf16 mode needs the bf16 shadow arena");
+  RMCL_REQUIRE(mode == RMCL_MODE_INFER || stash, "encoder_forward: stash required unless mode is INFER");
+  Ctx c{*d, params32, params_lp, {}, (hipStream_t)stream, d->dtype};
+  rmcl_param_layout(d, &c.lay);
+  const rmcl_layout& y = c.lay;
+  Stash st{};
+  Work w{};
+  carve_stash(*d, mode, stash, &st);
+  carve_work(*d, workspace, &w);
+  const int B = d->B, L = d->L, P = d->P, N = L + 1 + P, D = d->D, M = B * N, dt = d->dtype;
+  const bool keep = mode != RMCL_MODE_INFER, full = mode == RMCL_MODE_FULL;
+  hipStream_t s = c.s;
+
+  float* x0 = keep ? st.layer[0].x_in : w.x_a;
+  RMCL_TRY(rmcl_text_embed_fwd((const long*)text_ids, c.V(y.word), c.V(y.pos), c.V(y.btype), c.V(y.eln_w), c.V(y.eln_b),
+                               c.V(y.vtype), 1e-12f, x0, full ? st.text_e : nullptr, full ? st.text_mean : nullptr,
+                               full ? st.text_rstd : nullptr, B, L, N, D, s));
+  {
+    GemmArgs g = gemm_args(patches, c.W(y.patch_w), w.pe, B * P, D, d->patch_k, d->patch_k, d->patch_k, D);
+    g.epi = EPI_BIAS; g.bias = c.V(y.patch_b);
+    RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
+  }
+  RMCL_TRY(rmcl_image_assemble_fwd(w.pe, c.V(y.cls), c.V(y.pos_img), c.V(y.vtype) + D, x0, B, P, L, N, D, s));
+  RMCL_TRY(rmcl_co_mask((const long*)text_mask, patches, dt, co_mask, B, L, P, 3, d->patch_k / 3, s));
+
+  float* x = x0;
+  for (int l = 0; l < d->layers; ++l) {
+    LayerStash ls{};
+    if (keep) ls = st.layer[l];
+    float* x_mid = keep ? ls.x_mid : w.x_mid;
+    float* x_out = keep ? (l + 1 < d->layers ? st.layer[l + 1].x_in : st.x_final) : (x == w.x_a ? w.x_b : w.x_a);
+    float *m1 = keep ? ls.mean1 : w.stat, *r1 = keep ? ls.rstd1 : w.stat + M;
+    float *m2 = keep ? ls.mean2 : w.stat + 2 * M, *r2 = keep ? ls.rstd2 : w.stat + 3 * M;
+    void* ln1 = full ? ls.ln1 : w.ln;
+    void* ln2 = full ? ls.ln2 : w.ln;
+    void* qkv = keep ? ls.qkv : w.qkv;
+    void* probs = keep ? ls.probs : w.probs;
+    void* ao = full ? ls.ao : w.ao;
+    void* h = full ? ls.h : w.h;
+    void* u = keep ? ls.u : nullptr;
+
+    RMCL_TRY(rmcl_ln_fwd(x, D, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), 1e-6f, ln1, D, dt, m1, r1, M, D, 0, s));
+    {
+      GemmArgs g = gemm_args(ln1, c.W(c.L(l, y.qkv_w)), qkv, M, 3 * D, D, D, D, 3 * D);
+      g.epi = EPI_BIAS; g.bias = c.V(c.L(l, y.qkv_b));
+      RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
+    }
+    RMCL_TRY(rmcl_attention_fwd_impl(qkv, co_mask, ao, probs, w.scores, B, N, d->H, dt, d->exact, s));
+    {
+      GemmArgs g = gemm_args(ao, c.W(c.L(l, y.proj_w)), x_mid, M, D, D, D, D, D);
+      g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = D;
+      RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
+    }
+    RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2, D, dt, m2, r2, M, D, 0, s));
+    {
+      GemmArgs g = gemm_args(ln2, c.W(c.L(l, y.fc1_w)), h, M, d->mlp, D, D, D, d->mlp);
+      g.epi = EPI_BIAS | EPI_GELU | (u ? EPI_SAVE_PREACT : 0); g.bias = c.V(c.L(l, y.fc1_b)); g.C2 = u;
+      RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
+    }
+    {
+      GemmArgs g = gemm_args(h, c.W(c.L(l, y.fc2_w)), x_out, M, D, d->mlp, d->mlp, d->mlp, D);
+      g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.fc2_b)); g.aux = x_mid; g.ld_aux = D;
+      RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
+    }
+    x = x_out;
+  }
+  RMCL_TRY(rmcl_ln_fwd(x, D, c.V(y.norm_w), c.V(y.norm_b), 1e-6f, xn, D, RMCL_F32, keep ? st.meanF : w.stat,
+                       keep ? st.rstdF : w.stat + M, M, D, 0, s));
+  return 0;
+}
+
+int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
+                          const void* patches, const int32_t* co_mask, void* stash, void* workspace, const float* dxn,
+                          int cls_only, void* dpatches, float* G, void* stream) {
+  RMCL_TRY(check_dims(d));
+  RMCL_REQUIRE(mode == RMCL_MODE_DATA || mode == RMCL_MODE_FULL, "encoder_backward: mode must be DATA or FULL");
+  RMCL_REQUIRE(params32 && stash && workspace && dxn && co_mask, "encoder_backward: NULL argument");
+  RMCL_REQUIRE(mode != RMCL_MODE_FULL || (G && text_ids && patches), "encoder_backward: FULL mode needs grads32, text_ids, patches");
+  RMCL_REQUIRE(d->dtype == RMCL_F32 || params_lp, "encoder_backward: bf16 mode needs the bf16 shadow arena");
+  Ctx c{*d, params32, params_lp, {}, (hipStream_t)stream, d->dtype};
+  rmcl_param_layout(d, &c.lay);
+  const rmcl_layout& y = c.lay;
+  Stash st{};
+  Work w{};
+  carve_stash(*d, mode, stash, &st);
+  carve_work(*d, workspace, &w);
+  const int B = d->B, L = d->L, P = d->P, N = L + 1 + P, D = d->D, M = B * N, dt = d->dtype, mlp = d->mlp;
+  const bool full = mode == RMCL_MODE_FULL;
+  hipStream_t s = c.s;
+  auto Gp = [&](int64_t off) { return G + off; };
+
+  // final LayerNorm backward -> dx (the residual-stream gradient, fp32)
+  const float* dy = dxn;
+  if (cls_only) {
+    hipError_t e = hipMemsetAsync(w.dxn_full, 0, (size_t)M * D * sizeof(float), s);
+    if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+    RMCL_TRY(rmcl_scatter_rows(dxn, w.dxn_full, B, D, 1, N, 0, 0, s));
+    dy = w.dxn_full;
+  }
+  RMCL_TRY(rmcl_ln_bwd(dy, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), w.dx, D, 0,
+                       full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, s));
+
+  for (int l = d->layers - 1; l >= 0; --l) {
+    const LayerStash& ls = st.layer[l];
+    const void* dxT = w.dx;
+    // ---- MLP ----
+    if (dt != RMCL_F32) { RMCL_TRY(rmcl_cast(w.dx, w.dxT, dt, (long)M * D, s)); dxT = w.dxT; }
+    {
+      GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.fc2_w)), w.du, M, mlp, D, D, mlp, mlp);  // du = (dx W2) * gelu'(u)
+      g.epi = EPI_DGELU; g.aux = ls.u; g.ld_aux = mlp;
+      RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
+    }
+    if (full) {
+      RMCL_TRY(gemm_dw(c, dxT, D, ls.h, mlp, Gp(c.L(l, y.fc2_w)), D, mlp, M, dt));
+      RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.fc2_b)), M, D, s));
+      RMCL_TRY(gemm_dw(c, w.du, mlp, ls.ln2, D, Gp(c.L(l, y.fc1_w)), mlp, D, M, dt));
+      RMCL_TRY(rmcl_colsum(w.du, mlp, dt, Gp(c.L(l, y.fc1_b)), M, mlp, s));
+    }
+    {
+      GemmArgs g = gemm_args(w.du, c.W(c.L(l, y.fc1_w)), w.dln, M, D, mlp, mlp, D, D);   // dln2 = du W1
+      RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
+    }
+    RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
+                         full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, s));
+    // ---- attention ----
+    dxT = w.dx;
+    if (dt != RMCL_F32) { RMCL_TRY(rmcl_cast(w.dx, w.dxT, dt, (long)M * D, s)); dxT = w.dxT; }
+    {
+      GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);        // dao = dx Wproj
+      RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
+    }
+    if (full) {
+      RMCL_TRY(gemm_dw(c, dxT, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt));
+      RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.proj_b)), M, D, s));
+    }
+    RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, ls.probs, w.dao, w.dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
+    if (full) {
+      RMCL_TRY(gemm_dw(c, w.dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt));
+      RMCL_TRY(rmcl_colsum(w.dqkv, 3 * D, dt, Gp(c.L(l, y.qkv_b)), M, 3 * D, s));
+    }
+    {
+      GemmArgs g = gemm_args(w.dqkv, c.W(c.L(l, y.qkv_w)), w.dln, M, D, 3 * D, 3 * D, D, D);  // dln1 = dqkv Wqkv
+      RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
+    }
+    RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
+                         full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, s));
+  }
+
+  // ---- embeddings ----
+  RMCL_TRY(rmcl_image_assemble_bwd(w.dx, w.dpe, dt, full ? Gp(y.pos_img) : nullptr, full ? Gp(y.cls) : nullptr,
+                                   full ? Gp(y.vtype) + D : nullptr, B, P, L, N, D, s));
+  if (dpatches) {
+    GemmArgs g = gemm_args(w.dpe, c.W(y.patch_w), dpatches, B * P, d->patch_k, D, D, d->patch_k, d->patch_k);
+    RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
+  }
+  if (full) {
+    RMCL_TRY(gemm_dw(c, w.dpe, D, patches, d->patch_k, Gp(y.patch_w), D, d->patch_k, B * P, dt));
+    RMCL_TRY(rmcl_colsum(w.dpe, D, dt, Gp(y.patch_b), B * P, D, s));
+    // text rows: x[b*N+t] = LN(e) + vtype[0]
+    RMCL_TRY(rmcl_gather_rows(w.dx, w.dln, B * L, D, L, N, 0, s));
+    RMCL_TRY(rmcl_colsum(w.dln, D, RMCL_F32, Gp(y.vtype), B * L, D, s));
+    RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, st.text_e, D, st.text_mean, st.text_rstd, c.V(y.eln_w), c.V(y.eln_b), w.de, D, 0,
+                         Gp(y.eln_w), Gp(y.eln_b), B * L, D, 0, s));
+    RMCL_TRY(rmcl_text_embed_scatter((const long*)text_ids, w.de, Gp(y.word), Gp(y.pos), Gp(y.btype), B, L, D, 0, s));
+  }
+  return 0;
+}
+
+}  // extern "C"

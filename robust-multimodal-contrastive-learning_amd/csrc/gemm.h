@@ -1,0 +1,50 @@
+// GEMM argument block shared by the generic (exact-f32 MFMA) and fast (bf16 MFMA) kernels.
+//
+//   C[m,n] = epilogue( alpha * sum_k A(m,k) * B(k,n) )         (per batch z)
+//
+// Operand addressing is by "layout kind":
+//   A_KC : A(m,k) = A[m*lda + k]   (k contiguous, e.g. activations [M,K])
+//   A_MC : A(m,k) = A[k*lda + m]   (m contiguous, e.g. dY^T read from dY[tokens, N])
+//   B_KC : B(k,n) = B[n*ldb + k]   (k contiguous, e.g. nn.Linear weight [N,K] used as W^T)
+//   B_MC : B(k,n) = B[k*ldb + n]   (n contiguous, e.g. nn.Linear weight [N',K'] used as-is)
+// so  forward  Y = X W^T      -> A_KC, B_KC   ("NT")
+//     data grad dX = dY W     -> A_KC, B_MC   ("NN")
+//     weight grad dW = dY^T X -> A_MC, B_MC   ("TN", reduction over tokens)
+#pragma once
+#include <stdint.h>
+
+enum {
+  EPI_BIAS = 1,         // + bias[n]
+  EPI_GELU = 2,         // exact-erf GELU on the result
+  EPI_SAVE_PREACT = 4,  // also store the pre-GELU value to C2 (same type/ld as C)
+  EPI_RESIDUAL = 8,     // + aux_f32[m*ld_aux + n]   (fp32 residual stream)
+  EPI_DGELU = 16,       // * gelu'(aux_T[m*ld_aux + n])  (aux has the INPUT element type)
+  EPI_ATOMIC = 32,      // split-K: atomicAdd into fp32 C (C must be fp32, pre-zeroed or accumulating)
+  EPI_ACCUM = 64,       // C += result (fp32 or bf16 read-modify-write; not with split-K)
+  EPI_TANH = 128,       // tanh on the result
+  EPI_COLSUM = 256,     // TN only: blocks with blockIdx.y==0 atomically add column sums of A (= bias grad) into bias_grad[m]
+};
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  void* C2;
+  const float* bias;
+  const void* aux;
+  float* colsum;          // EPI_COLSUM target (fp32 [M])
+  int M, N, K;
+  long lda, ldb;
+  int ldc, ld_aux;
+  float alpha;
+  int epi;
+  int splitk;             // >1: blockIdx.z = K slice (then nbatch must be 1)
+  int nb1, nb2;           // batch = nb1*nb2 (blockIdx.z = b1*nb2 + b2) when splitk == 1
+  long sA1, sA2, sB1, sB2, sC1, sC2;  // element strides per batch level
+};
+
+#ifdef __cplusplus
+// dt_in / dt_out: RMCL_F32 or RMCL_BF16.  a_kc / b_kc: layout kinds above.
+// exact = 1 forces the f32-MFMA kernel (bf16 inputs are widened to f32 in LDS).
+int rmcl_launch_gemm(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc, int exact, hipStream_t stream);
+#endif

@@ -1,0 +1,221 @@
+// Exact-f32 GEMM on the gfx950 f32-input matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// This is the arithmetic of the fp32 parity path (bit-for-bit a k-ordered fmaf chain per output,
+// MI355X guide "FP32-input MFMA") and the any-shape fallback of the bf16 path (bf16 operands are
+// widened to f32 when they are staged into LDS).  128x128x16 block tile, 4 waves (2x2), each wave
+// 64x64 = 2x2 MFMA tiles of 32x32; LDS images are k-major [16][128+4] f32 so that the one-float
+// A/B fragments (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) are conflict-free ds_read_b32.
+// Register-staged double buffering: tile t+1 is loaded to VGPRs before the MFMAs of tile t.
+#include "rmcl_common.h"
+#include "gemm.h"
+
+#define GBM 128
+#define GBN 128
+#define GBK 16
+#define GLD (GBM + 4)
+
+template <typename TI> struct VecTraits;
+template <> struct VecTraits<float> { static constexpr int V = 4; };
+template <> struct VecTraits<bf16_t> { static constexpr int V = 8; };
+
+// Loads this thread's share (8 elements) of a [128 rows x 16 k] operand tile into f32 registers.
+// KC: element (r,k) at base[r*ld + k];  MC: element (r,k) at base[k*ld + r].
+template <typename TI, bool KC>
+__device__ __forceinline__ void tile_load(float (&reg)[8], const TI* __restrict__ base, long ld, int r0, int R,
+                                          int k0, int K, int t) {
+  constexpr int V = VecTraits<TI>::V;
+  constexpr int NV = 8 / V;  // vectors per thread
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = t + 256 * i;
+    int r, k;
+    if (KC) {
+      r = v / (GBK / V);
+      k = (v % (GBK / V)) * V;
+    } else {
+      k = v / (GBM / V);
+      r = (v % (GBM / V)) * V;
+    }
+    const bool ok = (r0 + r < R) && (k0 + k < K);
+    const TI* p = KC ? base + (long)(r0 + r) * ld + (k0 + k) : base + (long)(k0 + k) * ld + (r0 + r);
+    if (ok) {
+      if constexpr (V == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(p);
+        reg[4 * i + 0] = x.x; reg[4 * i + 1] = x.y; reg[4 * i + 2] = x.z; reg[4 * i + 3] = x.w;
+      } else {
+        const uint4 x = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          reg[2 * j + 0] = __uint_as_float(w[j] << 16);
+          reg[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+      // zero the tail of a vector that straddles the end of the contiguous dimension
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const bool in = KC ? (k0 + k + j < K) : (r0 + r + j < R);
+        if (!in) reg[V * i + j] = 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) reg[V * i + j] = 0.0f;
+    }
+  }
+}
+
+template <typename TI, bool KC>
+__device__ __forceinline__ void tile_store(const float (&reg)[8], float* __restrict__ S, int t) {
+  constexpr int V = VecTraits<TI>::V;
+  constexpr int NV = 8 / V;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = t + 256 * i;
+    if (KC) {
+      const int r = v / (GBK / V), k = (v % (GBK / V)) * V;
+#pragma unroll
+      for (int j = 0; j < V; ++j) S[(k + j) * GLD + r] = reg[V * i + j];
+    } else {
+      const int k = v / (GBM / V), r = (v % (GBM / V)) * V;
+#pragma unroll
+      for (int j = 0; j < V; j += 4)
+        *reinterpret_cast<float4*>(&S[k * GLD + r + j]) =
+            make_float4(reg[V * i + j], reg[V * i + j + 1], reg[V * i + j + 2], reg[V * i + j + 3]);
+    }
+  }
+}
+
+template <typename TI, typename TO, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_exact_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * GBK * GLD];
+  float* As = smem;
+  float* Bs = smem + 2 * GBK * GLD;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * GBN, m0 = blockIdx.y * GBM;
+
+  const TI* A = reinterpret_cast<const TI*>(g.A);
+  const TI* B = reinterpret_cast<const TI*>(g.B);
+  TO* C = reinterpret_cast<TO*>(g.C);
+  TO* C2 = reinterpret_cast<TO*>(g.C2);
+  const char* aux = reinterpret_cast<const char*>(g.aux);
+  int kbeg = 0, kend = g.K;
+  if (g.splitk > 1) {
+    const int per = ((g.K + g.splitk - 1) / g.splitk + GBK - 1) / GBK * GBK;
+    kbeg = blockIdx.z * per;
+    kend = min(g.K, kbeg + per);
+  } else {
+    const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
+    A += b1 * g.sA1 + b2 * g.sA2;
+    B += b1 * g.sB1 + b2 * g.sB2;
+    const long co = b1 * g.sC1 + b2 * g.sC2;
+    C += co;
+    if (C2) C2 += co;
+    if (aux) aux += co * ((g.epi & EPI_RESIDUAL) ? sizeof(float) : sizeof(TI));
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  float ra[8], rb[8];
+  const int nk = (kend - kbeg + GBK - 1) / GBK;
+  if (nk > 0) {
+    tile_load<TI, A_KC>(ra, A, g.lda, m0, g.M, kbeg, kend, t);
+    tile_load<TI, B_KC>(rb, B, g.ldb, n0, g.N, kbeg, kend, t);
+    tile_store<TI, A_KC>(ra, As, t);
+    tile_store<TI, B_KC>(rb, Bs, t);
+  }
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < nk) {
+      tile_load<TI, A_KC>(ra, A, g.lda, m0, g.M, kbeg + (it + 1) * GBK, kend, t);
+      tile_load<TI, B_KC>(rb, B, g.ldb, n0, g.N, kbeg + (it + 1) * GBK, kend, t);
+    }
+    const float* as = As + cur * GBK * GLD + wm * 64 + (lane & 31);
+    const float* bs = Bs + cur * GBK * GLD + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 2) {
+      const int kr = (kk + (lane >> 5)) * GLD;
+      const float a0 = as[kr], a1 = as[kr + 32];
+      const float b0 = bs[kr], b1 = bs[kr + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (it + 1 < nk) {
+      tile_store<TI, A_KC>(ra, As + (cur ^ 1) * GBK * GLD, t);
+      tile_store<TI, B_KC>(rb, Bs + (cur ^ 1) * GBK * GLD, t);
+    }
+    __syncthreads();
+  }
+
+  // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const int epi = g.epi;
+  const bool first_slice = (g.splitk <= 1) || (blockIdx.z == 0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (row < g.M && col < g.N) {
+          float v = g.alpha * acc[i][j][r];
+          if ((epi & EPI_BIAS) && first_slice) v += g.bias[col];
+          if (epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(aux)[(long)row * g.ld_aux + col];
+          if (epi & EPI_DGELU) v *= gelu_erf_grad(to_f32<TI>(reinterpret_cast<const TI*>(aux)[(long)row * g.ld_aux + col]));
+          const long ci = (long)row * g.ldc + col;
+          if (epi & EPI_SAVE_PREACT) C2[ci] = from_f32<TO>(v);
+          if (epi & EPI_GELU) v = gelu_erf(v);
+          if (epi & EPI_TANH) v = tanhf(v);
+          if (epi & EPI_ATOMIC) {
+            if constexpr (sizeof(TO) == 4) atomicAdd(reinterpret_cast<float*>(C) + ci, v);
+          } else if (epi & EPI_ACCUM) {
+            C[ci] = from_f32<TO>(to_f32<TO>(C[ci]) + v);
+          } else {
+            C[ci] = from_f32<TO>(v);
+          }
+        }
+      }
+}
+
+template <typename TI, typename TO>
+static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t s) {
+  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_exact_kernel<TI, TO, true, true>), grid, dim3(256), 0, s, g);
+  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_exact_kernel<TI, TO, true, false>), grid, dim3(256), 0, s, g);
+  else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_exact_kernel<TI, TO, false, false>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_exact_kernel<TI, TO, false, true>), grid, dim3(256), 0, s, g);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+int rmcl_launch_gemm_exact(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc, hipStream_t s) {
+  const int V = dt_in == RMCL_F32 ? 4 : 8;
+  RMCL_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "gemm: bad dims");
+  RMCL_REQUIRE(g.lda % V == 0 && g.ldb % V == 0, "gemm: lda/ldb must be a multiple of the 16-byte vector width");
+  // a vector may straddle the end of the contiguous dimension only if the row pitch covers it
+  const int Kr = (g.K + V - 1) / V * V, Mr = (g.M + V - 1) / V * V, Nr = (g.N + V - 1) / V * V;
+  RMCL_REQUIRE(a_kc ? (g.lda >= Kr) : (g.lda >= Mr), "gemm: lda too small for vector loads");
+  RMCL_REQUIRE(b_kc ? (g.ldb >= Kr) : (g.ldb >= Nr), "gemm: ldb too small for vector loads");
+  RMCL_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0, "gemm: A/B must be 16-byte aligned");
+  RMCL_REQUIRE(!(g.epi & EPI_ATOMIC) || dt_out == RMCL_F32, "gemm: atomic epilogue needs fp32 C");
+  RMCL_REQUIRE(g.splitk <= 1 || ((g.epi & EPI_ATOMIC) && g.nb1 * g.nb2 == 1), "gemm: split-K needs EPI_ATOMIC and no batching");
+  const int z = g.splitk > 1 ? g.splitk : g.nb1 * g.nb2;
+  RMCL_REQUIRE(z >= 1 && z <= 65535, "gemm: bad batch count");
+  dim3 grid(cdiv(g.N, GBN), cdiv(g.M, GBM), z);
+  if (dt_in == RMCL_F32 && dt_out == RMCL_F32) return launch_layout<float, float>(g, a_kc, b_kc, grid, s);
+  if (dt_in == RMCL_BF16 && dt_out == RMCL_BF16) return launch_layout<bf16_t, bf16_t>(g, a_kc, b_kc, grid, s);
+  if (dt_in == RMCL_BF16 && dt_out == RMCL_F32) return launch_layout<bf16_t, float>(g, a_kc, b_kc, grid, s);
+  if (dt_in == RMCL_F32 && dt_out == RMCL_BF16) return launch_layout<float, bf16_t>(g, a_kc, b_kc, grid, s);
+  rmcl_set_error("gemm: unsupported dtype combination");
+  return -1;
+}

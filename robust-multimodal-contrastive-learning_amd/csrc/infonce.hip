@@ -1,0 +1,249 @@
+// Fused MoCo InfoNCE (objectives.py:328-334,351; pgd_attack_vilt.py:152-158) against the
+// momentum queue, forward + gradient wrt the query in ONE pass over the queue, plus the
+// queue-distance metrics (objectives.py:337-349) as an epilogue.
+//
+//   logits_i = [q_i.k_i, q_i @ queue] / T ;  loss = mean_i (logsumexp(logits_i) - logits_i[0])
+//   dq_i = gscale/T * ( sum_j softmax_ij * key_j - k_i )
+//
+// The [B, 1+Kq] logits (16.8 MB at B=64) and the queue clone are never materialised: each
+// workgroup streams a 128-column slice of the queue (64 KB, coalesced 512-B rows) into LDS once,
+// computes its 64x128 logit tile with the exact-f32 matrix cores, a block-local softmax, and the
+// partial dq = P_tile @ slice^T from the same LDS image; a tiny combine kernel merges the
+// per-slice (max, sum, dq) partials with the usual log-sum-exp rescaling.
+#include "rmcl_common.h"
+#include "kernels.h"
+
+#define PD 128       // projection dim (MOCOHead output, heads.py:129-143)
+#define SLICE 128    // queue columns per workgroup
+#define RT 64        // query rows per workgroup
+#define ILD 129      // LDS row pitch (odd -> conflict-free column & row walks with ds_read_b32)
+#define NPART 8      // per-(slice,row) scalars: m, z, best, best_idx, dist_sum, cos_sum, dot_sum, unused
+
+__global__ __launch_bounds__(256) void infonce_partial_kernel(const float* __restrict__ q, const float* __restrict__ queue, long Kq,
+                                                              int B, float invT, float* __restrict__ part, float* __restrict__ dq_part,
+                                                              int Bpad) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Qs = sm;                    // [PD][ILD]   Qs[c][j]
+  float* qs = Qs + PD * ILD;         // [RT][ILD]   qs[i][c]
+  float* Ps = qs + RT * ILD;         // [RT][ILD]   logits then probabilities
+  float* c2 = Ps + RT * ILD;         // [SLICE] squared column norms
+  float* q2 = c2 + SLICE;            // [RT] squared query norms
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int slice = blockIdx.x, r0 = blockIdx.y * RT;
+  const long j0 = (long)slice * SLICE;
+
+  for (int i = 0; i < 16; ++i) {
+    const int v = t + 256 * i, c = v >> 5, jq = (v & 31) * 4;
+    const float4 x = *reinterpret_cast<const float4*>(queue + (long)c * Kq + j0 + jq);
+    float* d = Qs + c * ILD + jq;
+    d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+  }
+  for (int i = 0; i < 8; ++i) {
+    const int v = t + 256 * i, r = v >> 5, cq = (v & 31) * 4;
+    float4 x = make_float4(0, 0, 0, 0);
+    if (r0 + r < B) x = *reinterpret_cast<const float4*>(q + (long)(r0 + r) * PD + cq);
+    float* d = qs + r * ILD + cq;
+    d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+  }
+  __syncthreads();
+  if (t < SLICE) {
+    float s = 0.f;
+    for (int c = 0; c < PD; ++c) { const float v = Qs[c * ILD + t]; s += v * v; }
+    c2[t] = s;
+  } else if (t < SLICE + RT) {
+    const int r = t - SLICE;
+    float s = 0.f;
+    for (int c = 0; c < PD; ++c) { const float v = qs[r * ILD + c]; s += v * v; }
+    q2[r] = s;
+  }
+
+  const int wm = wave >> 1, wn = wave & 1;
+  {  // step 1: S[64 x 128] = qs @ Qs   (A[i][k=c] = qs, B[k=c][j] = Qs)
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    const float* ap = qs + (32 * wm + (lane & 31)) * ILD + (lane >> 5);
+    const float* bp = Qs + (lane >> 5) * ILD + 64 * wn + (lane & 31);
+#pragma unroll 8
+    for (int k = 0; k < PD; k += 2) {
+      const float a = ap[k], b0 = bp[k * ILD], b1 = bp[k * ILD + 32];
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = 64 * wn + (lane & 31);
+      Ps[row * ILD + col] = a0[r];
+      Ps[row * ILD + col + 32] = a1[r];
+    }
+  }
+  __syncthreads();
+  {  // step 2: per-row block softmax + metrics; 4 threads per row, columns interleaved by 4
+    const int row = t >> 2, sub = t & 3;
+    float m = -INFINITY, best = -INFINITY;
+    int bi = 0;
+    float sd = 0.f, sc = 0.f, so = 0.f;
+    const float qq = q2[row];
+    for (int i = 0; i < SLICE / 4; ++i) {
+      const int col = 4 * i + sub;
+      const float dot = Ps[row * ILD + col];
+      if (dot > best) { best = dot; bi = col; }
+      const float cc = c2[col];
+      sd += sqrtf(fmaxf(qq + cc - 2.f * dot, 0.f));
+      sc += dot / fmaxf(sqrtf(qq) * sqrtf(cc), 1e-6f);
+      so += dot;
+    }
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      sd += __shfl_xor(sd, o, 64);
+      sc += __shfl_xor(sc, o, 64);
+      so += __shfl_xor(so, o, 64);
+    }
+    m = best * invT;
+    float z = 0.f;
+    for (int i = 0; i < SLICE / 4; ++i) {
+      const int col = 4 * i + sub;
+      const float p = __expf(Ps[row * ILD + col] * invT - m);
+      Ps[row * ILD + col] = p;
+      z += p;
+    }
+    z += __shfl_xor(z, 1, 64);
+    z += __shfl_xor(z, 2, 64);
+    if (sub == 0 && r0 + row < B) {
+      float* o = part + ((long)slice * Bpad + r0 + row) * NPART;
+      o[0] = m; o[1] = z; o[2] = best; o[3] = __int_as_float((int)(j0 + bi));
+      o[4] = sd; o[5] = sc; o[6] = so; o[7] = 0.f;
+    }
+  }
+  __syncthreads();
+  {  // step 3: dq_part[64 x 128(c)] = Ps[64 x 128(j)] @ Qs^T  (A[i][k=j] = Ps, B[k=j][c] = Qs[c][j])
+    f32x16 a0, a1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    const float* ap = Ps + (32 * wm + (lane & 31)) * ILD + (lane >> 5);
+    const float* bp0 = Qs + (64 * wn + (lane & 31)) * ILD + (lane >> 5);
+    const float* bp1 = bp0 + 32 * ILD;
+#pragma unroll 8
+    for (int k = 0; k < SLICE; k += 2) {
+      const float a = ap[k];
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[k], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[k], a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = 64 * wn + (lane & 31);
+      if (row < B) {
+        float* o = dq_part + ((long)slice * Bpad + row) * PD;
+        o[col] = a0[r];
+        o[col + 32] = a1[r];
+      }
+    }
+  }
+}
+
+// One workgroup (128 threads = PD) per query row: merge slice partials, add the positive pair.
+// rows_out[i, 0..9] = loss_i, pred_i (argmax of the logits incl. the positive at index 0),
+//   l_pos, pos_dist, pos_cos, pos_dot, neg_dist_mean, neg_cos_mean, neg_dot_mean, logsumexp
+__global__ __launch_bounds__(PD) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ part, const float* __restrict__ dq_part,
+                                                             int nslice, int B, int Bpad, long Kq, float invT, float gscale,
+                                                             float* __restrict__ dq, float* __restrict__ rows_out,
+                                                             float* __restrict__ loss_sum) {
+  __shared__ float red[4][2];
+  __shared__ float sh[8];
+  const int i = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+  const float qc = q[(long)i * PD + c], kc = k[(long)i * PD + c];
+  float s_qk = wave_sum(qc * kc), s_qq = wave_sum(qc * qc), s_kk = wave_sum(kc * kc), s_d = wave_sum((qc - kc) * (qc - kc));
+  if (lane == 0) { red[0][wave] = s_qk; red[1][wave] = s_qq; red[2][wave] = s_kk; red[3][wave] = s_d; }
+  __syncthreads();
+  const float dotp = red[0][0] + red[0][1], qq = red[1][0] + red[1][1], kk = red[2][0] + red[2][1], dd = red[3][0] + red[3][1];
+  const float lpos = dotp * invT;
+  // pass 1 over the slice scalars (strided over threads), reduce max / best
+  float M = lpos, best = -INFINITY;
+  int bidx = 0;
+  float sd = 0.f, sc = 0.f, so = 0.f;
+  for (int s = c; s < nslice; s += PD) {
+    const float* o = part + ((long)s * Bpad + i) * NPART;
+    M = fmaxf(M, o[0]);
+    const int oi = __float_as_int(o[3]);
+    if (o[2] > best || (o[2] == best && oi < bidx)) { best = o[2]; bidx = oi; }
+    sd += o[4]; sc += o[5]; so += o[6];
+  }
+  __syncthreads();
+  // block reductions through LDS (2 waves)
+  M = wave_max(M);
+  sd = wave_sum(sd); sc = wave_sum(sc); so = wave_sum(so);
+  float wb = best; int wi = bidx;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(wb, o, 64); const int oi = __shfl_xor(wi, o, 64);
+    if (ob > wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
+  }
+  __shared__ float r2[2][8];
+  if (lane == 0) { r2[wave][0] = M; r2[wave][1] = sd; r2[wave][2] = sc; r2[wave][3] = so; r2[wave][4] = wb; r2[wave][5] = __int_as_float(wi); }
+  __syncthreads();
+  M = fmaxf(r2[0][0], r2[1][0]);
+  sd = r2[0][1] + r2[1][1]; sc = r2[0][2] + r2[1][2]; so = r2[0][3] + r2[1][3];
+  {
+    const float b0 = r2[0][4], b1 = r2[1][4];
+    const int i0 = __float_as_int(r2[0][5]), i1 = __float_as_int(r2[1][5]);
+    if (b1 > b0 || (b1 == b0 && i1 < i0)) { best = b1; bidx = i1; } else { best = b0; bidx = i0; }
+  }
+  // pass 2: Z and dq (each thread owns column c of dq)
+  float Z = 0.f, acc = 0.f;
+  for (int s = 0; s < nslice; ++s) {
+    const float* o = part + ((long)s * Bpad + i) * NPART;
+    const float f = __expf(o[0] - M);
+    Z += o[1] * f;
+    acc += f * dq_part[((long)s * Bpad + i) * PD + c];
+  }
+  const float epos = __expf(lpos - M);
+  Z += epos;
+  const float lse = logf(Z) + M;
+  if (dq) dq[(long)i * PD + c] = gscale * invT * ((epos / Z - 1.0f) * kc + acc / Z);
+  if (c == 0) {
+    float* o = rows_out + (long)i * 10;
+    const float loss = lse - lpos;
+    o[0] = loss;
+    o[1] = (dotp >= best) ? 0.f : (float)(bidx + 1);
+    o[2] = lpos;
+    o[3] = sqrtf(dd);
+    o[4] = dotp / fmaxf(sqrtf(qq) * sqrtf(kk), 1e-6f);
+    o[5] = dotp;
+    o[6] = sd / (float)Kq; o[7] = sc / (float)Kq; o[8] = so / (float)Kq;
+    o[9] = lse;
+    if (loss_sum) atomicAdd(loss_sum, loss / (float)B);
+  }
+  (void)sh;
+}
+
+long rmcl_infonce_workspace_bytes(int B, long Kq) {
+  const long Bpad = (B + RT - 1) / RT * RT, ns = Kq / SLICE;
+  return ns * Bpad * (NPART + PD) * (long)sizeof(float);
+}
+
+int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int Pd, long Kq, float T, float gscale, float* dq,
+                 float* rows_out, float* loss_sum, void* workspace, hipStream_t s) {
+  RMCL_REQUIRE(Pd == PD, "infonce: projection dim must be 128");
+  RMCL_REQUIRE(Kq % SLICE == 0 && Kq > 0, "infonce: queue length must be a multiple of 128");
+  RMCL_REQUIRE(B > 0, "infonce: empty batch");
+  const int Bpad = (B + RT - 1) / RT * RT, ns = (int)(Kq / SLICE);
+  float* part = reinterpret_cast<float*>(workspace);
+  float* dq_part = part + (long)ns * Bpad * NPART;
+  const size_t lds = (PD * ILD + 2 * RT * ILD + SLICE + RT) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(infonce_partial_kernel, dim3(ns, Bpad / RT), dim3(256), lds, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
+  RMCL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(infonce_combine_kernel, dim3(B), dim3(PD), 0, s, q, k, part, dq_part, ns, B, Bpad, Kq, 1.0f / T, gscale, dq,
+                     rows_out, loss_sum);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,55 @@
+// Internal launcher declarations (host side, C++ linkage).  Every launcher enqueues on `s`,
+// allocates nothing, never synchronises, and returns 0 or an error code after rmcl_set_error().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include "gemm.h"
+
+int rmcl_launch_gemm_exact(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc, hipStream_t s);
+int rmcl_launch_gemm_fast(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s);  // bf16 in
+bool rmcl_gemm_fast_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc);
+
+int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float eps, void* y, long ldy, int dt_out,
+                float* mean, float* rstd, int M, int D, int relu, hipStream_t s);
+int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
+                const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
+                int relu, hipStream_t s);
+int rmcl_softmax_fwd(const float* S, long lds, const int* mask, void* P, long ldp, int dt, int Z, int N, int H, hipStream_t s);
+int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* dS, long ldds, int dt, int Z, int N,
+                     float scale, hipStream_t s);
+int rmcl_colsum(const void* X, long ld, int dt, float* out, int M, int N, hipStream_t s);
+
+int rmcl_text_embed_fwd(const long* ids, const float* word, const float* pos, const float* btype0, const float* g,
+                        const float* beta, const float* vtype0, float eps, float* x, float* e_save, float* mean, float* rstd,
+                        int B, int L, int N, int D, hipStream_t s);
+int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, float* dpos, float* dbtype0, int B, int L, int D,
+                            long pad_id, hipStream_t s);
+int rmcl_gather_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, hipStream_t s);
+int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, int add, hipStream_t s);
+int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos, const float* vtype1, float* x, int B, int P,
+                            int L, int N, int D, hipStream_t s);
+int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,
+                            int N, int D, hipStream_t s);
+int rmcl_im2patch(const float* img, float* pat, int B, int C, int Hh, int Ww, int ps, int to_image, hipStream_t s);
+int rmcl_k_add_cast(const float* a, const float* d1, const float* d2, void* out, int dt, long n, hipStream_t s);
+int rmcl_cast(const float* in, void* out, int dt, long n, hipStream_t s);
+int rmcl_co_mask(const long* text_mask, const void* pat, int dt, int* co, int B, int L, int P, int C, int pp, hipStream_t s);
+int rmcl_pgd_update(const void* g, int dt, float* delta, unsigned* amax_bits, int B, long per_sample, float lr, float eps, hipStream_t s);
+int rmcl_delta_chan_norm(const float* d, float* out, long rows, int C, int pp, hipStream_t s);
+int rmcl_ema(float* k, const float* q, void* k_lp, float m, long n, hipStream_t s);
+int rmcl_enqueue(float* queue, const float* keys, int n, int Pd, long Kq, long ptr, hipStream_t s);
+int rmcl_l2norm_fwd(const float* z, float* q, float* nrm, int R, int D, float eps, hipStream_t s);
+int rmcl_l2norm_bwd(const float* dq, const float* q, const float* nrm, float* dz, int R, int D, hipStream_t s);
+int rmcl_tanh_bwd(float* g, const float* y, long n, hipStream_t s);
+int rmcl_adamw(float* p, const float* g, float* m, float* v, void* p_lp, const long* seg_end, const float* seg_lr_mult,
+               const float* seg_wd, int nseg, float lr, float b1, float b2, float eps, int step, float grad_scale, long n,
+               hipStream_t s);
+
+long rmcl_infonce_workspace_bytes(int B, long Kq);
+int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int Pd, long Kq, float T, float gscale, float* dq,
+                 float* rows_out, float* loss_sum, void* workspace, hipStream_t s);
+
+int rmcl_cost_finish(float* cost, const int* txt_valid, const int* img_valid, int B, int Lt, int Li, hipStream_t s);
+int rmcl_wpa_dist(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, hipStream_t s);
+int rmcl_ipot(const float* cost, const int* txt_valid, const int* img_valid, float* T, int B, int Lt, int Li, float beta,
+              int iters, hipStream_t s);

@@ -1,0 +1,296 @@
+// LayerNorm forward/backward, masked row softmax forward/backward, column sums.
+// All are HBM-bound row kernels: one 64-lane wave per row, 16-byte vector accesses, f32 math.
+#include "rmcl_common.h"
+#include "kernels.h"
+
+#define LN_MAXV 4  // float4 per lane -> D <= 1024
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x - mean) * rstd * w + b  (optionally ReLU), x f32 [M,D], y TO [M,D]
+// ---------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float eps, TO* __restrict__ y, long ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                     int relu) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (long)row * ldx;
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) {
+      v[i] = *reinterpret_cast<const float4*>(xr + c);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) {
+      const float a = v[i].x - mu, bb = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+      q += a * a + bb * bb + cc * cc + d * d;
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+  TO* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) {
+      const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
+      float o[4] = {(v[i].x - mu) * rs * ww.x + bb.x, (v[i].y - mu) * rs * ww.y + bb.y,
+                    (v[i].z - mu) * rs * ww.z + bb.z, (v[i].w - mu) * rs * ww.w + bb.w};
+      if (relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+      }
+      if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+        pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+        *reinterpret_cast<uint2*>(yr + c) = pk;
+      }
+    }
+  }
+}
+
+int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float eps, void* y, long ldy, int dt_out,
+                float* mean, float* rstd, int M, int D, int relu, hipStream_t s) {
+  RMCL_REQUIRE(D % 4 == 0 && D <= 256 * LN_MAXV && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: D must be a multiple of 4 and <= 1024");
+  if (M <= 0) return 0;
+  dim3 grid(cdiv(M, 4));
+  if (dt_out == RMCL_F32)
+    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, s, x, ldx, w, b, eps, (float*)y, ldy, mean, rstd, M, D, relu);
+  else
+    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, w, b, eps, (bf16_t*)y, ldy, mean, rstd, M, D, relu);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward.  dy TG [M,D] (grad of the LN output, before the optional ReLU mask),
+//   dx_out = (add ? dx_out : 0) + rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy * w
+//   dgamma += sum_rows dy*xhat, dbeta += sum_rows dy   (optional, fp32 atomics, one add per block)
+// relu: dy is first masked with (xhat*w + b > 0).
+// Rows handled per block: LNB_ROWS waves x LNB_ITERS rows, so dgamma/dbeta partials are reduced
+// in registers over LNB_ITERS rows, then across the 4 waves through LDS, then one atomic per column.
+// ---------------------------------------------------------------------------------------------
+#define LNB_ITERS 8
+template <typename TG>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ w, const float* __restrict__ b,
+                                                     float* __restrict__ dx, long lddx, int add, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int D, int relu) {
+  __shared__ float red[2][4][64 * 4 * LN_MAXV];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 gw[LN_MAXV], gb[LN_MAXV], ww[LN_MAXV], bb[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    gw[i] = make_float4(0, 0, 0, 0);
+    gb[i] = make_float4(0, 0, 0, 0);
+    const int c = (lane + 64 * i) * 4;
+    if (c < D) {
+      ww[i] = *reinterpret_cast<const float4*>(w + c);
+      bb[i] = relu ? *reinterpret_cast<const float4*>(b + c) : make_float4(0, 0, 0, 0);
+    }
+  }
+  for (int it = 0; it < LNB_ITERS; ++it) {
+    const int row = (blockIdx.x * LNB_ITERS + it) * 4 + wave;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[LN_MAXV], g[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < D) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (long)row * ldx + c);
+        float d[4];
+        if constexpr (sizeof(TG) == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(dy + (long)row * lddy + c);
+          d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        } else {
+          const uint2 t = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + c);
+          d[0] = __uint_as_float(t.x << 16); d[1] = __uint_as_float(t.x & 0xffff0000u);
+          d[2] = __uint_as_float(t.y << 16); d[3] = __uint_as_float(t.y & 0xffff0000u);
+        }
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        if (relu) {
+          if (xh[i].x * ww[i].x + bb[i].x <= 0.f) d[0] = 0.f;
+          if (xh[i].y * ww[i].y + bb[i].y <= 0.f) d[1] = 0.f;
+          if (xh[i].z * ww[i].z + bb[i].z <= 0.f) d[2] = 0.f;
+          if (xh[i].w * ww[i].w + bb[i].w <= 0.f) d[3] = 0.f;
+        }
+        gb[i].x += d[0]; gb[i].y += d[1]; gb[i].z += d[2]; gb[i].w += d[3];
+        gw[i].x += d[0] * xh[i].x; gw[i].y += d[1] * xh[i].y; gw[i].z += d[2] * xh[i].z; gw[i].w += d[3] * xh[i].w;
+        g[i] = make_float4(d[0] * ww[i].x, d[1] * ww[i].y, d[2] * ww[i].z, d[3] * ww[i].w);
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+      }
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < D) {
+        float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
+                               rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
+        float* p = dx + (long)row * lddx + c;
+        if (add) {
+          const float4 old = *reinterpret_cast<const float4*>(p);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(p) = o;
+      }
+    }
+  }
+  if (dgamma) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < D) {
+        *reinterpret_cast<float4*>(&red[0][wave][c]) = gw[i];
+        *reinterpret_cast<float4*>(&red[1][wave][c]) = gb[i];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+      atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+      atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+  }
+}
+
+int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
+                const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
+                int relu, hipStream_t s) {
+  RMCL_REQUIRE(D % 4 == 0 && D <= 256 * LN_MAXV && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm bwd: bad D/ld");
+  if (M <= 0) return 0;
+  dim3 grid(cdiv(M, 4 * LNB_ITERS));
+  if (dt_dy == RMCL_F32)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Masked row softmax (attention scores).  S f32 [Z, N, lds] -> P T [Z, N, ldp]; key j of batch
+// b = z / H is dropped (exact 0 probability, like masked_fill(-inf)) when mask[b*N + j] == 0.
+// Pad columns N..ldp-1 are written as zeros so that P can be a GEMM operand with K = N.
+// ---------------------------------------------------------------------------------------------
+#define SM_MAXE 8  // elements per lane -> N <= 512
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, long lds, const int* __restrict__ mask,
+                                                          T* __restrict__ P, long ldp, int rows, int N, int H) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const int b = (int)(row / ((long)N * H));
+  const float* sr = S + row * lds;
+  const int* mr = mask + (long)b * N;
+  float v[SM_MAXE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    const int j = lane + 64 * i;
+    v[i] = (j < N && mr[j] != 0) ? sr[j] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    v[i] = (v[i] == -INFINITY) ? 0.f : __expf(v[i] - mx);
+    sum += v[i];
+  }
+  const float inv = 1.0f / wave_sum(sum);
+  T* pr = P + row * ldp;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    const int j = lane + 64 * i;
+    if (j < ldp) pr[j] = from_f32<T>(j < N ? v[i] * inv : 0.f);
+  }
+}
+
+int rmcl_softmax_fwd(const float* S, long lds, const int* mask, void* P, long ldp, int dt, int Z, int N, int H, hipStream_t s) {
+  RMCL_REQUIRE(N <= 64 * SM_MAXE && ldp <= 64 * SM_MAXE, "softmax: N too large");
+  const long rows = (long)Z * N;
+  dim3 grid(cdiv(rows, 4));
+  if (dt == RMCL_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, dim3(256), 0, s, S, lds, mask, (float*)P, ldp, (int)rows, N, H);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, S, lds, mask, (bf16_t*)P, ldp, (int)rows, N, H);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// dS = scale * P * (dP - sum_j dP_j P_j)   (P T, dP f32, dS T; pads written as zero)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, long ldp, const float* __restrict__ dP, long lddp,
+                                                          T* __restrict__ dS, long ldds, int rows, int N, float scale) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float p[SM_MAXE], d[SM_MAXE];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    const int j = lane + 64 * i;
+    p[i] = j < N ? to_f32<T>(P[row * ldp + j]) : 0.f;
+    d[i] = j < N ? dP[row * lddp + j] : 0.f;
+    dot += p[i] * d[i];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < SM_MAXE; ++i) {
+    const int j = lane + 64 * i;
+    if (j < ldds) dS[row * ldds + j] = from_f32<T>(j < N ? scale * p[i] * (d[i] - dot) : 0.f);
+  }
+}
+
+int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* dS, long ldds, int dt, int Z, int N,
+                     float scale, hipStream_t s) {
+  RMCL_REQUIRE(N <= 64 * SM_MAXE && ldds <= 64 * SM_MAXE, "softmax bwd: N too large");
+  const long rows = (long)Z * N;
+  dim3 grid(cdiv(rows, 4));
+  if (dt == RMCL_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)P, ldp, dP, lddp, (float*)dS, ldds, (int)rows, N, scale);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)P, ldp, dP, lddp, (bf16_t*)dS, ldds, (int)rows, N, scale);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums (bias gradients): out[n] += sum_m X[m*ld + n].  Block = 64 columns x 4 row-lanes.
+// ---------------------------------------------------------------------------------------------
+#define CS_ROWS 256
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, long ld, float* __restrict__ out, int M, int N) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float acc = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) acc += to_f32<T>(X[(long)r * ld + c]);
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < N) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int rmcl_colsum(const void* X, long ld, int dt, float* out, int M, int N, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  dim3 grid(cdiv(N, 64), cdiv(M, CS_ROWS));
+  if (dt == RMCL_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ld, out, M, N);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ld, out, M, N);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}

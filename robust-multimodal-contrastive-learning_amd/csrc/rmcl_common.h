@@ -1,0 +1,74 @@
+// Common device/host helpers for the RMCL gfx950 kernels.  gfx950 (CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#define RMCL_F32 0
+#define RMCL_BF16 1
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __hip_bfloat16 h = __float2bfloat16(f);  // RNE, NaN-preserving (v_cvt_pk_bf16_f32 at -O3)
+  return *reinterpret_cast<bf16_t*>(&h);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f2bf(v); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host side -------------------------------------------------------------------------------
+#ifdef __cplusplus
+extern "C" void rmcl_set_error(const char* msg);
+#endif
+
+#define RMCL_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t _e = hipGetLastError();                        \
+    if (_e != hipSuccess) {                                   \
+      rmcl_set_error(hipGetErrorString(_e));                  \
+      return (int)_e;                                         \
+    }                                                         \
+  } while (0)
+
+#define RMCL_REQUIRE(cond, msg)                               \
+  do {                                                        \
+    if (!(cond)) {                                            \
+      rmcl_set_error("rmcl: requirement failed: " msg);       \
+      return -1;                                              \
+    }                                                         \
+  } while (0)
+
+#define RMCL_TRY(expr)                                        \
+  do {                                                        \
+    int _r = (expr);                                          \
+    if (_r != 0) return _r;                                   \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,241 @@
+"""Device runtime under the ViLTransformerSS mirror: flat parameter arenas in HBM, per-batch
+activation stashes / workspaces, and thin wrappers over the C ABI (include/rmcl.h).
+
+Data layout in HBM (DESIGN.md "Data layout"):
+  * q32 / k32     : fp32 parameter arenas (query / momentum), offsets from rmcl_param_layout();
+                    the momentum update, AdamW and the gradient all-reduce are single passes
+                    over these flat buffers instead of 161 per-tensor ops.
+  * q_lp / k_lp   : bf16 shadows of the GEMM weights (bf16 mode only).
+  * g32           : fp32 gradient arena, same offsets; the backward kernels accumulate into it.
+  * images are converted ONCE per step to patch rows [B*144, 3072] (the K-order of the
+    patch-embedding GEMM); delta, the PGD gradient and the attacked view stay in that layout.
+torch is used for allocation, streams and torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check, P, I64, F
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_dims(cfg: dict, B: int, dtype: int, exact: bool) -> L.Dims:
+    ps = cfg["patch_size"]
+    g = cfg["image_size"] // ps
+    return L.Dims(B=B, L=cfg["max_text_len"], P=g * g, D=cfg["hidden_size"], H=cfg["num_heads"],
+                  layers=cfg["num_layers"], mlp=cfg["hidden_size"] * cfg["mlp_ratio"], patch_k=3 * ps * ps,
+                  proj=128, vocab=cfg["vocab_size"], dtype=dtype, exact=int(exact))
+
+
+def param_specs(cfg: dict, lay: L.Layout) -> List[Tuple[str, int, Tuple[int, ...]]]:
+    """(reference state-dict name, arena element offset, shape) for every query-side parameter."""
+    D = cfg["hidden_size"]
+    ps = cfg["patch_size"]
+    g = cfg["image_size"] // ps
+    Hm = D * cfg["mlp_ratio"]
+    s = [
+        ("text_embeddings.word_embeddings.weight", lay.word, (cfg["vocab_size"], D)),
+        ("text_embeddings.position_embeddings.weight", lay.pos, (cfg["max_text_len"], D)),
+        ("text_embeddings.token_type_embeddings.weight", lay.btype, (2, D)),
+        ("text_embeddings.LayerNorm.weight", lay.eln_w, (D,)),
+        ("text_embeddings.LayerNorm.bias", lay.eln_b, (D,)),
+        ("token_type_embeddings.weight", lay.vtype, (2, D)),
+        ("transformer.cls_token", lay.cls, (1, 1, D)),
+        ("transformer.pos_embed", lay.pos_img, (1, g * g + 1, D)),
+        ("transformer.patch_embed.proj.weight", lay.patch_w, (D, 3, ps, ps)),
+        ("transformer.patch_embed.proj.bias", lay.patch_b, (D,)),
+    ]
+    for i in range(cfg["num_layers"]):
+        b = lay.layer0 + i * lay.layer_stride
+        n = f"transformer.blocks.{i}."
+        s += [
+            (n + "norm1.weight", b + lay.ln1_w, (D,)), (n + "norm1.bias", b + lay.ln1_b, (D,)),
+            (n + "attn.qkv.weight", b + lay.qkv_w, (3 * D, D)), (n + "attn.qkv.bias", b + lay.qkv_b, (3 * D,)),
+            (n + "attn.proj.weight", b + lay.proj_w, (D, D)), (n + "attn.proj.bias", b + lay.proj_b, (D,)),
+            (n + "norm2.weight", b + lay.ln2_w, (D,)), (n + "norm2.bias", b + lay.ln2_b, (D,)),
+            (n + "mlp.fc1.weight", b + lay.fc1_w, (Hm, D)), (n + "mlp.fc1.bias", b + lay.fc1_b, (Hm,)),
+            (n + "mlp.fc2.weight", b + lay.fc2_w, (D, Hm)), (n + "mlp.fc2.bias", b + lay.fc2_b, (D,)),
+        ]
+    s += [
+        ("transformer.norm.weight", lay.norm_w, (D,)), ("transformer.norm.bias", lay.norm_b, (D,)),
+        ("moco_head.projector.0.weight", lay.mh0_w, (D, D)), ("moco_head.projector.0.bias", lay.mh0_b, (D,)),
+        ("moco_head.projector.1.weight", lay.mh1_w, (D,)), ("moco_head.projector.1.bias", lay.mh1_b, (D,)),
+        ("moco_head.projector.3.weight", lay.mh3_w, (128, D)),
+        ("pooler.dense.weight", lay.pool_w, (D, D)), ("pooler.dense.bias", lay.pool_b, (D,)),
+        ("itm_score.fc.weight", lay.itm_w, (2, D)), ("itm_score.fc.bias", lay.itm_b, (2,)),
+    ]
+    return s
+
+
+EMA_GROUPS = ("text_embeddings", "token_type_embeddings", "transformer", "moco_head")
+
+
+class PassBuffers:
+    """Everything sized by the per-GPU batch B (allocated once, reused every step)."""
+
+    def __init__(self, eng: "Engine", B: int):
+        dev = eng.device
+        d = eng.dims(B)
+        self.B = B
+        self.d = d
+        N = d.L + 1 + d.P
+        M = B * N
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.workspace = u8(lib.rmcl_workspace_bytes(C.byref(d)))
+        self.stash_full = u8(lib.rmcl_stash_bytes(C.byref(d), L.MODE_FULL))
+        self.stash_data = u8(lib.rmcl_stash_bytes(C.byref(d), L.MODE_DATA))
+        self.hstash_q = u8(lib.rmcl_heads_stash_bytes(C.byref(d)))
+        self.hstash_k = u8(lib.rmcl_heads_stash_bytes(C.byref(d)))
+        self.co_mask = torch.empty(B, N, dtype=torch.int32, device=dev)
+        self.xn = f32(M, d.D)
+        self.patches32 = f32(B * d.P, d.patch_k)
+        tdt = torch.float32 if eng.dtype == L.F32 else torch.bfloat16
+        self.patchesT = torch.empty(B * d.P, d.patch_k, dtype=tdt, device=dev)
+        self.patchesT_full = torch.empty(B * d.P, d.patch_k, dtype=tdt, device=dev)
+        self.gpatch = torch.empty(B * d.P, d.patch_k, dtype=tdt, device=dev)
+        self.delta = f32(B * d.P, d.patch_k)
+        self.delta_prev = f32(B * d.P, d.patch_k)
+        self.amax = torch.empty(B, dtype=torch.int32, device=dev)
+        self.cls = f32(B, d.D)
+        self.q = f32(B, d.proj)
+        self.k = f32(B, d.proj)
+        self.dq = f32(B, d.proj)
+        self.dcls = f32(B, d.D)
+        self.rows = f32(B, 10)
+        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.nce_ws = u8(lib.rmcl_infonce_ws_bytes(B, I64(eng.num_negative)))
+        self.text_ids = None
+        self.text_mask = None
+
+
+class Engine:
+    def __init__(self, cfg: dict, device, dtype: str = "bf16", exact: bool = False):
+        if not torch.cuda.is_available():
+            raise L.RmclError("rmcl_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = {"f32": L.F32, "fp32": L.F32, "bf16": L.BF16}[dtype]
+        self.exact = bool(exact) or self.dtype == L.F32
+        self.num_negative = int(cfg.get("num_negative", 65536))
+        d0 = self.dims(1)
+        self.layout = L.Layout()
+        lib.rmcl_param_layout(C.byref(d0), C.byref(self.layout))
+        lay = self.layout
+        z = lambda n, dt=torch.float32: torch.zeros(int(n), dtype=dt, device=self.device)
+        self.q32 = z(lay.total)
+        self.k32 = z(lay.ema_end)
+        self.g32 = z(lay.total)
+        self.q_lp = z(lay.total, torch.bfloat16) if self.dtype == L.BF16 else None
+        self.k_lp = z(lay.ema_end, torch.bfloat16) if self.dtype == L.BF16 else None
+        self.specs = param_specs(cfg, lay)
+        self._bufs: Dict[int, PassBuffers] = {}
+        self.lp_stale = True
+
+    # ---- geometry ------------------------------------------------------------------------------
+    def dims(self, B: int) -> L.Dims:
+        return make_dims(self.cfg, B, self.dtype, getattr(self, "exact", False))
+
+    def bufs(self, B: int) -> PassBuffers:
+        if B not in self._bufs:
+            self._bufs[B] = PassBuffers(self, B)
+        return self._bufs[B]
+
+    def view(self, arena: torch.Tensor, off: int, shape) -> torch.Tensor:
+        n = 1
+        for s in shape:
+            n *= s
+        return arena[off:off + n].view(*shape)
+
+    # ---- parameter maintenance -----------------------------------------------------------------
+    def refresh_shadows(self):
+        """bf16 shadows of the query / momentum weights (after load_state_dict or an optimizer step)."""
+        if self.dtype == L.BF16:
+            check(lib.rmcl_cast_f32(P(self.q32), P(self.q_lp), L.BF16, I64(self.q32.numel()), stream_ptr()), "cast")
+            check(lib.rmcl_cast_f32(P(self.k32), P(self.k_lp), L.BF16, I64(self.k32.numel()), stream_ptr()), "cast")
+        self.lp_stale = False
+
+    def ema(self, m: float):
+        n = self.layout.ema_end
+        check(lib.rmcl_ema_f32(P(self.k32), P(self.q32), P(self.k_lp), F(m), I64(n), stream_ptr()), "ema")
+
+    def zero_grads(self):
+        self.g32.zero_()
+
+    # ---- per-step data -------------------------------------------------------------------------
+    def bind_batch(self, text_ids: torch.Tensor, text_mask: torch.Tensor, image: torch.Tensor) -> PassBuffers:
+        B, Cc, Hh, Ww = image.shape
+        ps = self.cfg["patch_size"]
+        g = self.cfg["image_size"] // ps
+        if Cc != 3 or Hh != g * ps or Ww != g * ps:
+            raise NotImplementedError(
+                f"dense visual_embed path needs {g * ps}x{g * ps} images (got {Hh}x{Ww}); the ragged "
+                "select/pad path of vision_transformer.py:605-651 is not built yet")
+        pb = self.bufs(B)
+        pb.text_ids = text_ids.to(self.device, torch.int64).contiguous()
+        pb.text_mask = text_mask.to(self.device, torch.int64).contiguous()
+        img = image.to(self.device, torch.float32).contiguous()
+        check(lib.rmcl_im2patch_f32(P(img), P(pb.patches32), B, 3, Hh, Ww, ps, 0, stream_ptr()), "im2patch")
+        return pb
+
+    def patches_to_image(self, pat: torch.Tensor, B: int) -> torch.Tensor:
+        S = self.cfg["image_size"]
+        out = torch.empty(B, 3, S, S, dtype=torch.float32, device=self.device)
+        check(lib.rmcl_im2patch_f32(P(out), P(pat), B, 3, S, S, self.cfg["patch_size"], 1, stream_ptr()), "patch2im")
+        return out
+
+    def make_operand(self, pb: PassBuffers, d1=None, d2=None, out=None) -> torch.Tensor:
+        """out = cast(patches32 + d1 + d2): the `img_init + img_delta` of pgd_attack_vilt.py:144."""
+        out = pb.patchesT if out is None else out
+        check(lib.rmcl_add_cast_f32(P(pb.patches32), P(d1), P(d2), P(out), self.dtype,
+                                    I64(pb.patches32.numel()), stream_ptr()), "add_cast")
+        return out
+
+    # ---- encoder passes ------------------------------------------------------------------------
+    def encoder_forward(self, pb: PassBuffers, key: bool, mode: int, patchesT: torch.Tensor):
+        if self.lp_stale:
+            self.refresh_shadows()
+        p32, plp = (self.k32, self.k_lp) if key else (self.q32, self.q_lp)
+        stash = {L.MODE_INFER: None, L.MODE_DATA: pb.stash_data, L.MODE_FULL: pb.stash_full}[mode]
+        check(lib.rmcl_encoder_forward(C.byref(pb.d), mode, P(p32), P(plp), P(pb.text_ids), P(pb.text_mask), P(patchesT),
+                                       P(pb.co_mask), P(stash), P(pb.workspace), P(pb.xn), stream_ptr()), "encoder_forward")
+
+    def heads_forward(self, pb: PassBuffers, key: bool, want_q: bool = True):
+        head = self.k32 if key else self.q32
+        hst = pb.hstash_k if key else pb.hstash_q
+        out_q = (pb.k if key else pb.q) if want_q else None
+        check(lib.rmcl_heads_forward(C.byref(pb.d), P(self.q32), P(head), P(pb.xn), P(hst), P(pb.cls), P(out_q),
+                                     stream_ptr()), "heads_forward")
+
+    def infonce(self, pb: PassBuffers, grad_scale: float, want_dq: bool):
+        pb.loss_sum.zero_()
+        check(lib.rmcl_infonce_f32(P(pb.q), P(pb.k), P(self.queue), pb.B, 128, I64(self.num_negative),
+                                   F(self.cfg["temperature"]), F(grad_scale), P(pb.dq if want_dq else None), P(pb.rows),
+                                   P(pb.loss_sum), P(pb.nce_ws), stream_ptr()), "infonce")
+
+    def heads_backward(self, pb: PassBuffers, dq, dcls_extra, with_grads: bool):
+        check(lib.rmcl_heads_backward(C.byref(pb.d), P(self.q32), P(self.q32), P(pb.hstash_q), P(dq), P(dcls_extra),
+                                      P(pb.dcls), P(self.g32 if with_grads else None), P(pb.workspace), stream_ptr()),
+              "heads_backward")
+
+    def encoder_backward(self, pb: PassBuffers, mode: int, patchesT, dxn, cls_only: bool, dpatches):
+        stash = pb.stash_data if mode == L.MODE_DATA else pb.stash_full
+        check(lib.rmcl_encoder_backward(C.byref(pb.d), mode, P(self.q32), P(self.q_lp), P(pb.text_ids), P(patchesT),
+                                        P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), int(cls_only), P(dpatches),
+                                        P(self.g32 if mode == L.MODE_FULL else None), stream_ptr()), "encoder_backward")
+
+    def pgd_step(self, pb: PassBuffers, lr: float, eps: float):
+        per = pb.d.P * pb.d.patch_k
+        check(lib.rmcl_pgd_step(P(pb.gpatch), self.dtype, P(pb.delta), P(pb.amax), pb.B, I64(per), F(lr), F(eps),
+                                stream_ptr()), "pgd_step")
+
+    def enqueue(self, keys_all: torch.Tensor, ptr: int):
+        check(lib.rmcl_enqueue_f32(P(self.queue), P(keys_all), keys_all.shape[0], 128, I64(self.num_negative), I64(ptr),
+                                   stream_ptr()), "enqueue")

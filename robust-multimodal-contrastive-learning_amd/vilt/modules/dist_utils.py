@@ -1,0 +1,73 @@
+"""Multi-GPU host logic of the RMCL step: one process per GPU, ``torch.distributed`` (backend
+"nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).  Device-agnostic on purpose so the
+world_size-2 gloo tests exercise exactly this code.
+
+Replaces: ``_concat_all_gather`` / ``_dequeue_and_enqueue`` (vilt/modules/objectives.py:226-248)
+and the implicit DDP gradient all-reduce of run.py:96.  The reference's detectron2-style pickle
+gathers (vilt/modules/dist_utils.py) serve IR/TR recall only and are out of scope."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class KeyGather:
+    """Asynchronous all-gather of the momentum keys [B,128] fp32 (32 KiB per rank), rank-major
+    like ``torch.cat(tensors_gather, 0)`` (objectives.py:231-234).  Launched right after the key
+    head; RCCL runs it on its own stream while the clean forward, the PGD loop and the attacked
+    forward proceed; ``wait()`` is called just before the enqueue (objectives.py:394-395)."""
+
+    def __init__(self, k: torch.Tensor):
+        self.k = k
+        self.out: Optional[torch.Tensor] = None
+        self.work = None
+        ws = world_size()
+        if ws == 1:
+            self.out = k
+            return
+        self.out = torch.empty(ws * k.shape[0], k.shape[1], dtype=k.dtype, device=k.device)
+        self.work = dist.all_gather_into_tensor(self.out, k.contiguous(), async_op=True)
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.out
+
+
+def queue_advance(ptr: int, n_keys: int, num_negative: int, per_step_bs: int) -> Tuple[bool, int]:
+    """Bookkeeping of ``_dequeue_and_enqueue`` (objectives.py:241-248): skip when the gathered batch
+    differs from per_step_bs; no wrap-around handling (needs num_negative % n_keys == 0)."""
+    if n_keys != per_step_bs:
+        return False, ptr
+    if ptr + n_keys > num_negative:
+        raise RuntimeError(f"queue block [{ptr}, {ptr + n_keys}) runs past num_negative={num_negative} "
+                           "(the reference requires num_negative % batch == 0)")
+    return True, (ptr + n_keys) % num_negative
+
+
+def allreduce_mean_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, async_op: bool = False):
+    """Gradient averaging over a flat fp32 arena in a few large buckets (xGMI is point-to-point:
+    few, large collectives).  Returns the list of work handles when async_op."""
+    ws = world_size()
+    if ws == 1:
+        return []
+    works = []
+    n = flat.numel()
+    for s in range(0, n, bucket_elems):
+        chunk = flat[s:min(n, s + bucket_elems)]
+        chunk.div_(ws)
+        w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works

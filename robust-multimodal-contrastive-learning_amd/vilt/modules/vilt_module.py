@@ -1,0 +1,207 @@
+"""``ViLTransformerSS``: the reference's LightningModule API (vilt/modules/vilt_module.py:20-507) over
+the MI355X engine.  Same constructor keys, state-dict names, ``infer`` / ``infer_k`` / ``forward`` /
+``training_step`` / ``configure_optimizers``; pytorch_lightning is not required (plain nn.Module with a
+minimal ``log`` / ``hparams`` shim), the caller may be any loop that does
+``loss = m.training_step(batch, i); loss.backward(); opt.step()``."""
+from __future__ import annotations
+
+import types
+
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ...runtime import Engine, EMA_GROUPS
+from ...attack.pgd_attack_vilt import PGDAttack_moco
+from . import objectives, vilt_utils, dist_utils
+
+
+class _Node(nn.Module):
+    """anonymous container so parameters get the reference's dotted state-dict names"""
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+class ViLTransformerSS(nn.Module):
+    def __init__(self, config, device="cuda:0", compute_dtype="bf16", exact=False):
+        super().__init__()
+        self.hparams = types.SimpleNamespace(config=config)
+        self.config = config
+        if config.get("drop_rate", 0.0) != 0.0:
+            raise NotImplementedError("dropout is not built yet: set drop_rate=0 (SURVEY quirk 6)")
+        self.engine = Engine(config, device, compute_dtype, exact)
+        eng = self.engine
+        self.current_tasks = []
+        self.logged = {}
+        # query parameters = views into the flat fp32 arena; .grad = views into the gradient arena
+        for name, off, shape in eng.specs:
+            if name.startswith("itm_score") and config["loss_names"].get("itm", 0) <= 0:
+                continue
+            if name.startswith("moco_head") and config["loss_names"].get("moco", 0) <= 0:
+                continue
+            p = nn.Parameter(eng.view(eng.q32, off, shape))
+            p.grad = eng.view(eng.g32, off, shape)
+            _attach(self, name, p)
+        self.init_weights()
+        if config["loss_names"].get("moco", 0) > 0:
+            self.multimodal = config.get("Multimodal", True)
+            self.per_step_bs = config["num_gpus"] * config["num_nodes"] * config["per_gpu_batchsize"]
+            for name, off, shape in eng.specs:
+                if name.split(".")[0] in EMA_GROUPS:
+                    p = nn.Parameter(eng.view(eng.k32, off, shape), requires_grad=False)
+                    _attach(self, "k_" + name, p)
+            self.shadow_momentum_encoder()
+            self.momentum = config["momentum"]
+            self.temperature = config["temperature"]
+            self.text_view = config["text_view"]
+            self.augmentation = config["augmentation"]
+            self.image_view = config["image_view"]
+            self.num_negative = config["num_negative"]
+            self.register_buffer("proj_queue", torch.randn(128, self.num_negative, device=eng.device))
+            self.register_buffer("proj_queue_ptr", torch.zeros(1, dtype=torch.long, device=eng.device))
+            eng.queue = self.proj_queue
+            self._queue_ptr_host = 0
+            if self.image_view and not self.augmentation:
+                self.pgd_attacker = PGDAttack_moco(config)
+        self.grad_anchor = torch.zeros((), device=eng.device, requires_grad=True)
+        self.sync_grads = True
+        self._register_load_state_dict_post_hook(lambda module, incompatible: module._after_load())
+
+    # ---- initialisation (objectives.init_weights :1505-1516, ViT _init_weights :512-519) ----
+    @torch.no_grad()
+    def init_weights(self):
+        for name, p in self.named_parameters():
+            if name.startswith("k_"):
+                continue
+            leaf = name.split(".")[-1]
+            is_ln = any(t in name for t in ("LayerNorm", "norm1", "norm2", "transformer.norm", "projector.1"))
+            if is_ln:
+                p.fill_(1.0 if leaf == "weight" else 0.0)
+            elif leaf == "bias":
+                p.zero_()
+            elif name.startswith("transformer."):
+                nn.init.trunc_normal_(p, std=0.02)
+            else:
+                p.normal_(mean=0.0, std=0.02)
+        self.engine.lp_stale = True
+
+    @torch.no_grad()
+    def shadow_momentum_encoder(self):
+        """_shadow_layer (vilt_module.py:270-273): copy q -> k."""
+        e = self.engine
+        e.k32.copy_(e.q32[: e.layout.ema_end])
+        e.lp_stale = True
+
+    def _after_load(self):
+        self.engine.lp_stale = True
+        if hasattr(self, "proj_queue_ptr"):
+            self._queue_ptr_host = None
+
+    # ---- Lightning shims -------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.engine.device
+
+    def log(self, name, value):
+        self.logged[name] = value
+
+    @property
+    def queue_ptr(self) -> int:
+        if self._queue_ptr_host is None:
+            self._queue_ptr_host = int(self.proj_queue_ptr)
+        return self._queue_ptr_host
+
+    @queue_ptr.setter
+    def queue_ptr(self, v: int):
+        self._queue_ptr_host = int(v)
+        self.proj_queue_ptr.fill_(int(v))
+
+    def after_backward(self):
+        """DDP replacement: average the flat gradient arena over ranks (run.py:96)."""
+        if self.sync_grads and dist_utils.world_size() > 1:
+            dist_utils.allreduce_mean_(self.engine.g32)
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.engine.zero_grads()
+
+    # ---- inference API ---------------------------------------------------------------------
+    def _infer(self, batch, key, mask_text, mask_image, image_token_type_idx, image_embeds, image_masks):
+        if mask_text or mask_image:
+            raise NotImplementedError("MLM/MPP masking is outside the RMCL hot path")
+        if image_embeds is not None or image_masks is not None:
+            raise NotImplementedError("image_embeds shortcut is not on the RMCL hot path")
+        if image_token_type_idx != 1:
+            raise NotImplementedError("image_token_type_idx != 1 (NLVR2) is outside the RMCL hot path")
+        eng = self.engine
+        text_ids, text_masks = batch["text_ids"], batch["text_masks"]
+        pb = eng.bind_batch(text_ids, text_masks, batch["image"][0])
+        op = eng.make_operand(pb)
+        eng.encoder_forward(pb, key=key, mode=L.MODE_INFER, patchesT=op)
+        eng.heads_forward(pb, key=key, want_q=False)
+        d = pb.d
+        N = d.L + 1 + d.P
+        x = pb.xn.view(pb.B, N, d.D)
+        g = self.config["image_size"] // self.config["patch_size"]
+        ii, jj = torch.meshgrid(torch.arange(g), torch.arange(g), indexing="ij")
+        patch_index = torch.stack([ii, jj], dim=-1).reshape(1, g * g, 2).expand(pb.B, -1, -1)
+        ret = {
+            "text_feats": x[:, : d.L].clone(),
+            "image_feats": x[:, d.L:].clone(),
+            "cls_feats": pb.cls.clone(),
+            "raw_cls_feats": x[:, 0].clone(),
+            "image_masks": pb.co_mask[:, d.L:].to(torch.int64),
+            "text_ids": text_ids,
+            "text_masks": text_masks,
+            "patch_index": (patch_index, (g, g)),
+        }
+        if not key:
+            ret["image_labels"] = None
+            ret["text_labels"] = batch.get("text_labels")
+        return ret
+
+    @torch.no_grad()
+    def infer(self, batch, mask_text=False, mask_image=False, image_token_type_idx=1, image_embeds=None, image_masks=None):
+        return self._infer(batch, False, mask_text, mask_image, image_token_type_idx, image_embeds, image_masks)
+
+    @torch.no_grad()
+    def infer_k(self, batch, mask_text=False, mask_image=False, image_token_type_idx=1, image_embeds=None, image_masks=None):
+        return self._infer(batch, True, mask_text, mask_image, image_token_type_idx, image_embeds, image_masks)
+
+    def forward(self, batch):
+        ret = dict()
+        if len(self.current_tasks) == 0:
+            ret.update(self.infer(batch))
+            return ret
+        if "itm" in self.current_tasks:
+            ret.update(objectives.compute_itm_wpa(self, batch))
+        if "moco" in self.current_tasks:
+            ret.update(objectives.compute_moco_contrastive(self, batch))
+        unsupported = [t for t in self.current_tasks if t not in ("itm", "moco")]
+        if unsupported:
+            raise NotImplementedError(f"tasks {unsupported} are outside the RMCL hot path (SURVEY 8)")
+        return ret
+
+    def training_step(self, batch, batch_idx):
+        vilt_utils.set_task(self)
+        output = self(batch)
+        total_loss = sum([v for k, v in output.items() if "loss" in k])
+        return total_loss
+
+    def validation_step(self, batch, batch_idx):
+        vilt_utils.set_task(self)
+        with torch.no_grad():
+            return self(batch)
+
+    def test_step(self, batch, batch_idx):
+        return self.validation_step(batch, batch_idx)
+
+    def configure_optimizers(self):
+        return vilt_utils.set_schedule(self)

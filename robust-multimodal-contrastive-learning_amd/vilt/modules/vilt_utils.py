@@ -1,0 +1,109 @@
+"""Training utilities on the hot path's edge: ``set_task`` (vilt/modules/vilt_utils.py:325-329) and
+``set_schedule`` (:331-437) = HF AdamW (beta (0.9,0.98), eps 1e-8, 4 parameter groups) + polynomial
+decay with warm-up, restated as ONE fused multi-tensor kernel over the flat parameter arena."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from ... import _lib as L
+from ..._lib import lib, check, P, I64, F
+from ...runtime import stream_ptr
+
+NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight", "norm1.bias", "norm1.weight",
+            "norm2.bias", "norm2.weight"]
+HEAD_NAMES = ["vqa_classifier", "nlvr2_classifier", "moco_head", "barlowtwinshead"]
+
+
+def set_task(pl_module):
+    pl_module.current_tasks = [k for k, v in pl_module.hparams.config["loss_names"].items() if v >= 1]
+    return
+
+
+class FusedAdamW:
+    """optimizer-like object (``step`` / ``zero_grad`` / ``param_groups``) over the engine's arenas."""
+
+    def __init__(self, pl_module, lr, wd, lr_mult, betas=(0.9, 0.98), eps=1e-8):
+        eng = pl_module.engine
+        self.eng = eng
+        self.betas, self.eps = betas, eps
+        self.m = torch.zeros_like(eng.q32)
+        self.v = torch.zeros_like(eng.q32)
+        self.t = 0
+        ends, mults, wds = [], [], []
+        specs = sorted(eng.specs, key=lambda s: s[1])
+        for i, (name, off, shape) in enumerate(specs):
+            end = specs[i + 1][1] if i + 1 < len(specs) else eng.layout.total
+            decay = not any(nd in name for nd in NO_DECAY)
+            head = any(bb in name for bb in HEAD_NAMES)
+            ends.append(end)
+            mults.append(lr_mult if head else 1.0)
+            wds.append(wd if decay else 0.0)
+        dev = eng.device
+        self.seg_end = torch.tensor(ends, dtype=torch.int64, device=dev)
+        self.seg_mult = torch.tensor(mults, dtype=torch.float32, device=dev)
+        self.seg_wd = torch.tensor(wds, dtype=torch.float32, device=dev)
+        self.param_groups = [{"lr": lr, "initial_lr": lr}]
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.eng.zero_grads()
+
+    def step(self):
+        self.t += 1
+        e = self.eng
+        check(lib.rmcl_adamw_f32(P(e.q32), P(e.g32), P(self.m), P(self.v), P(e.q_lp), P(self.seg_end), P(self.seg_mult),
+                                 P(self.seg_wd), int(self.seg_end.numel()), F(self.param_groups[0]["lr"]), F(self.betas[0]),
+                                 F(self.betas[1]), F(self.eps), self.t, F(self.grad_scale), I64(e.q32.numel()), stream_ptr()),
+              "adamw")
+
+
+class PolySchedule:
+    """get_polynomial_decay_schedule_with_warmup as called at vilt_utils.py:423-430; step() per iteration."""
+
+    def __init__(self, opt, warmup, total, end_lr, power):
+        self.opt, self.warmup, self.total, self.end_lr, self.power = opt, warmup, total, end_lr, power
+        self.base = opt.param_groups[0]["initial_lr"]
+        self.n = 0
+        self._apply()
+
+    def lr_at(self, step):
+        if step < self.warmup:
+            return self.base * step / max(1, self.warmup)
+        if step > self.total:
+            return self.end_lr
+        rem = 1 - (step - self.warmup) / (self.total - self.warmup)
+        return (self.base - self.end_lr) * rem ** self.power + self.end_lr
+
+    def _apply(self):
+        self.opt.param_groups[0]["lr"] = self.lr_at(self.n)
+
+    def step(self):
+        self.n += 1
+        self._apply()
+
+
+class CosineSchedule(PolySchedule):
+    def lr_at(self, step):
+        if step < self.warmup:
+            return self.base * step / max(1, self.warmup)
+        prog = (step - self.warmup) / max(1, self.total - self.warmup)
+        return self.base * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+
+
+def set_schedule(pl_module):
+    cfg = pl_module.hparams.config
+    if cfg["optim_type"] != "adamw":
+        raise NotImplementedError("only optim_type='adamw' (the reference default) is built")
+    opt = FusedAdamW(pl_module, cfg["learning_rate"], cfg["weight_decay"], cfg["lr_mult"])
+    max_steps = cfg["max_steps"]
+    warmup = cfg["warmup_steps"]
+    if isinstance(warmup, float):
+        warmup = int(max_steps * warmup)
+    if cfg["decay_power"] == "cosine":
+        sched = CosineSchedule(opt, warmup, max_steps, cfg["end_lr"], 1)
+    else:
+        sched = PolySchedule(opt, warmup, max_steps, cfg["end_lr"], cfg["decay_power"])
+    return [opt], [{"scheduler": sched, "interval": "step"}]

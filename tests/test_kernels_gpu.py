@@ -1,0 +1,220 @@
+"""-m gpu: kernel-level parity of the HIP kernels (through the C ABI) against plain PyTorch fp32/fp64
+references of the same op.  Tolerances: exact-f32 kernels 1e-5 relative (fp32 summation order only);
+bf16-storage variants 2^-8 relative to the row scale."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.gpu_util import DEV, L, lib, check, P, I64, F, stream, gemm, tdt  # noqa: E402
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("shape", [(370, 768, 768), (128, 128, 16), (200, 2304, 768), (37, 40, 24), (1, 8, 8), (513, 136, 264)])
+def test_gemm_nt_nn_tn(dt, shape):
+    M, N, K = shape
+    X = rnd(M, K, seed=1).to(tdt(dt))
+    W = rnd(N, K, seed=2, scale=0.05).to(tdt(dt))
+    ref = X.double() @ W.double().t()
+    tol = 2e-5 if dt == L.F32 else 1e-2
+    out = gemm(X, W, M, N, K, 1, 1, dt, L.F32)                                   # NT: Y = X W^T
+    assert rel_err(out, ref) < tol
+    Wn = W.t().contiguous()                                                      # [K, N]
+    out = gemm(X, Wn, M, N, K, 1, 0, dt, L.F32)                                  # NN: Y = X Wn
+    assert rel_err(out, ref) < tol
+    Xt = X.t().contiguous()                                                      # [K, M]
+    if M % 8 == 0 or dt == L.F32 and M % 4 == 0:
+        out = gemm(Xt, Wn, M, N, K, 0, 0, dt, L.F32)                             # TN: Y = Xt^T Wn
+        assert rel_err(out, ref) < tol
+
+
+def test_gemm_tn_splitk_atomic_accumulates():
+    T, N, K = 1110, 768, 256                                                     # dW[N,K] += dY[T,N]^T X[T,K]
+    dY, X = rnd(T, N, seed=3), rnd(T, K, seed=4)
+    base = rnd(N, K, seed=5)
+    ref = base.double() + dY.double().t() @ X.double()
+    out = gemm(dY, X, N, K, T, 0, 0, L.F32, L.F32, epi=32, splitk=5, C_init=base)
+    assert rel_err(out, ref) < 2e-5
+
+
+def test_gemm_epilogues():
+    M, N, K = 300, 256, 128
+    X, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    R = rnd(M, N, seed=4)
+    pre = X.double() @ W.double().t() + b.double()
+    out, u = gemm(X, W, M, N, K, 1, 1, L.F32, L.F32, bias=b, epi=1 | 2 | 4, want_c2=True)      # bias + GELU, save pre-act
+    assert rel_err(u, pre) < 2e-5
+    assert rel_err(out, torch.nn.functional.gelu(pre)) < 2e-5
+    out = gemm(X, W, M, N, K, 1, 1, L.F32, L.F32, bias=b, aux=R, ld_aux=N, epi=1 | 8)          # bias + residual
+    assert rel_err(out, pre + R.double()) < 2e-5
+    out = gemm(X, W, M, N, K, 1, 1, L.F32, L.F32, bias=b, epi=1 | 128)                         # bias + tanh
+    assert rel_err(out, torch.tanh(pre)) < 2e-5
+    U = rnd(M, N, seed=6)
+    ud = U.double().requires_grad_(True)
+    torch.nn.functional.gelu(ud).sum().backward()
+    out = gemm(X, W, M, N, K, 1, 1, L.F32, L.F32, aux=U, ld_aux=N, epi=16)                     # * gelu'(u)
+    assert rel_err(out, (X.double() @ W.double().t()) * ud.grad) < 2e-5
+
+
+def test_gemm_rejects_bad_leading_dim():
+    X, W = rnd(8, 6), rnd(8, 6)
+    with pytest.raises(L.RmclError):
+        gemm(X, W, 8, 8, 6, 1, 1, L.F32, L.F32)                                                # lda=6 not a multiple of 4
+
+
+# ------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("relu", [0, 1])
+def test_layernorm_fwd_bwd(relu):
+    M, D = 371, 768
+    x, w, b, dy = rnd(M, D, seed=1), 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3), rnd(M, D, seed=4)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(xd, (D,), wd, bd, 1e-6)
+    if relu:
+        y_ref = torch.relu(y_ref)
+    y_ref.backward(dy.double())
+    y = torch.empty(M, D, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    check(lib.rmcl_layernorm_fwd(P(x), P(w), P(b), F(1e-6), P(y), L.F32, P(mean), P(rstd), M, D, relu, stream()))
+    assert rel_err(y, y_ref) < 1e-5
+    dx0 = rnd(M, D, seed=9)
+    dx = dx0.clone()
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    check(lib.rmcl_layernorm_bwd(P(dy), L.F32, P(x), P(mean), P(rstd), P(w), P(b), P(dx), 1, P(dg), P(db), M, D, relu, stream()))
+    assert rel_err(dx - dx0, xd.grad) < 2e-5
+    assert rel_err(dg, wd.grad) < 2e-5 and rel_err(db, bd.grad) < 2e-5
+
+
+# ------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("BN", [(3, 185), (2, 64), (1, 241)])
+def test_attention_fwd_bwd(dt, BN):
+    B, N = BN
+    H, D = 12, 768
+    qkv = rnd(B * N, 3 * D, seed=1).to(tdt(dt))
+    mask = torch.ones(B, N, dtype=torch.int32)
+    mask[0, N - 17:N - 3] = 0                                  # ragged: masked keys in the middle/end
+    if B > 1:
+        mask[1, 5:9] = 0
+    mask = mask.to(DEV)
+    dout = rnd(B * N, D, seed=2).to(tdt(dt))
+    # reference (vision_transformer.py:309-332) in fp64
+    x = qkv.double().requires_grad_(True)
+    t = x.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (t[0] @ t[1].transpose(-2, -1)) * 0.125
+    s = s.masked_fill(~mask.bool()[:, None, None, :], float("-inf"))
+    o_ref = (s.softmax(-1) @ t[2]).transpose(1, 2).reshape(B * N, D)
+    o_ref.backward(dout.double())
+    ne = lib.rmcl_attention_scratch_elems(B, H, N)
+    out = torch.empty(B * N, D, dtype=tdt(dt), device=DEV)
+    probs = torch.empty(ne, dtype=tdt(dt), device=DEV)
+    scores = torch.empty(ne, dtype=torch.float32, device=DEV)
+    dS = torch.empty(ne, dtype=tdt(dt), device=DEV)
+    dqkv = torch.empty(B * N, 3 * D, dtype=tdt(dt), device=DEV)
+    check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(out), P(probs), P(scores), B, N, H, dt, 1, stream()))
+    check(lib.rmcl_attention_bwd(P(qkv), P(probs), P(dout), P(dqkv), P(scores), P(dS), B, N, H, dt, 1, stream()))
+    tol = 3e-5 if dt == L.F32 else 2e-2
+    assert rel_err(out, o_ref) < tol
+    assert rel_err(dqkv, x.grad) < tol
+
+
+# --------------------------------------------------------------------------------------- InfoNCE
+@pytest.mark.parametrize("B,Kq", [(4, 1024), (64, 65536), (70, 4096)])
+def test_infonce_matches_oracle(B, Kq):
+    from oracle import rmcl_oracle as O
+    T = 0.07
+    q = torch.nn.functional.normalize(rnd(B, 128, seed=1), dim=1)
+    k = torch.nn.functional.normalize(rnd(B, 128, seed=2) + 2 * q, dim=1)
+    queue = rnd(128, Kq, seed=3)
+    queue[:, 5] = 30 * q[0]                                        # spike: forces a late max jump / argmax != 0
+    qd = q.double().cpu().requires_grad_(True)
+    logits = O.infonce_logits(qd, k.double().cpu(), queue.double().cpu(), T)
+    loss_ref = O.infonce_loss(logits)
+    (loss_ref / 3.0).backward()
+    ws = torch.empty(lib.rmcl_infonce_ws_bytes(B, I64(Kq)), dtype=torch.uint8, device=DEV)
+    dq, rows, lsum = torch.empty(B, 128, device=DEV), torch.empty(B, 10, device=DEV), torch.zeros(1, device=DEV)
+    check(lib.rmcl_infonce_f32(P(q), P(k), P(queue), B, 128, I64(Kq), F(T), F(1.0 / (3.0 * B)), P(dq), P(rows), P(lsum), P(ws),
+                               stream()))
+    assert abs(float(lsum) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+    assert rel_err(dq.cpu(), qd.grad) < 1e-4
+    assert torch.equal(rows[:, 1].cpu().long(), logits.argmax(-1))
+    m = O.queue_metrics(q.double().cpu(), k.double().cpu(), queue.double().cpu())
+    for j, name in ((3, "pos_dist"), (4, "pos_cosine"), (5, "pos_dot"), (6, "neg_dist"), (7, "neg_cosine"), (8, "neg_dot")):
+        assert abs(float(rows[:, j].mean()) - float(m[name])) < 2e-5 * max(1.0, abs(float(m[name]))), name
+
+
+# ------------------------------------------------------------------------- PGD / EMA / queue / opt
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+def test_pgd_step(dt):
+    B, per = 3, 144 * 3072
+    g = rnd(B, per, seed=1).to(tdt(dt))
+    g[2] = 0                                                       # all-zero gradient: 1e-8 floor, delta unchanged
+    delta0 = (rnd(B, per, seed=2) * 0.002).clamp(-0.005, 0.005)
+    delta = delta0.clone()
+    amax = torch.empty(B, dtype=torch.int32, device=DEV)
+    check(lib.rmcl_pgd_step(P(g), dt, P(delta), P(amax), B, I64(per), F(0.05), F(0.005), stream()))
+    gf = g.float()
+    den = gf.abs().amax(dim=1, keepdim=True).clamp_min(1e-8)
+    ref = (delta0 + 0.05 * gf / den).clamp(-0.005, 0.005)
+    assert float((delta - ref).abs().max()) < 1e-8
+    assert float(delta.abs().max()) <= 0.005
+
+
+def test_ema_and_cast():
+    n = 1 << 20
+    k, q = rnd(n, seed=1), rnd(n, seed=2)
+    lp = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ref = k * 0.999 + q * (1 - 0.999)
+    check(lib.rmcl_ema_f32(P(k), P(q), P(lp), F(0.999), I64(n), stream()))
+    assert float((k - ref).abs().max()) < 1e-6
+    assert torch.equal(lp, k.to(torch.bfloat16))
+
+
+def test_enqueue_and_bounds():
+    Kq, n = 1024, 8
+    queue, keys = rnd(128, Kq, seed=1), rnd(n, 128, seed=2)
+    ref = queue.clone()
+    ref[:, 16:16 + n] = keys.t()
+    check(lib.rmcl_enqueue_f32(P(queue), P(keys), n, 128, I64(Kq), I64(16), stream()))
+    assert torch.equal(queue, ref)
+    with pytest.raises(L.RmclError):
+        check(lib.rmcl_enqueue_f32(P(queue), P(keys), n, 128, I64(Kq), I64(Kq - 4), stream()))
+
+
+def test_adamw_matches_oracle():
+    from oracle import rmcl_oracle as O
+    n = 4096
+    p, g = rnd(n, seed=1), rnd(n, seed=2)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pr, mr, vr = p.cpu().clone(), torch.zeros(n), torch.zeros(n)
+    seg_end = torch.tensor([1024, 4096], dtype=torch.int64, device=DEV)
+    mult = torch.tensor([1.0, 5.0], device=DEV)
+    wd = torch.tensor([0.01, 0.0], device=DEV)
+    for step in (1, 2, 3):
+        check(lib.rmcl_adamw_f32(P(p), P(g), P(m), P(v), None, P(seg_end), P(mult), P(wd), 2, F(1e-3), F(0.9), F(0.98), F(1e-8),
+                                 step, F(1.0), I64(n), stream()))
+        O.adamw_step(pr[:1024], g.cpu()[:1024], mr[:1024], vr[:1024], step, 1e-3, 0.01)
+        O.adamw_step(pr[1024:], g.cpu()[1024:], mr[1024:], vr[1024:], step, 5e-3, 0.0)
+    assert float((p.cpu() - pr).abs().max()) < 1e-6
+
+
+def test_im2patch_roundtrip():
+    from oracle import rmcl_oracle as O
+    img = rnd(2, 3, 384, 384, seed=1)
+    pat = torch.empty(2 * 144, 3072, device=DEV)
+    check(lib.rmcl_im2patch_f32(P(img), P(pat), 2, 3, 384, 384, 32, 0, stream()))
+    assert torch.equal(pat.cpu(), O.patchify(img.cpu(), 32).reshape(288, 3072))
+    back = torch.empty_like(img)
+    check(lib.rmcl_im2patch_f32(P(back), P(pat), 2, 3, 384, 384, 32, 1, stream()))
+    assert torch.equal(back, img)
