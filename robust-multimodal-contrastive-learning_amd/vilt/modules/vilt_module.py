@@ -73,7 +73,7 @@ class ViLTransformerSS(nn.Module):
                 self.pgd_attacker = PGDAttack_moco(config)
         self.grad_anchor = torch.zeros((), device=eng.device, requires_grad=True)
         self.sync_grads = True
-        self._register_load_state_dict_post_hook(lambda module, incompatible: module._after_load())
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._after_load())
 
     # ---- initialisation (objectives.init_weights :1505-1516, ViT _init_weights :512-519) ----
     @torch.no_grad()
