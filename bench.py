@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py - RMCL training step throughput on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete RMCL training step on a synthetic batch (BASELINE.json configs[2]/[3]):
+momentum update, key encoder, clean query, PGD K=3 image attack (3 x forward + data-gradient backward +
+L-inf-normalised step), attacked-view forward + full backward, InfoNCE against the 65 536-entry queue,
+key all-gather + enqueue, gradient all-reduce (N>1) and the fused AdamW step.  bs=64/GPU, 384x384 + 40
+tokens, bf16 operands / fp32 accumulate, inputs resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/unit/..., plus
+  roofline     - the dominant kernel class (the encoder MLP fc1/fc2 forward GEMMs) timed live with HIP
+                 events on the launch stream during the timed steps: algorithmic FLOPs / measured time
+                 vs the dense bf16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PFLOP/s);
+  step_mfma_frac - whole-step algorithmic FLOPs ((5+2K)F per pair) / step time / peak;
+  cpu_baseline - the CPU oracle (port of the reference algorithm, oracle/rmcl_oracle.py) timed on this
+                 host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16 = 2.5e15          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+F_PER_PAIR = 33.386e9       # one encoder forward, SURVEY.md 8(d)
+
+
+def synthetic_batch(cfg, B, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    S, Lt = cfg["image_size"], cfg["max_text_len"]
+    img = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    ids = torch.randint(1000, cfg["vocab_size"], (B, Lt), generator=g)
+    ids[:, 0], ids[:, -1] = 101, 102
+    return {"image": [img.to(device)], "text": ["synthetic"] * B, "text_ids": ids.to(device),
+            "text_masks": torch.ones(B, Lt, dtype=torch.int64, device=device),
+            "text_labels": torch.full((B, Lt), -100, dtype=torch.int64, device=device)}
+
+
+def cpu_baseline(K_adv):
+    """Oracle (kind "port") on the host cores: one RMCL step (image view, PGD K) + backward."""
+    from oracle import rmcl_oracle as O
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:                                           # cgroup v2 CPU quota (the GPU box gives a share of the host)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = min(threads, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    threads = min(threads, 32)
+    torch.set_num_threads(threads)
+    Bc = 2
+    ocfg = O.default_config(per_gpu_batchsize=Bc, adv_steps_img=K_adv)
+    p = O.init_params(ocfg, 1)
+    for n, t in p.items():
+        if not n.startswith("k_"):
+            t.requires_grad_(True)
+    queue = O.init_queue(ocfg, 0)
+    batch = O.synthetic_batch(ocfg, Bc, 2)
+    t0 = time.time()
+    ret = O.compute_moco_contrastive(p, ocfg, batch, queue, 0, training=True)
+    ret["moco_loss"].backward()
+    dt = time.time() - t0
+    return {"value": Bc / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"1 step of the same workload at bs={Bc} (12 layers, queue 65536, PGD K={K_adv}), fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--adv-steps", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    import rmcl_pkg  # noqa: F401
+    from rmcl_amd import _lib as L
+    from rmcl_amd.vilt.config import task_moco
+    from rmcl_amd.vilt.modules import ViLTransformerSS
+
+    B, K = args.batch, args.adv_steps
+    cfg = task_moco(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=0.0, image_view=True,
+                    text_view=False, max_steps=100000)
+    torch.manual_seed(0)
+    model = ViLTransformerSS(cfg, device=device, compute_dtype=args.dtype)
+    model.train()
+    (opt,), (sched,) = model.configure_optimizers()
+    batch = synthetic_batch(cfg, B, 1234 + rank, device)
+
+    def step(i):
+        loss = model.training_step(batch, i)
+        loss.backward()
+        opt.step()
+        sched["scheduler"].step()
+        opt.zero_grad()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # roofline leg: time the MLP forward GEMM class in-stream during the timed steps
+    L.check(L.lib.rmcl_prof_begin(1 | 2, 4096), "prof_begin")
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
+    L.check(L.lib.rmcl_prof_end(C.byref(ms), C.byref(n), C.byref(fl)), "prof_end")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / elapsed
+        step_flops = (5 + 2 * K) * F_PER_PAIR * B               # algorithmic, per GPU per step
+        kern_tf = (fl.value / max(n.value, 1)) / (ms.value / max(n.value, 1) * 1e-3) / 1e12 if n.value else 0.0
+        out = {
+            "metric": "image-text pairs/sec, ViLT-B/32 RMCL step (PGD K=3)", "value": round(value, 2), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"RMCL step, PGD K={K} image attack + MoCo InfoNCE (queue 65536) + full backward + AdamW, "
+                                   f"ViLT-B/32, bs={B}/GPU, 384x384 img + 40 tok (BASELINE configs[2]; [3] when n_gpus=8)",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+            "roofline": {"bound": "mfma", "achieved": round(kern_tf, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                         "frac": round(kern_tf * 1e12 / PEAK_BF16, 4), "traffic": None,
+                         "kernel": "encoder MLP forward GEMMs (fc1 768->3072 +bias+GELU, fc2 3072->768 +bias+residual), "
+                                   f"M={B * 185}; {n.value} launches, avg {ms.value / max(n.value, 1):.4f} ms"},
+            "step_mfma_frac": round(step_flops / (elapsed / args.steps) / PEAK_BF16, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(K)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

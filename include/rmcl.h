@@ -63,6 +63,12 @@ typedef struct rmcl_layout {
 const char* rmcl_last_error(void);
 int rmcl_version(void);
 
+/* In-stream timing of one class of GEMM launches (tag mask: csrc/gemm.h GEMM_TAG_*) with hipEvents
+ * recorded around each launch on the launch stream; used by bench.py for the roofline object.
+ * rmcl_prof_end synchronises the recorded events and returns total ms, launches and algorithmic FLOPs. */
+int rmcl_prof_begin(int tag_mask, int max_launches);
+int rmcl_prof_end(double* ms_total, int64_t* launches, double* flops_total);
+
 void rmcl_param_layout(const rmcl_dims* d, rmcl_layout* out);
 int64_t rmcl_stash_bytes(const rmcl_dims* d, int mode);
 int64_t rmcl_workspace_bytes(const rmcl_dims* d);

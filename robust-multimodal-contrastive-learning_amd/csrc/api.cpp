@@ -13,9 +13,30 @@ int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* p
 int rmcl_attention_bwd_impl(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dS, int B,
                             int N, int H, int dt, int exact, hipStream_t s);
 
+// ---- optional in-stream timing of one GEMM class (bench.py roofline leg) ------------------------
+#include <vector>
+namespace {
+struct Prof {
+  bool on = false;
+  int mask = 0;
+  size_t n = 0, cap = 0;
+  std::vector<hipEvent_t> ev;   // 2 per launch
+  double flops = 0.0;
+} g_prof;
+}
+
 int rmcl_launch_gemm(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc, int exact, hipStream_t stream) {
-  if (!exact && rmcl_gemm_fast_supported(g, dt_in, dt_out, a_kc, b_kc)) return rmcl_launch_gemm_fast(g, dt_out, a_kc, b_kc, stream);
-  return rmcl_launch_gemm_exact(g, dt_in, dt_out, a_kc, b_kc, stream);
+  const bool timed = g_prof.on && (g.tag & g_prof.mask) && g_prof.n < g_prof.cap;
+  if (timed) (void)hipEventRecord(g_prof.ev[2 * g_prof.n], stream);
+  int rc;
+  if (!exact && rmcl_gemm_fast_supported(g, dt_in, dt_out, a_kc, b_kc)) rc = rmcl_launch_gemm_fast(g, dt_out, a_kc, b_kc, stream);
+  else rc = rmcl_launch_gemm_exact(g, dt_in, dt_out, a_kc, b_kc, stream);
+  if (timed) {
+    (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], stream);
+    g_prof.flops += 2.0 * g.M * g.N * g.K * (g.splitk > 1 ? 1 : g.nb1 * g.nb2);
+    ++g_prof.n;
+  }
+  return rc;
 }
 
 namespace {
@@ -45,6 +66,33 @@ GemmArgs ga(const void* A, const void* B, void* C, int M, int N, int K, long lda
 extern "C" {
 
 const char* rmcl_last_error(void) { return g_err.c_str(); }
+
+int rmcl_prof_begin(int tag_mask, int max_launches) {
+  RMCL_REQUIRE(max_launches > 0 && max_launches <= (1 << 16), "prof_begin: bad max_launches");
+  while (g_prof.ev.size() < (size_t)2 * max_launches) {
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) { rmcl_set_error(hipGetErrorString(r)); return (int)r; }
+    g_prof.ev.push_back(e);
+  }
+  g_prof.on = true; g_prof.mask = tag_mask; g_prof.n = 0; g_prof.cap = max_launches; g_prof.flops = 0.0;
+  return 0;
+}
+int rmcl_prof_end(double* ms_total, int64_t* launches, double* flops_total) {
+  g_prof.on = false;
+  double ms = 0.0;
+  for (size_t i = 0; i < g_prof.n; ++i) {
+    hipError_t r = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+    float t = 0.f;
+    if (r == hipSuccess) r = hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+    if (r != hipSuccess) { rmcl_set_error(hipGetErrorString(r)); return (int)r; }
+    ms += t;
+  }
+  if (ms_total) *ms_total = ms;
+  if (launches) *launches = (int64_t)g_prof.n;
+  if (flops_total) *flops_total = g_prof.flops;
+  return 0;
+}
 int rmcl_version(void) { return 1; }
 
 int64_t rmcl_heads_stash_bytes(const rmcl_dims* d) { return (int64_t)carve_heads(*d, nullptr, nullptr) + 256; }

@@ -27,6 +27,8 @@ struct Bump {
 inline size_t esz(int dt) { return dt == RMCL_F32 ? 4 : 2; }
 inline int ldp_of(int N) { return (N + 7) / 8 * 8; }
 
+#define SLAB_FLOATS(d) ((size_t)4 * (size_t)std::max((d).mlp, (d).patch_k) * (size_t)(d).D)
+
 struct LayerStash {
   float *x_in, *x_mid, *mean1, *rstd1, *mean2, *rstd2;
   void *qkv, *probs, *u;           // DATA+
@@ -47,6 +49,7 @@ struct Work {
   // backward
   float *dx, *dln, *dxn_full, *de;
   void *dxT, *du, *dqkv, *dao, *dS, *dpe;
+  float* slab;        // split-K partial slabs of the weight-gradient GEMMs
 };
 
 // Stash carve.  INFER: nothing is stashed (everything aliases workspace).
@@ -113,6 +116,7 @@ size_t carve_work(const rmcl_dims& d, void* base, Work* w) {
   k.dao = b.take_bytes(M * D * e);
   k.dS = b.take_bytes(zn * e);
   k.dpe = b.take_bytes((size_t)d.B * d.P * D * e);
+  k.slab = b.take<float>(SLAB_FLOATS(d));
   if (w) *w = k;
   return b.off;
 }
@@ -163,9 +167,22 @@ int dw_splitk(int Mout, int Nout, int K) {
 }
 
 // dW[Nout, Kin] += dY[tokens, Nout]^T @ X[tokens, Kin]   (fp32 atomics into the gradient arena)
-int gemm_dw(const Ctx& c, const void* dY, long lddy, const void* X, long ldx, float* dW, int Nout, int Kin, int tokens, int dt_in) {
+int gemm_dw(const Ctx& c, const void* dY, long lddy, const void* X, long ldx, float* dW, int Nout, int Kin, int tokens, int dt_in,
+            float* slab, size_t slab_floats) {
   GemmArgs g = gemm_args(dY, X, dW, Nout, Kin, tokens, lddy, ldx, Kin);
-  g.epi = EPI_ATOMIC;
+  if (!c.d.exact && dt_in == RMCL_BF16 && slab) {
+    // bf16 MFMA path: split-K over tokens into fp32 slabs + ordered reduce (no float atomics)
+    GemmArgs probe = g;
+    if (rmcl_gemm_fast_supported(probe, dt_in, RMCL_F32, 0, 0)) {
+      const int tiles = (Nout / 128) * (Kin / 128);
+      int sk = std::max(1, std::min(8, (256 + tiles - 1) / tiles));
+      sk = std::min<int>(sk, std::max<size_t>(1, slab_floats / ((size_t)Nout * Kin)));
+      sk = std::min(sk, std::max(1, tokens / 64));
+      g.splitk = sk; g.tag = GEMM_TAG_DW;
+      return rmcl_launch_gemm_fast_slab(g, slab, dW, c.s);
+    }
+  }
+  g.epi = EPI_ATOMIC; g.tag = GEMM_TAG_DW;
   g.splitk = dw_splitk(Nout, Kin, tokens);
   if (g.splitk == 1) g.epi = EPI_ACCUM;
   return gemm(c, g, dt_in, RMCL_F32, 0, 0);
@@ -287,7 +304,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
                                full ? st.text_rstd : nullptr, B, L, N, D, s));
   {
     GemmArgs g = gemm_args(patches, c.W(y.patch_w), w.pe, B * P, D, d->patch_k, d->patch_k, d->patch_k, D);
-    g.epi = EPI_BIAS; g.bias = c.V(y.patch_b);
+    g.epi = EPI_BIAS; g.bias = c.V(y.patch_b); g.tag = GEMM_TAG_PATCH;
     RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
   }
   RMCL_TRY(rmcl_image_assemble_fwd(w.pe, c.V(y.cls), c.V(y.pos_img), c.V(y.vtype) + D, x0, B, P, L, N, D, s));
@@ -312,24 +329,24 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     RMCL_TRY(rmcl_ln_fwd(x, D, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), 1e-6f, ln1, D, dt, m1, r1, M, D, 0, s));
     {
       GemmArgs g = gemm_args(ln1, c.W(c.L(l, y.qkv_w)), qkv, M, 3 * D, D, D, D, 3 * D);
-      g.epi = EPI_BIAS; g.bias = c.V(c.L(l, y.qkv_b));
+      g.epi = EPI_BIAS; g.bias = c.V(c.L(l, y.qkv_b)); g.tag = GEMM_TAG_QKV;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
     }
     RMCL_TRY(rmcl_attention_fwd_impl(qkv, co_mask, ao, probs, w.scores, B, N, d->H, dt, d->exact, s));
     {
       GemmArgs g = gemm_args(ao, c.W(c.L(l, y.proj_w)), x_mid, M, D, D, D, D, D);
-      g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = D;
+      g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = D; g.tag = GEMM_TAG_PROJ;
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
     }
     RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2, D, dt, m2, r2, M, D, 0, s));
     {
       GemmArgs g = gemm_args(ln2, c.W(c.L(l, y.fc1_w)), h, M, d->mlp, D, D, D, d->mlp);
-      g.epi = EPI_BIAS | EPI_GELU | (u ? EPI_SAVE_PREACT : 0); g.bias = c.V(c.L(l, y.fc1_b)); g.C2 = u;
+      g.epi = EPI_BIAS | EPI_GELU | (u ? EPI_SAVE_PREACT : 0); g.bias = c.V(c.L(l, y.fc1_b)); g.C2 = u; g.tag = GEMM_TAG_FC1;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
     }
     {
       GemmArgs g = gemm_args(h, c.W(c.L(l, y.fc2_w)), x_out, M, D, d->mlp, d->mlp, d->mlp, D);
-      g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.fc2_b)); g.aux = x_mid; g.ld_aux = D;
+      g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.fc2_b)); g.aux = x_mid; g.ld_aux = D; g.tag = GEMM_TAG_FC2;
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
     }
     x = x_out;
@@ -377,17 +394,18 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     if (dt != RMCL_F32) { RMCL_TRY(rmcl_cast(w.dx, w.dxT, dt, (long)M * D, s)); dxT = w.dxT; }
     {
       GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.fc2_w)), w.du, M, mlp, D, D, mlp, mlp);  // du = (dx W2) * gelu'(u)
-      g.epi = EPI_DGELU; g.aux = ls.u; g.ld_aux = mlp;
+      g.epi = EPI_DGELU; g.aux = ls.u; g.ld_aux = mlp; g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
     }
     if (full) {
-      RMCL_TRY(gemm_dw(c, dxT, D, ls.h, mlp, Gp(c.L(l, y.fc2_w)), D, mlp, M, dt));
+      RMCL_TRY(gemm_dw(c, dxT, D, ls.h, mlp, Gp(c.L(l, y.fc2_w)), D, mlp, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.fc2_b)), M, D, s));
-      RMCL_TRY(gemm_dw(c, w.du, mlp, ls.ln2, D, Gp(c.L(l, y.fc1_w)), mlp, D, M, dt));
+      RMCL_TRY(gemm_dw(c, w.du, mlp, ls.ln2, D, Gp(c.L(l, y.fc1_w)), mlp, D, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(w.du, mlp, dt, Gp(c.L(l, y.fc1_b)), M, mlp, s));
     }
     {
       GemmArgs g = gemm_args(w.du, c.W(c.L(l, y.fc1_w)), w.dln, M, D, mlp, mlp, D, D);   // dln2 = du W1
+      g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
     }
     RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
@@ -397,19 +415,21 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     if (dt != RMCL_F32) { RMCL_TRY(rmcl_cast(w.dx, w.dxT, dt, (long)M * D, s)); dxT = w.dxT; }
     {
       GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);        // dao = dx Wproj
+      g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
     }
     if (full) {
-      RMCL_TRY(gemm_dw(c, dxT, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt));
+      RMCL_TRY(gemm_dw(c, dxT, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.proj_b)), M, D, s));
     }
     RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, ls.probs, w.dao, w.dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
     if (full) {
-      RMCL_TRY(gemm_dw(c, w.dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt));
+      RMCL_TRY(gemm_dw(c, w.dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(w.dqkv, 3 * D, dt, Gp(c.L(l, y.qkv_b)), M, 3 * D, s));
     }
     {
       GemmArgs g = gemm_args(w.dqkv, c.W(c.L(l, y.qkv_w)), w.dln, M, D, 3 * D, 3 * D, D, D);  // dln1 = dqkv Wqkv
+      g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
     }
     RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
@@ -424,7 +444,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
   }
   if (full) {
-    RMCL_TRY(gemm_dw(c, w.dpe, D, patches, d->patch_k, Gp(y.patch_w), D, d->patch_k, B * P, dt));
+    RMCL_TRY(gemm_dw(c, w.dpe, D, patches, d->patch_k, Gp(y.patch_w), D, d->patch_k, B * P, dt, w.slab, SLAB_FLOATS(*d)));
     RMCL_TRY(rmcl_colsum(w.dpe, D, dt, Gp(y.patch_b), B * P, D, s));
     // text rows: x[b*N+t] = LN(e) + vtype[0]
     RMCL_TRY(rmcl_gather_rows(w.dx, w.dln, B * L, D, L, N, 0, s));

@@ -25,6 +25,11 @@ enum {
   EPI_COLSUM = 256,     // TN only: blocks with blockIdx.y==0 atomically add column sums of A (= bias grad) into bias_grad[m]
 };
 
+enum {
+  GEMM_TAG_FC1 = 1, GEMM_TAG_FC2 = 2, GEMM_TAG_QKV = 4, GEMM_TAG_PROJ = 8,   // encoder forward GEMMs
+  GEMM_TAG_DX = 16, GEMM_TAG_DW = 32, GEMM_TAG_PATCH = 64, GEMM_TAG_ATTN = 128, GEMM_TAG_HEAD = 256,
+};
+
 struct GemmArgs {
   const void* A;
   const void* B;
@@ -41,6 +46,7 @@ struct GemmArgs {
   int splitk;             // >1: blockIdx.z = K slice (then nbatch must be 1)
   int nb1, nb2;           // batch = nb1*nb2 (blockIdx.z = b1*nb2 + b2) when splitk == 1
   long sA1, sA2, sB1, sB2, sC1, sC2;  // element strides per batch level
+  int tag;                // profiling class (GEMM_TAG_*), 0 = untagged
 };
 
 #ifdef __cplusplus

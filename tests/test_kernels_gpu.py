@@ -218,3 +218,40 @@ def test_im2patch_roundtrip():
     back = torch.empty_like(img)
     check(lib.rmcl_im2patch_f32(P(back), P(pat), 2, 3, 384, 384, 32, 1, stream()))
     assert torch.equal(back, img)
+
+
+# ------------------------------------------------------------------ bf16 MFMA GEMM (fast path)
+@pytest.mark.parametrize("shape", [(11840, 768, 768), (300, 128, 64), (1000, 3072, 768), (256, 768, 3072)])
+def test_gemm_fast_bf16_layouts(shape):
+    """exact=0 routes to the glds/tr-read MFMA kernel; reference = fp64 matmul of the same bf16 inputs,
+    tolerance = fp32 accumulation-order noise only (products of bf16 are exact in fp32)."""
+    M, N, K = shape
+    X = rnd(M, K, seed=1).to(torch.bfloat16)
+    W = rnd(N, K, seed=2, scale=0.05).to(torch.bfloat16)
+    ref = X.double() @ W.double().t()
+    out = gemm(X, W, M, N, K, 1, 1, L.BF16, L.F32, exact=0)                        # NT
+    assert rel_err(out, ref) < 2e-5
+    Wn = W.t().contiguous()
+    out = gemm(X, Wn, M, N, K, 1, 0, L.BF16, L.F32, exact=0)                       # NN (tr-read B)
+    assert rel_err(out, ref) < 2e-5
+    out_bf = gemm(X, Wn, M, N, K, 1, 0, L.BF16, L.BF16, exact=0)
+    assert rel_err(out_bf, ref) < 1e-2
+    if M % 128 == 0:
+        Xt = X.t().contiguous()
+        base = rnd(M, N, seed=7)
+        out = gemm(Xt, Wn, M, N, K, 0, 0, L.BF16, L.F32, exact=0, epi=64, C_init=base)   # TN + accumulate
+        assert rel_err(out, ref + base.double()) < 2e-5
+
+
+def test_gemm_fast_epilogues_match_exact_kernel():
+    M, N, K = 1111, 256, 192
+    X, W, b = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2, scale=0.1).to(torch.bfloat16), rnd(N, seed=3)
+    R = rnd(M, N, seed=4)
+    U = rnd(M, N, seed=6).to(torch.bfloat16)
+    for epi, kw in ((1 | 2 | 4, dict(bias=b, want_c2=True)), (1 | 8, dict(bias=b, aux=R, ld_aux=N)), (16, dict(aux=U, ld_aux=N))):
+        for dto in (L.F32, L.BF16):
+            a = gemm(X, W, M, N, K, 1, 1, L.BF16, dto, epi=epi, exact=1, **kw)
+            f = gemm(X, W, M, N, K, 1, 1, L.BF16, dto, epi=epi, exact=0, **kw)
+            a, f = (a, f) if isinstance(a, tuple) else ((a,), (f,))
+            for x, y in zip(a, f):
+                assert rel_err(y, x) < (2e-5 if dto == L.F32 else 1e-2)
