@@ -152,12 +152,13 @@ int rmcl_layernorm_bwd(const void* dy, int dt_dy, const float* x, const float* m
                        const float* b, float* dx, int add, float* dgamma, float* dbeta, int M, int D, int relu, void* stream);
 /* Masked multi-head self-attention on a packed qkv [B*N, 3*H*64] (Attention.forward,
  * vision_transformer.py:309-332).  out [B*N, H*64]; probs (stash) and scores (scratch) sized by
- * rmcl_attention_scratch_elems.                                                                  */
+ * rmcl_attention_scratch_elems.  With dtype bf16 and exact=0 the fused flash-style kernels run and
+ * `probs` holds only the per-row log-sum-exp.                                                                  */
 int64_t rmcl_attention_scratch_elems(int B, int H, int N);
 int rmcl_attention_fwd(const void* qkv, const int32_t* mask, void* out, void* probs, float* scores, int B, int N, int H,
                        int dtype, int exact, void* stream);
-int rmcl_attention_bwd(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dscores,
-                       int B, int N, int H, int dtype, int exact, void* stream);
+int rmcl_attention_bwd(const void* qkv, const int32_t* mask, const void* probs, const void* dout, void* dqkv, float* scores,
+                       void* dscores, int B, int N, int H, int dtype, int exact, void* stream);
 
 #ifdef __cplusplus
 }

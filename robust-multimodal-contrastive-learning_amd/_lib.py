@@ -3,6 +3,11 @@ library raises immediately."""
 import ctypes as C
 import os
 
+# torch bundles its own libamdhip64; it MUST be loaded first so that librmcl_hip.so (NEEDED
+# libamdhip64.so.7) binds to that same runtime instance.  Two HIP runtimes in one process leave the
+# second without a device ("no ROCm-capable device is detected").
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librmcl_hip.so")
 

@@ -10,8 +10,8 @@ extern "C" void rmcl_set_error(const char* msg) { g_err = msg ? msg : ""; }
 
 int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* probs, float* scores, int B, int N, int H, int dt,
                             int exact, hipStream_t s);
-int rmcl_attention_bwd_impl(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dS, int B,
-                            int N, int H, int dt, int exact, hipStream_t s);
+int rmcl_attention_bwd_impl(const void* qkv, const int* mask, const void* probs, const void* dout, void* dqkv, float* scores,
+                            void* dS, int B, int N, int H, int dt, int exact, hipStream_t s);
 
 // ---- optional in-stream timing of one GEMM class (bench.py roofline leg) ------------------------
 #include <vector>
@@ -258,10 +258,10 @@ int rmcl_attention_fwd(const void* qkv, const int32_t* mask, void* out, void* pr
   RMCL_REQUIRE(qkv && mask && out && probs && scores, "attention_fwd: NULL argument");
   return rmcl_attention_fwd_impl(qkv, mask, out, probs, scores, B, N, H, dtype, exact, (hipStream_t)stream);
 }
-int rmcl_attention_bwd(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dscores, int B, int N,
-                       int H, int dtype, int exact, void* stream) {
-  RMCL_REQUIRE(qkv && probs && dout && dqkv && scores && dscores, "attention_bwd: NULL argument");
-  return rmcl_attention_bwd_impl(qkv, probs, dout, dqkv, scores, dscores, B, N, H, dtype, exact, (hipStream_t)stream);
+int rmcl_attention_bwd(const void* qkv, const int32_t* mask, const void* probs, const void* dout, void* dqkv, float* scores,
+                       void* dscores, int B, int N, int H, int dtype, int exact, void* stream) {
+  RMCL_REQUIRE(qkv && mask && probs && dout && dqkv && scores && dscores, "attention_bwd: NULL argument");
+  return rmcl_attention_bwd_impl(qkv, mask, probs, dout, dqkv, scores, dscores, B, N, H, dtype, exact, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,393 @@
+// Fused masked multi-head self-attention for gfx950 (bf16 MFMA, fp32 softmax), forward and backward.
+// Replaces Attention.forward (vilt/modules/vision_transformer.py:309-332): QK^T * 0.125, key-padding
+// mask as -inf, softmax, @V  -- without materialising the [B,12,185,185] score / probability tensors.
+//
+// Shape regime of ViLT-B/32: N = 185 tokens (<= 256), head dim 64, so ALL keys of one (batch, head)
+// fit in LDS (192 x 64 bf16 = 24 KiB per image) and a whole score row (12 key tiles) fits in a wave's
+// registers: no online-softmax rescaling is needed.  One workgroup (4 waves) per (batch, head).
+//
+//  forward  : per 16-query tile S^T = K Q^T (keys on registers, query on the lane), softmax in
+//             registers, then O = P V with the S^T accumulators re-used directly as the A operand
+//             (permuted k order) and V read with the hardware-transposing ds_read_b64_tr_b16.
+//  backward : two kernels, both recompute P from the saved log-sum-exp:
+//     dq  kernel (query-parallel): delta = rowsum(P*dP), dS, dQ = dS K          (K via tr-read)
+//     dkv kernel (key-parallel)  : dV = P^T dO, dK = dS^T Q on 16x16x16 MFMAs    (Q, dO via tr-read)
+// LDS images are filled with 16-byte global_load_lds; bank conflicts are removed by permuting the
+// per-lane SOURCE chunk (row images: chunk ^= row&7; transposed-read images: 32-B group ^= (row>>1)&3).
+#include "rmcl_common.h"
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+#define SCALE 0.125f
+
+// ---- staging: rows [0,N) of a [*, 64] bf16 slice (row pitch ld elements) -> LDS image of NKP rows x 128 B
+template <bool TR>
+__device__ __forceinline__ void stage_rows(char* img, const bf16_t* __restrict__ src, long ld, int N, int NKP, int wave, int lane) {
+  for (int inst = wave; inst < NKP / 8; inst += 4) {
+    const int row = inst * 8 + (lane >> 3), cp = lane & 7;
+    int c;
+    if (TR) c = (((cp >> 1) ^ ((row >> 1) & 3)) << 1) | (cp & 1);
+    else c = cp ^ (row & 7);
+    const bf16_t* p = src + (long)min(row, N - 1) * ld + c * 8;
+    __builtin_amdgcn_global_load_lds((glb_void*)p, (lds_void*)(img + inst * 1024), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ bf16x8 frag_row_lds(const char* img, int row0, int s, int lane) {
+  const int row = row0 + (lane & 15);
+  const int chunk = (4 * s + (lane >> 4)) ^ (row & 7);
+  return *reinterpret_cast<const bf16x8*>(img + row * 128 + chunk * 16);
+}
+
+__device__ __forceinline__ bf16x8 frag_row_global(const bf16_t* __restrict__ src, long ld, int row0, int N, int s, int lane) {
+  const int row = min(row0 + (lane & 15), N - 1);
+  return *reinterpret_cast<const bf16x8*>(src + (long)row * ld + 32 * s + 8 * (lane >> 4));
+}
+
+__device__ __forceinline__ s16x4 tr4(const char* img, int row, int dt, int p) {
+  const int t = dt ^ ((row >> 1) & 3);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + row * 128 + t * 32 + p * 8));
+}
+
+// B operand for a 32-deep k step whose k order is the accumulator order: k(g,j) = base + 16*(j>>2) + 4g + (j&3)
+__device__ __forceinline__ bf16x8 frag_tr32_lds(const char* img, int base, int dt, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  union { bf16x8 v; s16x4 h[2]; } u;
+  u.h[0] = tr4(img, base + 4 * g + q, dt, p);
+  u.h[1] = tr4(img, base + 16 + 4 * g + q, dt, p);
+  return u.v;
+}
+// B operand for the 16x16x16 MFMA: rows base + 4g + j
+__device__ __forceinline__ s16x4 frag_tr16_lds(const char* img, int base, int dt, int lane) {
+  return tr4(img, base + 4 * (lane >> 4) + ((lane & 15) >> 2), dt, lane & 3);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  union { bf16x8 v; bf16_t e[8]; } u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { u.e[i] = f2bf(a[i]); u.e[4 + i] = f2bf(b[i]); }
+  return u.v;
+}
+__device__ __forceinline__ s16x4 pack4(const f32x4& a) {
+  union { s16x4 v; bf16_t e[4]; } u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u.e[i] = f2bf(a[i]);
+  return u.v;
+}
+
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups that share lane&15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+__device__ __forceinline__ void fill_maskbias(float* mb, const int* __restrict__ mask, int N, int NKP, int t) {
+  for (int j = t; j < NKP; j += 256) mb[j] = (j < N && mask[j] != 0) ? 0.f : -INFINITY;
+}
+
+// ================================================================================== forward
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
+                                                       bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int NKP = NKT * 16;
+  char* Kimg = sm;
+  char* Vimg = sm + NKP * 128;
+  float* mb = reinterpret_cast<float*>(sm + 2 * NKP * 128);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * 64;
+  const long ld = 3 * D;
+  const bf16_t* base = qkv + (long)b * N * ld + h * 64;
+  stage_rows<false>(Kimg, base + D, ld, N, NKP, wave, lane);
+  stage_rows<true>(Vimg, base + 2 * D, ld, N, NKP, wave, lane);
+  fill_maskbias(mb, mask + (long)b * N, N, NKP, t);
+  __syncthreads();
+
+  const int nqt = (N + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    bf16x8 qf[2];
+    qf[0] = frag_row_global(base, ld, qt * 16, N, 0, lane);
+    qf[1] = frag_row_global(base, ld, qt * 16, N, 1, lane);
+    f32x4 S[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row_lds(Kimg, kt * 16, s, lane), qf[s], S[kt], 0, 0, 0);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const float4 bias = *reinterpret_cast<const float4*>(mb + kt * 16 + 4 * g);
+      S[kt][0] = S[kt][0] * SCALE + bias.x; S[kt][1] = S[kt][1] * SCALE + bias.y;
+      S[kt][2] = S[kt][2] * SCALE + bias.z; S[kt][3] = S[kt][3] * SCALE + bias.w;
+      m = fmaxf(m, fmaxf(fmaxf(S[kt][0], S[kt][1]), fmaxf(S[kt][2], S[kt][3])));
+    }
+    m = group_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { S[kt][r] = __expf(S[kt][r] - m); l += S[kt][r]; }
+    l = group_sum(l);
+    const int q_lane = qt * 16 + (lane & 15);
+    if (g == 0 && q_lane < N) lse[((long)blockIdx.x) * NKP + q_lane] = m + __logf(l);
+    f32x4 O[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 pa = pack8(S[2 * u], S[2 * u + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr32_lds(Vimg, 32 * u, dt, lane), O[dt], 0, 0, 0);
+    }
+    const float linv = 1.0f / l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float li = __shfl(linv, 4 * g + r, 64);           // 1/l of query row 4g+r lives in lane 4g+r
+      const int q = qt * 16 + 4 * g + r;
+      if (q < N) {
+        bf16_t* o = out + ((long)b * N + q) * D + h * 64 + (lane & 15);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[16 * dt] = f2bf(O[dt][r] * li);
+      }
+    }
+  }
+}
+
+// ================================================================================== backward: dQ, delta
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
+                                                          const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int NKP = NKT * 16;
+  char* Krow = sm;
+  char* Vrow = sm + NKP * 128;
+  char* Ktr = sm + 2 * NKP * 128;
+  float* mb = reinterpret_cast<float*>(sm + 3 * NKP * 128);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * 64;
+  const long ld = 3 * D;
+  const bf16_t* base = qkv + (long)b * N * ld + h * 64;
+  const bf16_t* dob = dout + (long)b * N * D + h * 64;
+  stage_rows<false>(Krow, base + D, ld, N, NKP, wave, lane);
+  stage_rows<false>(Vrow, base + 2 * D, ld, N, NKP, wave, lane);
+  stage_rows<true>(Ktr, base + D, ld, N, NKP, wave, lane);
+  fill_maskbias(mb, mask + (long)b * N, N, NKP, t);
+  __syncthreads();
+
+  const int nqt = (N + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    bf16x8 qf[2], df[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      qf[s] = frag_row_global(base, ld, qt * 16, N, s, lane);
+      df[s] = frag_row_global(dob, D, qt * 16, N, s, lane);
+    }
+    const int q_lane = qt * 16 + (lane & 15);
+    const float L = q_lane < N ? lse[((long)blockIdx.x) * NKP + q_lane] : INFINITY;
+    f32x4 S[NKT], dP[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dP[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row_lds(Krow, kt * 16, s, lane), qf[s], S[kt], 0, 0, 0);
+        dP[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row_lds(Vrow, kt * 16, s, lane), df[s], dP[kt], 0, 0, 0);
+      }
+    }
+    float dl = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const float4 bias = *reinterpret_cast<const float4*>(mb + kt * 16 + 4 * g);
+      const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        S[kt][r] = __expf(S[kt][r] * SCALE + bb[r] - L);       // P
+        dl += S[kt][r] * dP[kt][r];
+      }
+    }
+    dl = group_sum(dl);
+    if (g == 0 && q_lane < N) delta[((long)blockIdx.x) * NKP + q_lane] = dl;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S[kt][r] = S[kt][r] * (dP[kt][r] - dl) * SCALE;   // dS
+    f32x4 dQ[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 sa = pack8(S[2 * u], S[2 * u + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dQ[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, frag_tr32_lds(Ktr, 32 * u, dt, lane), dQ[dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = qt * 16 + 4 * g + r;
+      if (q < N) {
+        bf16_t* o = dqkv + ((long)b * N + q) * ld + h * 64 + (lane & 15);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[16 * dt] = f2bf(dQ[dt][r]);
+      }
+    }
+  }
+}
+
+// ================================================================================== backward: dK, dV
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
+                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                           const float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int NKP = NKT * 16, TPW = NKT / 4;
+  char* Qtr = sm;
+  char* Dtr = sm + NKP * 128;
+  float* Ls = reinterpret_cast<float*>(sm + 2 * NKP * 128);   // lse per query (+inf for pad rows)
+  float* Ds = Ls + NKP;                                       // delta per query
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * 64;
+  const long ld = 3 * D;
+  const bf16_t* base = qkv + (long)b * N * ld + h * 64;
+  const bf16_t* dob = dout + (long)b * N * D + h * 64;
+  stage_rows<true>(Qtr, base, ld, N, NKP, wave, lane);
+  stage_rows<true>(Dtr, dob, D, N, NKP, wave, lane);
+  for (int j = t; j < NKP; j += 256) {
+    Ls[j] = j < N ? lse[((long)blockIdx.x) * NKP + j] : INFINITY;
+    Ds[j] = j < N ? delta[((long)blockIdx.x) * NKP + j] : 0.f;
+  }
+  // this wave's key tiles: kt = wave + 4*i ; K / V fragments and key mask stay in registers
+  bf16x8 kf[TPW][2], vf[TPW][2];
+  float mbk[TPW];
+  const int* mrow = mask + (long)b * N;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = wave + 4 * i, key = kt * 16 + (lane & 15);
+    mbk[i] = (key < N && mrow[key] != 0) ? 0.f : -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      kf[i][s] = frag_row_global(base + D, ld, kt * 16, N, s, lane);
+      vf[i][s] = frag_row_global(base + 2 * D, ld, kt * 16, N, s, lane);
+    }
+  }
+  f32x4 dK[TPW][4], dV[TPW][4];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dK[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __syncthreads();
+
+  const int nqt = (N + 15) / 16;
+  for (int qt = 0; qt < nqt; ++qt) {
+    bf16x8 qf[2], df[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      qf[s] = frag_row_global(base, ld, qt * 16, N, s, lane);
+      df[s] = frag_row_global(dob, D, qt * 16, N, s, lane);
+    }
+    const float4 L4 = *reinterpret_cast<const float4*>(Ls + qt * 16 + 4 * g);
+    const float4 D4 = *reinterpret_cast<const float4*>(Ds + qt * 16 + 4 * g);
+    const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+    s16x4 dot[4], qtr[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dot[dt] = frag_tr16_lds(Dtr, qt * 16, dt, lane);
+      qtr[dt] = frag_tr16_lds(Qtr, qt * 16, dt, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], kf[i][s], S, 0, 0, 0);        // S[q=4g+r][key=lane&15]
+        dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[s], vf[i][s], dP, 0, 0, 0);
+      }
+      f32x4 P, dS;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        P[r] = __expf(S[r] * SCALE + mbk[i] - Lr[r]);
+        dS[r] = P[r] * (dP[r] - Dr[r]) * SCALE;
+      }
+      const s16x4 pa = pack4(P), sa = pack4(dS);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dV[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, dot[dt], dV[i][dt], 0, 0, 0);   // += P^T dO
+        dK[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(sa, qtr[dt], dK[i][dt], 0, 0, 0);   // += dS^T Q
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int kt = wave + 4 * i;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kt * 16 + 4 * g + r;
+      if (key < N) {
+        bf16_t* o = dqkv + ((long)b * N + key) * ld + h * 64 + (lane & 15);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          o[D + 16 * dt] = f2bf(dK[i][dt][r]);
+          o[2 * D + 16 * dt] = f2bf(dV[i][dt][r]);
+        }
+      }
+    }
+  }
+}
+
+// ================================================================================== launchers
+static inline int nkt_for(int N) { return N <= 64 ? 4 : N <= 128 ? 8 : N <= 192 ? 12 : 16; }
+
+long rmcl_attn_stat_elems(int B, int H, int N) { return (long)B * H * nkt_for(N) * 16; }
+
+template <int NKT> static int launch_fwd(const bf16_t* qkv, const int* mask, bf16_t* out, float* lse, int B, int N, int H, hipStream_t s) {
+  const size_t lds = (size_t)2 * NKT * 16 * 128 + NKT * 16 * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RMCL_LAUNCH(attn_fwd_kernel<NKT>, dim3(B * H), dim3(256), lds, s, qkv, mask, out, lse, N, H);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+template <int NKT> static int launch_bwd(const bf16_t* qkv, const int* mask, const bf16_t* dout, const float* lse, float* delta,
+                                         bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
+  const size_t lds1 = (size_t)3 * NKT * 16 * 128 + NKT * 16 * 4, lds2 = (size_t)2 * NKT * 16 * 128 + 2 * NKT * 16 * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+  RMCL_LAUNCH(attn_bwd_dq_kernel<NKT>, dim3(B * H), dim3(256), lds1, s, qkv, mask, dout, lse, delta, dqkv, N, H);
+  RMCL_CHECK_LAUNCH();
+  RMCL_LAUNCH(attn_bwd_dkv_kernel<NKT>, dim3(B * H), dim3(256), lds2, s, qkv, mask, dout, lse, delta, dqkv, N, H);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+int rmcl_attn_fused_fwd(const void* qkv, const int* mask, void* out, float* lse, int B, int N, int H, hipStream_t s) {
+  RMCL_REQUIRE(N >= 1 && N <= 256, "fused attention: N must be <= 256");
+  const bf16_t* q = (const bf16_t*)qkv;
+  bf16_t* o = (bf16_t*)out;
+  switch (nkt_for(N)) {
+    case 4: return launch_fwd<4>(q, mask, o, lse, B, N, H, s);
+    case 8: return launch_fwd<8>(q, mask, o, lse, B, N, H, s);
+    case 12: return launch_fwd<12>(q, mask, o, lse, B, N, H, s);
+    default: return launch_fwd<16>(q, mask, o, lse, B, N, H, s);
+  }
+}
+
+int rmcl_attn_fused_bwd(const void* qkv, const int* mask, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                        int N, int H, hipStream_t s) {
+  RMCL_REQUIRE(N >= 1 && N <= 256, "fused attention: N must be <= 256");
+  const bf16_t* q = (const bf16_t*)qkv;
+  const bf16_t* d = (const bf16_t*)dout;
+  bf16_t* o = (bf16_t*)dqkv;
+  switch (nkt_for(N)) {
+    case 4: return launch_bwd<4>(q, mask, d, lse, delta, o, B, N, H, s);
+    case 8: return launch_bwd<8>(q, mask, d, lse, delta, o, B, N, H, s);
+    case 12: return launch_bwd<12>(q, mask, d, lse, delta, o, B, N, H, s);
+    default: return launch_bwd<16>(q, mask, d, lse, delta, o, B, N, H, s);
+  }
+}

@@ -61,7 +61,7 @@ int rmcl_text_embed_fwd(const long* ids, const float* word, const float* pos, co
                         const float* beta, const float* vtype0, float eps, float* x, float* e_save, float* mean, float* rstd,
                         int B, int L, int N, int D, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0 && D <= 1024, "text_embed: D must be a multiple of 4 and <= 1024");
-  hipLaunchKernelGGL(text_embed_fwd_kernel, dim3(cdiv((long)B * L, 4)), dim3(256), 0, s, ids, word, pos, btype0, g, beta, vtype0,
+  RMCL_LAUNCH(text_embed_fwd_kernel, dim3(cdiv((long)B * L, 4)), dim3(256), 0, s, ids, word, pos, btype0, g, beta, vtype0,
                      eps, x, e_save, mean, rstd, B, L, N, D);
   RMCL_CHECK_LAUNCH();
   return 0;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void text_embed_scatter_kernel(const long* __r
 
 int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, float* dpos, float* dbtype0, int B, int L, int D,
                             long pad_id, hipStream_t s) {
-  hipLaunchKernelGGL(text_embed_scatter_kernel, dim3(B * L), dim3(256), 0, s, ids, de, dword, dpos, dbtype0, B, L, D, pad_id);
+  RMCL_LAUNCH(text_embed_scatter_kernel, dim3(B * L), dim3(256), 0, s, ids, de, dword, dpos, dbtype0, B, L, D, pad_id);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 int rmcl_gather_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0, "gather_rows: D%4");
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv((long)R * (D / 4), 256)), dim3(256), 0, s, in, out, R, D, rows_per, stride_outer, off);
+  RMCL_LAUNCH(gather_rows_kernel, dim3(cdiv((long)R * (D / 4), 256)), dim3(256), 0, s, in, out, R, D, rows_per, stride_outer, off);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
 }
 int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, int add, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0, "scatter_rows: D%4");
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(cdiv((long)R * (D / 4), 256)), dim3(256), 0, s, in, out, R, D, rows_per, stride_outer, off, add);
+  RMCL_LAUNCH(scatter_rows_kernel, dim3(cdiv((long)R * (D / 4), 256)), dim3(256), 0, s, in, out, R, D, rows_per, stride_outer, off, add);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void image_assemble_fwd_kernel(const float* __
 int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos, const float* vtype1, float* x, int B, int P,
                             int L, int N, int D, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0, "image_assemble: D%4");
-  hipLaunchKernelGGL(image_assemble_fwd_kernel, dim3(cdiv((long)B * (P + 1) * (D / 4), 256)), dim3(256), 0, s, pe, cls, pos, vtype1, x, B, P, L, N, D);
+  RMCL_LAUNCH(image_assemble_fwd_kernel, dim3(cdiv((long)B * (P + 1) * (D / 4), 256)), dim3(256), 0, s, pe, cls, pos, vtype1, x, B, P, L, N, D);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void image_assemble_bwd_kernel(const float* __
 int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,
                             int N, int D, hipStream_t s) {
   dim3 grid(P + 1, cdiv(D, 256));
-  if (dt == RMCL_F32) hipLaunchKernelGGL(image_assemble_bwd_kernel<float>, grid, dim3(256), 0, s, dx, (float*)dpe, dpos, dcls, dvtype1, B, P, L, N, D);
-  else hipLaunchKernelGGL(image_assemble_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dx, (bf16_t*)dpe, dpos, dcls, dvtype1, B, P, L, N, D);
+  if (dt == RMCL_F32) RMCL_LAUNCH(image_assemble_bwd_kernel<float>, grid, dim3(256), 0, s, dx, (float*)dpe, dpos, dcls, dvtype1, B, P, L, N, D);
+  else RMCL_LAUNCH(image_assemble_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dx, (bf16_t*)dpe, dpos, dcls, dvtype1, B, P, L, N, D);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void im2patch_kernel(const float* __restrict__
 }
 int rmcl_im2patch(const float* img, float* pat, int B, int C, int Hh, int Ww, int ps, int to_image, hipStream_t s) {
   RMCL_REQUIRE(ps % 4 == 0 && Hh % ps == 0 && Ww % ps == 0, "im2patch: image sides must be multiples of the patch size");
-  hipLaunchKernelGGL(im2patch_kernel, dim3(cdiv((long)B * C * Hh * Ww / 4, 256)), dim3(256), 0, s, img, pat, B, C, Hh, Ww, ps, to_image);
+  RMCL_LAUNCH(im2patch_kernel, dim3(cdiv((long)B * C * Hh * Ww / 4, 256)), dim3(256), 0, s, img, pat, B, C, Hh, Ww, ps, to_image);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__
 int rmcl_k_add_cast(const float* a, const float* d1, const float* d2, void* out, int dt, long n, hipStream_t s) {
   RMCL_REQUIRE(n % 4 == 0, "add_cast: n%4");
   const int grid = (int)std::min<long>(cdiv(n / 4, 256), 8192);
-  if (dt == RMCL_F32) hipLaunchKernelGGL(add_cast_kernel<float>, dim3(grid), dim3(256), 0, s, a, d1, d2, (float*)out, n / 4);
-  else hipLaunchKernelGGL(add_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, d1, d2, (bf16_t*)out, n / 4);
+  if (dt == RMCL_F32) RMCL_LAUNCH(add_cast_kernel<float>, dim3(grid), dim3(256), 0, s, a, d1, d2, (float*)out, n / 4);
+  else RMCL_LAUNCH(add_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, a, d1, d2, (bf16_t*)out, n / 4);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void co_mask_kernel(const long* __restrict__ t
 }
 int rmcl_co_mask(const long* text_mask, const void* pat, int dt, int* co, int B, int L, int P, int C, int pp, hipStream_t s) {
   dim3 grid(cdiv((long)B * (L + 1 + P), 256));
-  if (dt == RMCL_F32) hipLaunchKernelGGL(co_mask_kernel<float>, grid, dim3(256), 0, s, text_mask, (const float*)pat, co, B, L, P, C, pp);
-  else hipLaunchKernelGGL(co_mask_kernel<bf16_t>, grid, dim3(256), 0, s, text_mask, (const bf16_t*)pat, co, B, L, P, C, pp);
+  if (dt == RMCL_F32) RMCL_LAUNCH(co_mask_kernel<float>, grid, dim3(256), 0, s, text_mask, (const float*)pat, co, B, L, P, C, pp);
+  else RMCL_LAUNCH(co_mask_kernel<bf16_t>, grid, dim3(256), 0, s, text_mask, (const bf16_t*)pat, co, B, L, P, C, pp);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -303,11 +303,11 @@ int rmcl_pgd_update(const void* g, int dt, float* delta, unsigned* amax_bits, in
   if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
   dim3 grid(std::min<long>(cdiv(per_sample, 1024), 64), B);
   if (dt == RMCL_F32) {
-    hipLaunchKernelGGL(absmax_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, per_sample);
-    hipLaunchKernelGGL(pgd_update_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, delta, per_sample, lr, eps);
+    RMCL_LAUNCH(absmax_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, per_sample);
+    RMCL_LAUNCH(pgd_update_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, delta, per_sample, lr, eps);
   } else {
-    hipLaunchKernelGGL(absmax_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, amax_bits, per_sample);
-    hipLaunchKernelGGL(pgd_update_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, amax_bits, delta, per_sample, lr, eps);
+    RMCL_LAUNCH(absmax_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, amax_bits, per_sample);
+    RMCL_LAUNCH(pgd_update_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, amax_bits, delta, per_sample, lr, eps);
   }
   RMCL_CHECK_LAUNCH();
   return 0;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void delta_chan_norm_kernel(const float* __res
   if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 int rmcl_delta_chan_norm(const float* d, float* out, long rows, int C, int pp, hipStream_t s) {
-  hipLaunchKernelGGL(delta_chan_norm_kernel, dim3(std::min<long>(cdiv(rows * pp, 256), 2048)), dim3(256), 0, s, d, out, rows, C, pp);
+  RMCL_LAUNCH(delta_chan_norm_kernel, dim3(std::min<long>(cdiv(rows * pp, 256), 2048)), dim3(256), 0, s, d, out, rows, C, pp);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ k, const f
 }
 int rmcl_ema(float* k, const float* q, void* k_lp, float m, long n, hipStream_t s) {
   RMCL_REQUIRE(n % 4 == 0, "ema: n%4");
-  hipLaunchKernelGGL(ema_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 4096)), dim3(256), 0, s, k, q, (bf16_t*)k_lp, m, n / 4);
+  RMCL_LAUNCH(ema_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 4096)), dim3(256), 0, s, k, q, (bf16_t*)k_lp, m, n / 4);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void enqueue_kernel(float* __restrict__ queue,
 }
 int rmcl_enqueue(float* queue, const float* keys, int n, int Pd, long Kq, long ptr, hipStream_t s) {
   RMCL_REQUIRE(ptr >= 0 && ptr + n <= Kq, "enqueue: block would run past the end of the queue (needs Kq % batch == 0)");
-  hipLaunchKernelGGL(enqueue_kernel, dim3(cdiv((long)n * Pd, 256)), dim3(256), 0, s, queue, keys, n, Pd, Kq, ptr);
+  RMCL_LAUNCH(enqueue_kernel, dim3(cdiv((long)n * Pd, 256)), dim3(256), 0, s, queue, keys, n, Pd, Kq, ptr);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict_
   for (int c = lane; c < D; c += 64) q[(long)r * D + c] = z[(long)r * D + c] / n;
 }
 int rmcl_l2norm_fwd(const float* z, float* q, float* nrm, int R, int D, float eps, hipStream_t s) {
-  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(R), dim3(64), 0, s, z, q, nrm, D, eps);
+  RMCL_LAUNCH(l2norm_fwd_kernel, dim3(R), dim3(64), 0, s, z, q, nrm, D, eps);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void l2norm_bwd_kernel(const float* __restrict_
   for (int c = lane; c < D; c += 64) dz[(long)r * D + c] = (dq[(long)r * D + c] - q[(long)r * D + c] * s) * inv;
 }
 int rmcl_l2norm_bwd(const float* dq, const float* q, const float* nrm, float* dz, int R, int D, hipStream_t s) {
-  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(R), dim3(64), 0, s, dq, q, nrm, dz, D);
+  RMCL_LAUNCH(l2norm_bwd_kernel, dim3(R), dim3(64), 0, s, dq, q, nrm, dz, D);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(float* __restrict__ g, co
   if (i < n) g[i] *= (1.0f - y[i] * y[i]);
 }
 int rmcl_tanh_bwd(float* g, const float* y, long n, hipStream_t s) {
-  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g, y, n);
+  RMCL_LAUNCH(tanh_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, g, y, n);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -465,7 +465,7 @@ int rmcl_adamw(float* p, const float* g, float* m, float* v, void* p_lp, const l
                hipStream_t s) {
   RMCL_REQUIRE(n % 4 == 0 && nseg > 0 && step >= 1, "adamw: bad args");
   const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 4096)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp, seg_end,
+  RMCL_LAUNCH(adamw_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 4096)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp, seg_end,
                      seg_lr_mult, seg_wd, nseg, lr, b1, b2, eps, bc1, bc2s, n / 4, grad_scale);
   RMCL_CHECK_LAUNCH();
   return 0;

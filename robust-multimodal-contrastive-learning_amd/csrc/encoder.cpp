@@ -192,6 +192,8 @@ int gemm_dw(const Ctx& c, const void* dY, long lddy, const void* X, long ldx, fl
 
 int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* probs, float* scores, int B, int N, int H, int dt,
                             int exact, hipStream_t s) {
+  // bf16 fast path: fused kernel; `probs` then holds only the per-row log-sum-exp (fp32 [B,H,NKP])
+  if (dt == RMCL_BF16 && !exact && N <= 256) return rmcl_attn_fused_fwd(qkv, mask, out, (float*)probs, B, N, H, s);
   const int D = H * 64, ldp = ldp_of(N);
   const size_t e = esz(dt);
   // S = 0.125 * Q K^T   (batched over (b,h); Q/K rows are 3D apart, heads 64 apart)
@@ -211,8 +213,11 @@ int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* p
   return 0;
 }
 
-int rmcl_attention_bwd_impl(const void* qkv, const void* probs, const void* dout, void* dqkv, float* scores, void* dS, int B,
-                            int N, int H, int dt, int exact, hipStream_t s) {
+int rmcl_attention_bwd_impl(const void* qkv, const int* mask, const void* probs, const void* dout, void* dqkv, float* scores,
+                            void* dS, int B, int N, int H, int dt, int exact, hipStream_t s) {
+  // bf16 fast path: probs = saved log-sum-exp, scores = scratch for delta (both fp32 [B,H,NKP])
+  if (dt == RMCL_BF16 && !exact && N <= 256)
+    return rmcl_attn_fused_bwd(qkv, mask, dout, (const float*)probs, scores, dqkv, B, N, H, s);
   const int D = H * 64, ldp = ldp_of(N);
   const size_t e = esz(dt);
   const long sQ1 = (long)N * 3 * D, sP1 = (long)H * N * ldp, sP2 = (long)N * ldp;
@@ -422,7 +427,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       RMCL_TRY(gemm_dw(c, dxT, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.proj_b)), M, D, s));
     }
-    RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, ls.probs, w.dao, w.dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
+    RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, co_mask, ls.probs, w.dao, w.dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
     if (full) {
       RMCL_TRY(gemm_dw(c, w.dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(w.dqkv, 3 * D, dt, Gp(c.L(l, y.qkv_b)), M, 3 * D, s));

@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256) void gemm_exact_kernel(GemmArgs g) {
 
 template <typename TI, typename TO>
 static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipStream_t s) {
-  if (a_kc && b_kc) hipLaunchKernelGGL((gemm_exact_kernel<TI, TO, true, true>), grid, dim3(256), 0, s, g);
-  else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_exact_kernel<TI, TO, true, false>), grid, dim3(256), 0, s, g);
-  else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_exact_kernel<TI, TO, false, false>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_exact_kernel<TI, TO, false, true>), grid, dim3(256), 0, s, g);
+  if (a_kc && b_kc) RMCL_LAUNCH((gemm_exact_kernel<TI, TO, true, true>), grid, dim3(256), 0, s, g);
+  else if (a_kc && !b_kc) RMCL_LAUNCH((gemm_exact_kernel<TI, TO, true, false>), grid, dim3(256), 0, s, g);
+  else if (!a_kc && !b_kc) RMCL_LAUNCH((gemm_exact_kernel<TI, TO, false, false>), grid, dim3(256), 0, s, g);
+  else RMCL_LAUNCH((gemm_exact_kernel<TI, TO, false, true>), grid, dim3(256), 0, s, g);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

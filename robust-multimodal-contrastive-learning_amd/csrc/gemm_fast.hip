@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 int rmcl_slab_reduce(const float* slab, float* out, long n, int nz, hipStream_t s) {
   RMCL_REQUIRE(n % 4 == 0, "slab_reduce: n%4");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 2048)), dim3(256), 0, s, slab, out, n / 4, nz);
+  RMCL_LAUNCH(slab_reduce_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 2048)), dim3(256), 0, s, slab, out, n / 4, nz);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -238,8 +238,8 @@ static int launch_fast(const GemmArgs& g, int dt_out, dim3 grid, int tm, int tn,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     attr = true;
   }
-  if (dt_out == RMCL_F32) hipLaunchKernelGGL((gemm_fast_kernel<A_KC, B_KC, float>), grid, dim3(256), 2 * STAGE_BYTES, s, g, tm, tn);
-  else hipLaunchKernelGGL((gemm_fast_kernel<A_KC, B_KC, bf16_t>), grid, dim3(256), 2 * STAGE_BYTES, s, g, tm, tn);
+  if (dt_out == RMCL_F32) RMCL_LAUNCH((gemm_fast_kernel<A_KC, B_KC, float>), grid, dim3(256), 2 * STAGE_BYTES, s, g, tm, tn);
+  else RMCL_LAUNCH((gemm_fast_kernel<A_KC, B_KC, bf16_t>), grid, dim3(256), 2 * STAGE_BYTES, s, g, tm, tn);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

@@ -240,9 +240,9 @@ int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int 
     hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(infonce_partial_kernel, dim3(ns, Bpad / RT), dim3(256), lds, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
+  RMCL_LAUNCH(infonce_partial_kernel, dim3(ns, Bpad / RT), dim3(256), lds, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
   RMCL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(infonce_combine_kernel, dim3(B), dim3(PD), 0, s, q, k, part, dq_part, ns, B, Bpad, Kq, 1.0f / T, gscale, dq,
+  RMCL_LAUNCH(infonce_combine_kernel, dim3(B), dim3(PD), 0, s, q, k, part, dq_part, ns, B, Bpad, Kq, 1.0f / T, gscale, dq,
                      rows_out, loss_sum);
   RMCL_CHECK_LAUNCH();
   return 0;

@@ -72,7 +72,7 @@ int rmcl_ipot(const float* cost, const int* txt_valid, const int* img_valid, flo
     hipFuncSetAttribute(reinterpret_cast<const void*>(ipot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
-  hipLaunchKernelGGL(ipot_kernel, dim3(B), dim3(256), lds, s, cost, txt_valid, img_valid, T, Lt, Li, beta, iters);
+  RMCL_LAUNCH(ipot_kernel, dim3(B), dim3(256), lds, s, cost, txt_valid, img_valid, T, Lt, Li, beta, iters);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void cost_finish_kernel(float* __restrict__ co
   cost[i] = ok ? 1.0f - cost[i] : 0.f;
 }
 int rmcl_cost_finish(float* cost, const int* txt_valid, const int* img_valid, int B, int Lt, int Li, hipStream_t s) {
-  hipLaunchKernelGGL(cost_finish_kernel, dim3(cdiv((long)B * Lt * Li, 256)), dim3(256), 0, s, cost, txt_valid, img_valid, B, Lt, Li);
+  RMCL_LAUNCH(cost_finish_kernel, dim3(cdiv((long)B * Lt * Li, 256)), dim3(256), 0, s, cost, txt_valid, img_valid, B, Lt, Li);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void wpa_dist_kernel(const float* __restrict__
   if (t == 0) dist[b] = red[0] + red[1] + red[2] + red[3];
 }
 int rmcl_wpa_dist(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, hipStream_t s) {
-  hipLaunchKernelGGL(wpa_dist_kernel, dim3(B), dim3(256), 0, s, cost, T, w, dist, dsim, Lt, Li);
+  RMCL_LAUNCH(wpa_dist_kernel, dim3(B), dim3(256), 0, s, cost, T, w, dist, dsim, Lt, Li);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

@@ -68,9 +68,9 @@ int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float 
   if (M <= 0) return 0;
   dim3 grid(cdiv(M, 4));
   if (dt_out == RMCL_F32)
-    hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, dim3(256), 0, s, x, ldx, w, b, eps, (float*)y, ldy, mean, rstd, M, D, relu);
+    RMCL_LAUNCH(ln_fwd_kernel<float>, grid, dim3(256), 0, s, x, ldx, w, b, eps, (float*)y, ldy, mean, rstd, M, D, relu);
   else
-    hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, w, b, eps, (bf16_t*)y, ldy, mean, rstd, M, D, relu);
+    RMCL_LAUNCH(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, w, b, eps, (bf16_t*)y, ldy, mean, rstd, M, D, relu);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -178,9 +178,9 @@ int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, 
   if (M <= 0) return 0;
   dim3 grid(cdiv(M, 4 * LNB_ITERS));
   if (dt_dy == RMCL_F32)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu);
+    RMCL_LAUNCH(ln_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu);
+    RMCL_LAUNCH(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -228,8 +228,8 @@ int rmcl_softmax_fwd(const float* S, long lds, const int* mask, void* P, long ld
   RMCL_REQUIRE(N <= 64 * SM_MAXE && ldp <= 64 * SM_MAXE, "softmax: N too large");
   const long rows = (long)Z * N;
   dim3 grid(cdiv(rows, 4));
-  if (dt == RMCL_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, grid, dim3(256), 0, s, S, lds, mask, (float*)P, ldp, (int)rows, N, H);
-  else hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, S, lds, mask, (bf16_t*)P, ldp, (int)rows, N, H);
+  if (dt == RMCL_F32) RMCL_LAUNCH(softmax_fwd_kernel<float>, grid, dim3(256), 0, s, S, lds, mask, (float*)P, ldp, (int)rows, N, H);
+  else RMCL_LAUNCH(softmax_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, S, lds, mask, (bf16_t*)P, ldp, (int)rows, N, H);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -263,8 +263,8 @@ int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* 
   RMCL_REQUIRE(N <= 64 * SM_MAXE && ldds <= 64 * SM_MAXE, "softmax bwd: N too large");
   const long rows = (long)Z * N;
   dim3 grid(cdiv(rows, 4));
-  if (dt == RMCL_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)P, ldp, dP, lddp, (float*)dS, ldds, (int)rows, N, scale);
-  else hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)P, ldp, dP, lddp, (bf16_t*)dS, ldds, (int)rows, N, scale);
+  if (dt == RMCL_F32) RMCL_LAUNCH(softmax_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)P, ldp, dP, lddp, (float*)dS, ldds, (int)rows, N, scale);
+  else RMCL_LAUNCH(softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)P, ldp, dP, lddp, (bf16_t*)dS, ldds, (int)rows, N, scale);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, lo
 int rmcl_colsum(const void* X, long ld, int dt, float* out, int M, int N, hipStream_t s) {
   if (M <= 0 || N <= 0) return 0;
   dim3 grid(cdiv(N, 64), cdiv(M, CS_ROWS));
-  if (dt == RMCL_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ld, out, M, N);
-  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ld, out, M, N);
+  if (dt == RMCL_F32) RMCL_LAUNCH(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ld, out, M, N);
+  else RMCL_LAUNCH(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ld, out, M, N);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

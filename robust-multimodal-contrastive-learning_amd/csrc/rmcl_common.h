@@ -48,6 +48,14 @@ __device__ __forceinline__ float wave_max(float v) {
 extern "C" void rmcl_set_error(const char* msg);
 #endif
 
+// Launch with a clean error slate: hipGetLastError() is per-thread sticky state that other HIP users in
+// the process (torch) may have left set; clear it first so RMCL_CHECK_LAUNCH reports OUR launch only.
+#define RMCL_LAUNCH(...)                 \
+  do {                                   \
+    (void)hipGetLastError();             \
+    hipLaunchKernelGGL(__VA_ARGS__);     \
+  } while (0)
+
 #define RMCL_CHECK_LAUNCH()                                   \
   do {                                                        \
     hipError_t _e = hipGetLastError();                        \

@@ -97,9 +97,10 @@ def test_layernorm_fwd_bwd(relu):
 
 
 # ------------------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("dt", [L.F32, L.BF16])
-@pytest.mark.parametrize("BN", [(3, 185), (2, 64), (1, 241)])
-def test_attention_fwd_bwd(dt, BN):
+@pytest.mark.parametrize("dt,exact", [(L.F32, 1), (L.BF16, 1), (L.BF16, 0)])
+@pytest.mark.parametrize("BN", [(3, 185), (2, 64), (1, 241), (2, 130)])
+def test_attention_fwd_bwd(dt, exact, BN):
+    """exact=1: unfused exact-f32 path (scores materialised); (bf16, exact=0): fused flash-style kernels."""
     B, N = BN
     H, D = 12, 768
     qkv = rnd(B * N, 3 * D, seed=1).to(tdt(dt))
@@ -122,8 +123,8 @@ def test_attention_fwd_bwd(dt, BN):
     scores = torch.empty(ne, dtype=torch.float32, device=DEV)
     dS = torch.empty(ne, dtype=tdt(dt), device=DEV)
     dqkv = torch.empty(B * N, 3 * D, dtype=tdt(dt), device=DEV)
-    check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(out), P(probs), P(scores), B, N, H, dt, 1, stream()))
-    check(lib.rmcl_attention_bwd(P(qkv), P(probs), P(dout), P(dqkv), P(scores), P(dS), B, N, H, dt, 1, stream()))
+    check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(out), P(probs), P(scores), B, N, H, dt, exact, stream()))
+    check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), P(dqkv), P(scores), P(dS), B, N, H, dt, exact, stream()))
     tol = 3e-5 if dt == L.F32 else 2e-2
     assert rel_err(out, o_ref) < tol
     assert rel_err(dqkv, x.grad) < tol
