@@ -389,14 +389,15 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     RMCL_TRY(rmcl_scatter_rows(dxn, w.dxn_full, B, D, 1, N, 0, 0, s));
     dy = w.dxn_full;
   }
-  RMCL_TRY(rmcl_ln_bwd(dy, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), w.dx, D, 0,
-                       full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, s));
+  void* const lp = dt != RMCL_F32 ? w.dxT : nullptr;   // bf16 copy of dx written by every LN backward
+  RMCL_TRY(rmcl_ln_bwd_lp(dy, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), w.dx, D, 0,
+                          full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, lp, s));
 
   for (int l = d->layers - 1; l >= 0; --l) {
     const LayerStash& ls = st.layer[l];
     const void* dxT = w.dx;
     // ---- MLP ----
-    if (dt != RMCL_F32) { RMCL_TRY(rmcl_cast(w.dx, w.dxT, dt, (long)M * D, s)); dxT = w.dxT; }
+    if (dt != RMCL_F32) dxT = w.dxT;
     {
       GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.fc2_w)), w.du, M, mlp, D, D, mlp, mlp);  // du = (dx W2) * gelu'(u)
       g.epi = EPI_DGELU; g.aux = ls.u; g.ld_aux = mlp; g.tag = GEMM_TAG_DX;
@@ -413,11 +414,11 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
     }
-    RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
-                         full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, s));
+    RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
+                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, lp, s));
     // ---- attention ----
     dxT = w.dx;
-    if (dt != RMCL_F32) { RMCL_TRY(rmcl_cast(w.dx, w.dxT, dt, (long)M * D, s)); dxT = w.dxT; }
+    if (dt != RMCL_F32) dxT = w.dxT;
     {
       GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);        // dao = dx Wproj
       g.tag = GEMM_TAG_DX;
@@ -437,8 +438,8 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
     }
-    RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
-                         full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, s));
+    RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, RMCL_F32, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
+                            full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, lp, s));
   }
 
   // ---- embeddings ----

@@ -198,7 +198,11 @@ static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipSt
   return 0;
 }
 
+bool rmcl_gemm_skinny_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc);
+int rmcl_launch_gemm_skinny(const GemmArgs& g, int b_kc, hipStream_t s);
+
 int rmcl_launch_gemm_exact(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc, hipStream_t s) {
+  if (g.A && g.B && g.C && g.M > 0 && g.N > 0 && rmcl_gemm_skinny_supported(g, dt_in, dt_out, a_kc)) return rmcl_launch_gemm_skinny(g, b_kc, s);
   const int V = dt_in == RMCL_F32 ? 4 : 8;
   RMCL_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "gemm: bad dims");
   RMCL_REQUIRE(g.lda % V == 0 && g.ldb % V == 0, "gemm: lda/ldb must be a multiple of the 16-byte vector width");
@@ -218,4 +222,66 @@ int rmcl_launch_gemm_exact(const GemmArgs& g, int dt_in, int dt_out, int a_kc, i
   if (dt_in == RMCL_F32 && dt_out == RMCL_BF16) return launch_layout<float, bf16_t>(g, a_kc, b_kc, grid, s);
   rmcl_set_error("gemm: unsupported dtype combination");
   return -1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Skinny exact-f32 GEMM for the heads (pooler / MoCo head / ITM): M <= 64 rows per block, K long.
+// The 128x128 kernel above would run such a problem on N/128 = 6 workgroups, latency-bound at
+// ~120 us; here every workgroup owns 64 rows x 16 columns (N/16 workgroups), each wave one 16x16
+// MFMA tile (v_mfma_f32_16x16x4_f32), operands streamed straight from L2 with 16-byte loads, no LDS.
+// k order inside a 16-wide chunk is permuted (lane group g, element j <-> k = 16c + 4g + j) on both
+// operands, so one float4 per lane feeds four MFMAs.
+// ---------------------------------------------------------------------------------------------------
+template <bool B_KC>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, gq = lane >> 4;
+  const int m = blockIdx.y * 64 + wave * 16 + (lane & 15), n = blockIdx.x * 16 + (lane & 15);
+  const float* A = reinterpret_cast<const float*>(g.A) + (long)min(m, g.M - 1) * g.lda + 4 * gq;
+  const float* B = reinterpret_cast<const float*>(g.B);
+  const int nc = min(n, g.N - 1);
+  B += B_KC ? (long)nc * g.ldb + 4 * gq : (long)(4 * gq) * g.ldb + nc;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const float4 a = *reinterpret_cast<const float4*>(A + k0);
+    float b[4];
+    if (B_KC) {
+      const float4 t = *reinterpret_cast<const float4*>(B + k0);
+      b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = B[(long)(k0 + j) * g.ldb];
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3], acc, 0, 0, 0);
+  }
+  float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = blockIdx.y * 64 + wave * 16 + 4 * gq + r;
+    if (row < g.M && n < g.N) {
+      float v = g.alpha * acc[r];
+      if (g.epi & EPI_BIAS) v += g.bias[n];
+      if (g.epi & EPI_TANH) v = tanhf(v);
+      const long ci = (long)row * g.ldc + n;
+      if (g.epi & EPI_ACCUM) v += C[ci];
+      C[ci] = v;
+    }
+  }
+}
+
+bool rmcl_gemm_skinny_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc) {
+  return a_kc && dt_in == RMCL_F32 && dt_out == RMCL_F32 && g.M <= 256 && g.K % 16 == 0 && g.K >= 256 && g.splitk <= 1 &&
+         g.nb1 * g.nb2 == 1 && (g.epi & ~(EPI_BIAS | EPI_TANH | EPI_ACCUM)) == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+         ((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0;
+}
+
+int rmcl_launch_gemm_skinny(const GemmArgs& g, int b_kc, hipStream_t s) {
+  dim3 grid(cdiv(g.N, 16), cdiv(g.M, 64));
+  if (b_kc) RMCL_LAUNCH(gemm_skinny_kernel<true>, grid, dim3(256), 0, s, g);
+  else RMCL_LAUNCH(gemm_skinny_kernel<false>, grid, dim3(256), 0, s, g);
+  RMCL_CHECK_LAUNCH();
+  return 0;
 }

@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles
       }
       if (epi & EPI_DGELU) {
         const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ld_aux + n);
-        v[0] *= gelu_erf_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_erf_grad(__uint_as_float(u.x & 0xffff0000u));
-        v[2] *= gelu_erf_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_erf_grad(__uint_as_float(u.y & 0xffff0000u));
+        v[0] *= gelu_fast_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_fast_grad(__uint_as_float(u.x & 0xffff0000u));
+        v[2] *= gelu_fast_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_fast_grad(__uint_as_float(u.y & 0xffff0000u));
       }
       const long ci = (long)m * g.ldc + n;
       if (epi & EPI_SAVE_PREACT) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles
       }
       if (epi & EPI_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
       }
       if constexpr (sizeof(TO) == 2) {
         uint2 pk;

@@ -16,6 +16,9 @@ int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float 
 int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
                 const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
                 int relu, hipStream_t s);
+int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
+                   const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
+                   int relu, void* dx_lp, hipStream_t s);
 int rmcl_softmax_fwd(const float* S, long lds, const int* mask, void* P, long ldp, int dt, int Z, int N, int H, hipStream_t s);
 int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* dS, long ldds, int dt, int Z, int N,
                      float scale, hipStream_t s);

@@ -32,6 +32,30 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
 }
 
+// Fast GELU / GELU' for the bf16 path's GEMM epilogues: erf by Abramowitz-Stegun 7.1.26
+// (|abs err| <= 1.5e-7, below bf16 and fp32-accumulation noise) - one v_exp + one v_rcp instead of
+// the ~40-instruction erff.  exp(-z^2) with z = x/sqrt(2) is exp(-x^2/2): shared by GELU and GELU'.
+// The exact-f32 parity path keeps erff.
+__device__ __forceinline__ void gelu_fast_parts(float x, float& cdf, float& pdf_e) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;                    // erf(|z|)
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));              // Phi(x)
+  pdf_e = e;                                                // exp(-x^2/2)
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float c, e;
+  gelu_fast_parts(x, c, e);
+  return x * c;
+}
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+  float c, e;
+  gelu_fast_parts(x, c, e);
+  return c + x * 0.39894228040143268f * e;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -256,3 +256,15 @@ def test_gemm_fast_epilogues_match_exact_kernel():
             a, f = (a, f) if isinstance(a, tuple) else ((a,), (f,))
             for x, y in zip(a, f):
                 assert rel_err(y, x) < (2e-5 if dto == L.F32 else 1e-2)
+
+
+def test_gemm_skinny_heads_shapes():
+    """M <= 256 fp32 problems (pooler / MoCo head) run on the skinny 64x16-tile kernel."""
+    for M, N, K in ((64, 768, 768), (64, 128, 768), (2, 768, 768), (70, 40, 256)):
+        X, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+        pre = X.double() @ W.double().t() + b.double()
+        out = gemm(X, W, M, N, K, 1, 1, L.F32, L.F32, bias=b, epi=1 | 128)
+        assert rel_err(out, torch.tanh(pre)) < 2e-5
+        base = rnd(M, N, seed=5)
+        out = gemm(X, W.t().contiguous(), M, N, K, 1, 0, L.F32, L.F32, epi=64, C_init=base)
+        assert rel_err(out, X.double() @ W.double().t() + base.double()) < 2e-5
