@@ -66,6 +66,9 @@ int rmcl_version(void);
 /* In-stream timing of one class of GEMM launches (tag mask: csrc/gemm.h GEMM_TAG_*) with hipEvents
  * recorded around each launch on the launch stream; used by bench.py for the roofline object.
  * rmcl_prof_end synchronises the recorded events and returns total ms, launches and algorithmic FLOPs. */
+/* Tuning knobs (developer use).  key 0: bf16 GEMM tile/pipeline configuration (-1 = automatic). */
+int rmcl_tune_set(int key, int value);
+
 int rmcl_prof_begin(int tag_mask, int max_launches);
 int rmcl_prof_end(double* ms_total, int64_t* launches, double* flops_total);
 
@@ -137,9 +140,24 @@ int rmcl_adamw_f32(float* p, const float* g, float* m, float* v, void* p_lp, con
                    const float* seg_lr_mult, const float* seg_wd, int nseg, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale, int64_t n, void* stream);
 
-/* ITM + word-patch alignment (objectives.py:24-76,714-787): masked cosine cost and IPOT.          */
+/* ITM + word-patch alignment (objectives.py:24-76,714-787).  cost / dsim are [B, Lt, ld] f32 with
+ * ld >= Li a multiple of 4 (GEMM operand pitch); T is [B, Li, Lt] like the reference's ipot().      */
+int rmcl_gemm_batched(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int ldc, float alpha,
+                      int nbatch, int64_t strideA, int64_t strideB, int64_t strideC, int dt_in, int dt_out, int a_kc, int b_kc,
+                      void* stream);
+int rmcl_l2norm_rows_fwd(const float* x, float* y, float* norms, int rows, int D, float eps, void* stream);   /* cost_matrix_cosine :31-32 */
+int rmcl_l2norm_rows_bwd(const float* dy, const float* y, const float* norms, float* dx, int rows, int D, void* stream);
+int rmcl_wpa_cost_finish(float* cost, const int32_t* txt_valid, const int32_t* img_valid, int B, int Lt, int Li, int ld, void* stream);
 int rmcl_ipot_f32(const float* cost, const int32_t* txt_valid, const int32_t* img_valid, float* T, int B, int Lt, int Li,
-                  float beta, int iters, void* stream);
+                  int ld, float beta, int iters, void* stream);
+/* dist[b] = trace(cost_b @ T_b) (objectives.py:761); dsim = -w[b] * T^T = d(sum_b w_b dist_b)/d(cosine sim)  */
+int rmcl_wpa_distance(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, int ld,
+                      void* stream);
+/* ITMHead + 2-class CE (heads.py:173-180, objectives.py:764-765): logits, mean loss (+=), dlogits = grad_scale*(softmax-onehot) */
+int rmcl_itm_fwd(const float* cls, const float* W, const float* bias, const int32_t* labels, float* logits, float* dlogits,
+                 float* loss_sum, int B, int D, float grad_scale, void* stream);
+int rmcl_itm_bwd(const float* dlogits, const float* cls, const float* W, float* dcls, float* dW, float* db, int B, int D,
+                 float scale, void* stream);
 
 /* ---- kernel-level entry points (unit parity tests) ----------------------------------------- */
 /* C = epilogue(alpha * op(A) op(B)); layout kinds and epilogue flags: csrc/gemm.h                 */

@@ -39,6 +39,8 @@ int rmcl_launch_gemm(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_k
   return rc;
 }
 
+void rmcl_gemm_fast_set_cfg(int cfg);
+
 namespace {
 struct HeadStash {
   float *cls_in, *pooled, *h1, *mean, *rstd, *h2r, *z, *q, *nrm;
@@ -94,6 +96,12 @@ int rmcl_prof_end(double* ms_total, int64_t* launches, double* flops_total) {
   return 0;
 }
 int rmcl_version(void) { return 1; }
+
+int rmcl_tune_set(int key, int value) {
+  if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }
+  rmcl_set_error("tune_set: unknown key");
+  return -1;
+}
 
 int64_t rmcl_heads_stash_bytes(const rmcl_dims* d) { return (int64_t)carve_heads(*d, nullptr, nullptr) + 256; }
 
@@ -230,8 +238,46 @@ int rmcl_adamw_f32(float* p, const float* g, float* m, float* v, void* p_lp, con
                     (hipStream_t)stream);
 }
 int rmcl_ipot_f32(const float* cost, const int32_t* txt_valid, const int32_t* img_valid, float* T, int B, int Lt, int Li,
-                  float beta, int iters, void* stream) {
-  return rmcl_ipot(cost, txt_valid, img_valid, T, B, Lt, Li, beta, iters, (hipStream_t)stream);
+                  int ld, float beta, int iters, void* stream) {
+  RMCL_REQUIRE(cost && txt_valid && img_valid && T, "ipot: NULL argument");
+  return rmcl_ipot(cost, txt_valid, img_valid, T, B, Lt, Li, ld, beta, iters, (hipStream_t)stream);
+}
+
+int rmcl_gemm_batched(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int ldc, float alpha,
+                      int nbatch, int64_t strideA, int64_t strideB, int64_t strideC, int dt_in, int dt_out, int a_kc, int b_kc,
+                      void* stream) {
+  RMCL_REQUIRE(A && B && C && nbatch >= 1, "gemm_batched: bad argument");
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = alpha; g.splitk = 1; g.nb1 = nbatch; g.nb2 = 1; g.sA1 = strideA; g.sB1 = strideB; g.sC1 = strideC;
+  return rmcl_launch_gemm_exact(g, dt_in, dt_out, a_kc, b_kc, (hipStream_t)stream);
+}
+int rmcl_l2norm_rows_fwd(const float* x, float* y, float* norms, int rows, int D, float eps, void* stream) {
+  RMCL_REQUIRE(x && y && norms, "l2norm_rows_fwd: NULL argument");
+  return rmcl_l2norm_fwd(x, y, norms, rows, D, eps, (hipStream_t)stream);
+}
+int rmcl_l2norm_rows_bwd(const float* dy, const float* y, const float* norms, float* dx, int rows, int D, void* stream) {
+  RMCL_REQUIRE(dy && y && norms && dx, "l2norm_rows_bwd: NULL argument");
+  return rmcl_l2norm_bwd(dy, y, norms, dx, rows, D, (hipStream_t)stream);
+}
+int rmcl_wpa_cost_finish(float* cost, const int32_t* txt_valid, const int32_t* img_valid, int B, int Lt, int Li, int ld, void* stream) {
+  RMCL_REQUIRE(cost && txt_valid && img_valid, "wpa_cost_finish: NULL argument");
+  return rmcl_cost_finish(cost, txt_valid, img_valid, B, Lt, Li, ld, (hipStream_t)stream);
+}
+int rmcl_wpa_distance(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, int ld,
+                      void* stream) {
+  RMCL_REQUIRE(cost && T && dist, "wpa_distance: NULL argument");
+  return rmcl_wpa_dist(cost, T, w, dist, dsim, B, Lt, Li, ld, (hipStream_t)stream);
+}
+int rmcl_itm_fwd(const float* cls, const float* W, const float* bias, const int32_t* labels, float* logits, float* dlogits,
+                 float* loss_sum, int B, int D, float grad_scale, void* stream) {
+  RMCL_REQUIRE(cls && W && bias && labels && logits, "itm_fwd: NULL argument");
+  return rmcl_itm_head_fwd(cls, W, bias, labels, logits, dlogits, loss_sum, B, D, grad_scale, (hipStream_t)stream);
+}
+int rmcl_itm_bwd(const float* dlogits, const float* cls, const float* W, float* dcls, float* dW, float* db, int B, int D,
+                 float scale, void* stream) {
+  RMCL_REQUIRE(dlogits && cls && W && dcls, "itm_bwd: NULL argument");
+  return rmcl_itm_head_bwd(dlogits, cls, W, dcls, dW, db, B, D, scale, (hipStream_t)stream);
 }
 
 int rmcl_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K,

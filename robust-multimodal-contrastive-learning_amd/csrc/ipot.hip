@@ -6,7 +6,7 @@
 #include "kernels.h"
 
 __global__ __launch_bounds__(256) void ipot_kernel(const float* __restrict__ cost, const int* __restrict__ txt_valid,
-                                                   const int* __restrict__ img_valid, float* __restrict__ Tout, int Lt, int Li,
+                                                   const int* __restrict__ img_valid, float* __restrict__ Tout, int Lt, int Li, int ldc,
                                                    float beta, int iters) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int ld = Lt + 1;
@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void ipot_kernel(const float* __restrict__ cos
   float* ymask = xmask + Lt;     // [Li]
   __shared__ float lens[2];
   const int b = blockIdx.x, t = threadIdx.x;
-  const float* C = cost + (long)b * Lt * Li;
+  const float* C = cost + (long)b * Lt * ldc;
   const int* tv = txt_valid + (long)b * Lt;
   const int* iv = img_valid + (long)b * Li;
   if (t == 0) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void ipot_kernel(const float* __restrict__ cos
   for (int i = t; i < Li * Lt; i += 256) {
     const int n = i / Lt, m = i % Lt;
     const bool pad = !(tv[m] && iv[n]);
-    A[n * ld + m] = pad ? 0.f : expf(-C[(long)m * Li + n] / beta);
+    A[n * ld + m] = pad ? 0.f : expf(-C[(long)m * ldc + n] / beta);
     T[n * ld + m] = pad ? 0.f : 1.f;
   }
   __syncthreads();
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void ipot_kernel(const float* __restrict__ cos
   }
 }
 
-int rmcl_ipot(const float* cost, const int* txt_valid, const int* img_valid, float* T, int B, int Lt, int Li, float beta, int iters,
-              hipStream_t s) {
+int rmcl_ipot(const float* cost, const int* txt_valid, const int* img_valid, float* T, int B, int Lt, int Li, int ld, float beta,
+              int iters, hipStream_t s) {
   const size_t lds = ((size_t)2 * Li * (Lt + 1) + 2 * Lt + 2 * Li) * sizeof(float);
   RMCL_REQUIRE(lds <= 150 * 1024, "ipot: problem too large for LDS");
   static size_t attr = 0;
@@ -72,22 +72,22 @@ int rmcl_ipot(const float* cost, const int* txt_valid, const int* img_valid, flo
     hipFuncSetAttribute(reinterpret_cast<const void*>(ipot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
-  RMCL_LAUNCH(ipot_kernel, dim3(B), dim3(256), lds, s, cost, txt_valid, img_valid, T, Lt, Li, beta, iters);
+  RMCL_LAUNCH(ipot_kernel, dim3(B), dim3(256), lds, s, cost, txt_valid, img_valid, T, Lt, Li, ld, beta, iters);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
 
 // cost[b,m,n] = masked ? 0 : 1 - dots[b,m,n]   (dots = cosine similarities, in place)
 __global__ __launch_bounds__(256) void cost_finish_kernel(float* __restrict__ cost, const int* __restrict__ txt_valid,
-                                                          const int* __restrict__ img_valid, int B, int Lt, int Li) {
+                                                          const int* __restrict__ img_valid, int B, int Lt, int Li, int ld) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)B * Lt * Li) return;
-  const int n = (int)(i % Li), m = (int)((i / Li) % Lt), b = (int)(i / ((long)Li * Lt));
-  const bool ok = txt_valid[(long)b * Lt + m] && img_valid[(long)b * Li + n];
+  if (i >= (long)B * Lt * ld) return;
+  const int n = (int)(i % ld), m = (int)((i / ld) % Lt), b = (int)(i / ((long)ld * Lt));
+  const bool ok = n < Li && txt_valid[(long)b * Lt + m] && img_valid[(long)b * Li + n];
   cost[i] = ok ? 1.0f - cost[i] : 0.f;
 }
-int rmcl_cost_finish(float* cost, const int* txt_valid, const int* img_valid, int B, int Lt, int Li, hipStream_t s) {
-  RMCL_LAUNCH(cost_finish_kernel, dim3(cdiv((long)B * Lt * Li, 256)), dim3(256), 0, s, cost, txt_valid, img_valid, B, Lt, Li);
+int rmcl_cost_finish(float* cost, const int* txt_valid, const int* img_valid, int B, int Lt, int Li, int ld, hipStream_t s) {
+  RMCL_LAUNCH(cost_finish_kernel, dim3(cdiv((long)B * Lt * ld, 256)), dim3(256), 0, s, cost, txt_valid, img_valid, B, Lt, Li, ld);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -95,23 +95,24 @@ int rmcl_cost_finish(float* cost, const int* txt_valid, const int* img_valid, in
 // dist[b] = sum_{m,n} cost[b,m,n] * T[b,n,m];  dsim[b,m,n] = -w[b] * T[b,n,m]  (d loss / d cosine-sim)
 __global__ __launch_bounds__(256) void wpa_dist_kernel(const float* __restrict__ cost, const float* __restrict__ T,
                                                        const float* __restrict__ w, float* __restrict__ dist, float* __restrict__ dsim,
-                                                       int Lt, int Li) {
+                                                       int Lt, int Li, int ld) {
   __shared__ float red[4];
   const int b = blockIdx.x, t = threadIdx.x;
   float acc = 0.f;
-  for (int i = t; i < Lt * Li; i += 256) {
-    const int m = i / Li, n = i % Li;
-    const float tv = T[(long)b * Li * Lt + (long)n * Lt + m];
-    acc += cost[(long)b * Lt * Li + i] * tv;
-    if (dsim) dsim[(long)b * Lt * Li + i] = -w[b] * tv;
+  for (int i = t; i < Lt * ld; i += 256) {
+    const int m = i / ld, n = i % ld;
+    const float tv = n < Li ? T[(long)b * Li * Lt + (long)n * Lt + m] : 0.f;
+    acc += cost[(long)b * Lt * ld + i] * tv;
+    if (dsim) dsim[(long)b * Lt * ld + i] = -w[b] * tv;
   }
   acc = wave_sum(acc);
   if ((t & 63) == 0) red[t >> 6] = acc;
   __syncthreads();
   if (t == 0) dist[b] = red[0] + red[1] + red[2] + red[3];
 }
-int rmcl_wpa_dist(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, hipStream_t s) {
-  RMCL_LAUNCH(wpa_dist_kernel, dim3(B), dim3(256), 0, s, cost, T, w, dist, dsim, Lt, Li);
+int rmcl_wpa_dist(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, int ld,
+                  hipStream_t s) {
+  RMCL_LAUNCH(wpa_dist_kernel, dim3(B), dim3(256), 0, s, cost, T, w, dist, dsim, Lt, Li, ld);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

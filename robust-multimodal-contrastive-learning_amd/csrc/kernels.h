@@ -57,7 +57,13 @@ long rmcl_infonce_workspace_bytes(int B, long Kq);
 int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int Pd, long Kq, float T, float gscale, float* dq,
                  float* rows_out, float* loss_sum, void* workspace, hipStream_t s);
 
-int rmcl_cost_finish(float* cost, const int* txt_valid, const int* img_valid, int B, int Lt, int Li, hipStream_t s);
-int rmcl_wpa_dist(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, hipStream_t s);
-int rmcl_ipot(const float* cost, const int* txt_valid, const int* img_valid, float* T, int B, int Lt, int Li, float beta,
+int rmcl_cost_finish(float* cost, const int* txt_valid, const int* img_valid, int B, int Lt, int Li, int ld, hipStream_t s);
+int rmcl_wpa_dist(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, int ld,
+                  hipStream_t s);
+int rmcl_ipot(const float* cost, const int* txt_valid, const int* img_valid, float* T, int B, int Lt, int Li, int ld, float beta,
               int iters, hipStream_t s);
+
+int rmcl_itm_head_fwd(const float* cls, const float* W, const float* bias, const int* labels, float* logits, float* dlogits,
+                      float* loss_sum, int B, int D, float gscale, hipStream_t s);
+int rmcl_itm_head_bwd(const float* dl, const float* cls, const float* W, float* dcls, float* dW, float* db, int B, int D, float scale,
+                      hipStream_t s);

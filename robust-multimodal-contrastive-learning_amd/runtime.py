@@ -136,17 +136,19 @@ class Engine:
         self.q_lp = z(lay.total, torch.bfloat16) if self.dtype == L.BF16 else None
         self.k_lp = z(lay.ema_end, torch.bfloat16) if self.dtype == L.BF16 else None
         self.specs = param_specs(cfg, lay)
-        self._bufs: Dict[int, PassBuffers] = {}
+        self._bufs: Dict[tuple, PassBuffers] = {}
         self.lp_stale = True
 
     # ---- geometry ------------------------------------------------------------------------------
     def dims(self, B: int) -> L.Dims:
         return make_dims(self.cfg, B, self.dtype, getattr(self, "exact", False))
 
-    def bufs(self, B: int) -> PassBuffers:
-        if B not in self._bufs:
-            self._bufs[B] = PassBuffers(self, B)
-        return self._bufs[B]
+    def bufs(self, B: int, tag: str = "moco") -> PassBuffers:
+        """Per-(batch size, objective) buffers: each objective keeps its own FULL stash so that several
+        task losses of one training_step can be backpropagated after all forwards have run."""
+        if (B, tag) not in self._bufs:
+            self._bufs[(B, tag)] = PassBuffers(self, B)
+        return self._bufs[(B, tag)]
 
     def view(self, arena: torch.Tensor, off: int, shape) -> torch.Tensor:
         n = 1
@@ -170,7 +172,7 @@ class Engine:
         self.g32.zero_()
 
     # ---- per-step data -------------------------------------------------------------------------
-    def bind_batch(self, text_ids: torch.Tensor, text_mask: torch.Tensor, image: torch.Tensor) -> PassBuffers:
+    def bind_batch(self, text_ids: torch.Tensor, text_mask: torch.Tensor, image: torch.Tensor, tag: str = "moco") -> PassBuffers:
         B, Cc, Hh, Ww = image.shape
         ps = self.cfg["patch_size"]
         g = self.cfg["image_size"] // ps
@@ -178,7 +180,7 @@ class Engine:
             raise NotImplementedError(
                 f"dense visual_embed path needs {g * ps}x{g * ps} images (got {Hh}x{Ww}); the ragged "
                 "select/pad path of vision_transformer.py:605-651 is not built yet")
-        pb = self.bufs(B)
+        pb = self.bufs(B, tag)
         pb.text_ids = text_ids.to(self.device, torch.int64).contiguous()
         pb.text_mask = text_mask.to(self.device, torch.int64).contiguous()
         img = image.to(self.device, torch.float32).contiguous()

@@ -41,6 +41,96 @@ def compute_pgd(pl_module, batch, loss_name, k_modality=None):
     return batch
 
 
+def compute_itm_wpa(pl_module, batch):
+    """objectives.compute_itm_wpa (:714-787): ITM head + CE, and the word-patch-alignment OT distance
+    (cosine cost :24-34, IPOT :46-76 with beta=0.5 / 50 iterations, trace :37-43)."""
+    import ctypes as C
+    from ..._lib import F
+    eng = pl_module.engine
+    dev = eng.device
+    Bn = len(batch["text"])
+    pos_len = Bn // 2
+    itm_labels = torch.cat([torch.ones(pos_len), torch.zeros(Bn - pos_len)]).to(dev)
+    forced = getattr(pl_module, "itm_labels_override", None)            # test hook: fix the 50/50 draw
+    itm_labels = forced.to(dev).float() if forced is not None else itm_labels[torch.randperm(Bn, device=dev)]
+    img, fimg = batch["image"][0].to(dev), batch["false_image_0"][0].to(dev)
+    images = torch.where(itm_labels.view(-1, 1, 1, 1) == 1, img, fimg)                 # :722-730
+
+    pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], images, tag="itm")
+    d = pb.d
+    Lt, Li, D = d.L, d.P + 1, d.D
+    N = Lt + Li
+    need_grad = torch.is_grad_enabled() and pl_module.training
+    op = eng.make_operand(pb, out=pb.patchesT_full)
+    eng.encoder_forward(pb, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op)
+    eng.heads_forward(pb, key=False, want_q=False)
+    st = stream_ptr()
+    lay = eng.layout
+
+    labels_i = itm_labels.to(torch.int32)
+    logits = torch.empty(Bn, 2, device=dev)
+    dlogits = torch.empty(Bn, 2, device=dev)
+    losses = torch.zeros(2, device=dev)
+    w_itm, b_itm = eng.q32[lay.itm_w:lay.itm_w + 2 * D], eng.q32[lay.itm_b:lay.itm_b + 2]
+    check(lib.rmcl_itm_fwd(P(pb.cls), P(w_itm), P(b_itm), P(labels_i), P(logits), P(dlogits), P(losses), Bn, D, F(1.0 / Bn), st), "itm_fwd")
+
+    # masks (:739-745): drop [CLS], the last valid text token and the image cls slot
+    txt_mask = pb.text_mask.bool().clone()
+    lens = txt_mask.sum(dim=1)
+    txt_mask[torch.arange(Bn, device=dev), lens - 1] = False
+    txt_mask[:, 0] = False
+    img_mask = pb.co_mask[:, Lt:].bool().clone()
+    img_mask[:, 0] = False
+    txt_valid, img_valid = txt_mask.to(torch.int32).contiguous(), img_mask.to(torch.int32).contiguous()
+
+    ld = (Li + 3) // 4 * 4
+    M = Bn * N
+    xhat, norms = torch.empty(M, D, device=dev), torch.empty(M, device=dev)
+    check(lib.rmcl_l2norm_rows_fwd(P(pb.xn), P(xhat), P(norms), M, D, F(1e-5), st), "l2norm")
+    cost = torch.zeros(Bn, Lt, ld, device=dev)
+    img_rows = xhat[Lt:]                                                   # first image row of sample 0
+    check(lib.rmcl_gemm_batched(P(xhat), P(img_rows), P(cost), Lt, Li, D, I64(D), I64(D), ld, F(1.0), Bn, I64(N * D), I64(N * D),
+                                I64(Lt * ld), L.F32, L.F32, 1, 1, st), "cosine sim")
+    check(lib.rmcl_wpa_cost_finish(P(cost), P(txt_valid), P(img_valid), Bn, Lt, Li, ld, st), "cost_finish")
+    T = torch.empty(Bn, Li, Lt, device=dev)
+    check(lib.rmcl_ipot_f32(P(cost), P(txt_valid), P(img_valid), P(T), Bn, Lt, Li, ld, F(0.5), 50, st), "ipot")
+    w = (itm_labels * 2 - 1) * (0.1 / Bn)                                  # 0.1 * (sum_pos - sum_neg) / B  (:763-765,771)
+    dist = torch.empty(Bn, device=dev)
+    dsim = torch.empty(Bn, Lt, ld, device=dev) if need_grad else None
+    check(lib.rmcl_wpa_distance(P(cost), P(T), P(w), P(dist), P(dsim), Bn, Lt, Li, ld, st), "wpa_distance")
+    losses[1] = (dist * w).sum()
+    value = losses.clone()
+
+    if need_grad:
+        def backward(grad_out, pb=pb, dlogits=dlogits, dsim=dsim, xhat=xhat, norms=norms, op=op):
+            st2 = stream_ptr()
+            g = grad_out.to(torch.float32)
+            dl = dlogits * g[0]
+            dcls_itm = torch.empty(Bn, D, device=dev)
+            gw, gb = eng.g32[lay.itm_w:lay.itm_w + 2 * D], eng.g32[lay.itm_b:lay.itm_b + 2]
+            check(lib.rmcl_itm_bwd(P(dl), P(pb.cls), P(w_itm), P(dcls_itm), P(gw), P(gb), Bn, D, F(1.0), st2), "itm_bwd")
+            eng.heads_backward(pb, None, dcls_itm, with_grads=True)
+            ds = dsim * g[1]
+            dxhat = torch.zeros(M, D, device=dev)
+            check(lib.rmcl_gemm_batched(P(ds), P(xhat[Lt:]), P(dxhat), Lt, D, Li, I64(ld), I64(D), D, F(1.0), Bn, I64(Lt * ld),
+                                        I64(N * D), I64(N * D), L.F32, L.F32, 1, 0, st2), "d txt")
+            check(lib.rmcl_gemm_batched(P(ds), P(xhat), P(dxhat[Lt:]), Li, D, Lt, I64(ld), I64(D), D, F(1.0), Bn, I64(Lt * ld),
+                                        I64(N * D), I64(N * D), L.F32, L.F32, 0, 0, st2), "d img")
+            dxn = torch.empty(M, D, device=dev)
+            check(lib.rmcl_l2norm_rows_bwd(P(dxhat), P(xhat), P(norms), P(dxn), M, D, st2), "l2norm_bwd")
+            dxn.view(Bn, N, D)[:, 0] += pb.dcls
+            eng.encoder_backward(pb, L.MODE_FULL, op, dxn, cls_only=False, dpatches=None)
+            pl_module.after_backward()
+
+        value = _DeferredBackward.apply(pl_module.grad_anchor, value, backward)
+    ret = {"itm_loss": value[0], "itm_wpa_loss": value[1], "itm_logits": logits, "itm_labels": itm_labels}
+    phase = "train" if pl_module.training else "val"
+    pl_module.log(f"itm/{phase}/loss", ret["itm_loss"].detach())
+    pl_module.log(f"itm/{phase}/wpa_loss", ret["itm_wpa_loss"].detach())
+    pl_module.log(f"itm/{phase}/accuracy", (logits.argmax(-1) == itm_labels.long()).float().mean())
+    return ret
+
+
 def compute_moco_contrastive(pl_module, batch):
     """objectives.py:217-447 (image view).  Returns {"moco_loss", pos_/neg_{dist,cosine,dot}_attacked_img}."""
     eng = pl_module.engine

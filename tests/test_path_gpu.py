@@ -164,3 +164,31 @@ def test_full_size_properties_bs64():
     k_before = m.engine.k32.clone()
     m.engine.ema(0.999)
     assert float((m.engine.k32 - k_before).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["L2_B4_ragged", "L12_B2"])
+def test_itm_wpa_matches_reference_golden(tag):
+    """BASELINE configs[0]/[1] objective: ITM head + word-patch alignment (IPOT) against the reference."""
+    g = load(f"itm_{tag}.npz")
+    ocfg, B, sw, sb, ragged = cfg_from_meta(O, g["meta"], kind="itm")
+    cfg = task_moco(num_layers=ocfg["num_layers"], num_negative=1024, per_gpu_batchsize=B, drop_rate=0.0, num_gpus=1, num_nodes=1)
+    cfg["loss_names"] = dict(cfg["loss_names"], moco=0, itm=1)
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype="f32")
+    p = O.init_params(ocfg, sw)
+    m.load_state_dict({n: t.to(DEV) for n, t in p.items() if not n.startswith("k_") and not n.startswith("moco_head")}, strict=False)
+    m.train()
+    m.itm_labels_override = torch.from_numpy(g["itm_labels"])
+    batch = dev_batch(O.synthetic_batch(ocfg, B, sb, ragged_text=ragged))
+    m.zero_grad()
+    loss = m.training_step(batch, 0)                                   # itm_loss + itm_wpa_loss (vilt_module.py:475)
+    assert abs(float(loss) - (float(g["itm_loss"]) + float(g["itm_wpa_loss"]))) < 1e-4
+    np.testing.assert_allclose(m.logged["itm/train/loss"].item(), float(g["itm_loss"]), atol=1e-4)
+    np.testing.assert_allclose(m.logged["itm/train/wpa_loss"].item(), float(g["itm_wpa_loss"]), atol=2e-5)
+    loss.backward()
+    params = dict(m.named_parameters())
+    for name, dg in zip(g["grad_names"], g["grad_digest"]):
+        if str(name) not in params:
+            continue
+        mine = digest(params[str(name)].grad)
+        assert abs(mine[1] - dg[1]) <= 5e-3 * max(dg[1], 1e-6) + 1e-7, (name, mine[1], dg[1])
+        np.testing.assert_allclose(mine[3:], dg[3:], atol=5e-3 * dg[2] + 1e-7, err_msg=str(name))

@@ -33,6 +33,11 @@ if __name__ == "__main__":
               ("qkv dX NN", M, 768, 2304, 1, 0, L.F32, 0), ("proj dX NN", M, 768, 768, 1, 0, L.BF16, 0),
               ("fc1 dW TN", 3072, 768, M, 0, 0, L.F32, 64), ("fc2 dW TN", 768, 3072, M, 0, 0, L.F32, 64),
               ("qkv dW TN", 2304, 768, M, 0, 0, L.F32, 64), ("proj dW TN", 768, 768, M, 0, 0, L.F32, 64)]
+    cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
     for name, m, n, k, akc, bkc, dto, epi in shapes:
-        ms, tf = bench(m, n, k, akc, bkc, dto, epi)
-        print(f"{name:14s} M={m:6d} N={n:5d} K={k:6d}  {ms*1e3:8.1f} us  {tf:8.1f} TFLOP/s", flush=True)
+        line = f"{name:14s} M={m:6d} N={n:5d} K={k:6d} "
+        for c in cfgs:
+            lib.rmcl_tune_set(0, c)
+            ms, tf = bench(m, n, k, akc, bkc, dto, epi)
+            line += f" | cfg{c}: {ms*1e3:7.1f} us {tf:7.1f} TF"
+        print(line, flush=True)
