@@ -1,0 +1,69 @@
+"""CPU, world_size 2 over gloo: the multi-GPU host logic of the RMCL step (rmcl_amd.vilt.modules.dist_utils):
+rank-major key all-gather feeding the enqueue, the reference's skip rule, queue pointer bookkeeping, and
+gradient averaging over the flat arena.  On MI355X the same code runs with backend "nccl" (RCCL over xGMI)."""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import rmcl_pkg  # noqa: F401
+from oracle import rmcl_oracle as O
+
+
+def _worker(rank, world, initfile, out_dir):
+    import rmcl_pkg  # noqa: F401
+    from rmcl_amd.vilt.modules import dist_utils
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    try:
+        B, Pd, Kq = 4, 128, 64
+        g = torch.Generator().manual_seed(100 + rank)
+        k = torch.nn.functional.normalize(torch.randn(B, Pd, generator=g), dim=1)
+        gather = dist_utils.KeyGather(k)                       # async; other work would overlap here
+        filler = torch.randn(64, 64) @ torch.randn(64, 64)     # stands in for the PGD loop
+        keys_all = gather.wait()
+        assert keys_all.shape == (world * B, Pd) and filler is not None
+        assert torch.equal(keys_all[rank * B:(rank + 1) * B], k)            # rank-major like torch.cat(tensors_gather)
+        # enqueue bookkeeping: every rank applies the same block -> queues stay bit-identical
+        queue = torch.zeros(Pd, Kq)
+        ptr = 0
+        for step in range(3):
+            do, new_ptr = dist_utils.queue_advance(ptr, keys_all.shape[0], Kq, per_step_bs=world * B)
+            assert do
+            ptr = O.enqueue(queue, ptr, keys_all, world * B)                # oracle = reference semantics
+            assert ptr == new_ptr
+        assert ptr == (3 * world * B) % Kq
+        do, same = dist_utils.queue_advance(ptr, keys_all.shape[0], Kq, per_step_bs=world * B + 1)   # skip rule (:242-243)
+        assert not do and same == ptr
+        # flat-arena gradient averaging in buckets
+        grads = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        dist_utils.allreduce_mean_(grads, bucket_elems=256)
+        expect = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        assert torch.allclose(grads, expect)
+        torch.save({"queue": queue, "keys": keys_all}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_enqueue_allreduce():
+    with tempfile.TemporaryDirectory() as d:
+        initfile = os.path.join(d, "init")
+        mp.spawn(_worker, args=(2, initfile, d), nprocs=2, join=True)
+        a, b = torch.load(os.path.join(d, "r0.pt")), torch.load(os.path.join(d, "r1.pt"))
+        assert torch.equal(a["queue"], b["queue"]) and torch.equal(a["keys"], b["keys"])
+
+
+def test_queue_advance_rejects_wraparound():
+    from rmcl_amd.vilt.modules import dist_utils
+    with pytest.raises(RuntimeError):
+        dist_utils.queue_advance(60, 8, 64, per_step_bs=8)
+    assert dist_utils.queue_advance(56, 8, 64, per_step_bs=8) == (True, 0)
+
+
+def test_single_process_is_a_no_op():
+    from rmcl_amd.vilt.modules import dist_utils
+    k = torch.randn(3, 128)
+    assert dist_utils.KeyGather(k).wait() is k
+    assert dist_utils.allreduce_mean_(torch.ones(4)) == []
