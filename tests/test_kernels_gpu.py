@@ -222,11 +222,13 @@ def test_im2patch_roundtrip():
 
 
 # ------------------------------------------------------------------ bf16 MFMA GEMM (fast path)
+@pytest.mark.parametrize("cfg", [-1, 1])
 @pytest.mark.parametrize("shape", [(11840, 768, 768), (300, 128, 64), (1000, 3072, 768), (256, 768, 3072)])
-def test_gemm_fast_bf16_layouts(shape):
+def test_gemm_fast_bf16_layouts(shape, cfg):
     """exact=0 routes to the glds/tr-read MFMA kernel; reference = fp64 matmul of the same bf16 inputs,
     tolerance = fp32 accumulation-order noise only (products of bf16 are exact in fp32)."""
     M, N, K = shape
+    lib.rmcl_tune_set(0, cfg)                                                      # persistent grid: default 2 workgroups per CU, or 1
     X = rnd(M, K, seed=1).to(torch.bfloat16)
     W = rnd(N, K, seed=2, scale=0.05).to(torch.bfloat16)
     ref = X.double() @ W.double().t()
@@ -242,6 +244,7 @@ def test_gemm_fast_bf16_layouts(shape):
         base = rnd(M, N, seed=7)
         out = gemm(Xt, Wn, M, N, K, 0, 0, L.BF16, L.F32, exact=0, epi=64, C_init=base)   # TN + accumulate
         assert rel_err(out, ref + base.double()) < 2e-5
+    lib.rmcl_tune_set(0, -1)
 
 
 def test_gemm_fast_epilogues_match_exact_kernel():
