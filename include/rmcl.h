@@ -69,6 +69,10 @@ int rmcl_version(void);
 /* Tuning knobs (developer use).  key 0: bf16 GEMM tile/pipeline configuration (-1 = automatic). */
 int rmcl_tune_set(int key, int value);
 
+/* Optional second HIP stream: the weight-gradient GEMMs of rmcl_encoder_backward (mode FULL, bf16) then run
+ * concurrently with the data-gradient chain, fork/joined with events on `stream`.  NULL disables it.     */
+int rmcl_set_side_stream(void* stream);
+
 int rmcl_prof_begin(int tag_mask, int max_launches);
 int rmcl_prof_end(double* ms_total, int64_t* launches, double* flops_total);
 

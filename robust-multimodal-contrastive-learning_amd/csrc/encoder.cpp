@@ -49,6 +49,7 @@ struct Work {
   // backward
   float *dx, *dln, *dxn_full, *de;
   void *dxT, *du, *dqkv, *dao, *dS, *dpe;
+  void *dxT2, *du2, *dqkv2;   // second copies: weight-gradient GEMMs read them on the side stream
   float* slab;        // split-K partial slabs of the weight-gradient GEMMs
 };
 
@@ -117,6 +118,9 @@ size_t carve_work(const rmcl_dims& d, void* base, Work* w) {
   k.dS = b.take_bytes(zn * e);
   k.dpe = b.take_bytes((size_t)d.B * d.P * D * e);
   k.slab = b.take<float>(SLAB_FLOATS(d));
+  k.dxT2 = b.take_bytes(M * D * e);
+  k.du2 = b.take_bytes(M * d.mlp * e);
+  k.dqkv2 = b.take_bytes(M * 3 * D * e);
   if (w) *w = k;
   return b.off;
 }
@@ -188,7 +192,23 @@ int gemm_dw(const Ctx& c, const void* dY, long lddy, const void* X, long ldx, fl
   return gemm(c, g, dt_in, RMCL_F32, 0, 0);
 }
 
+// ---- side stream for the weight-gradient GEMMs (fills the tile-quantisation tails of the dX chain) ----
+hipStream_t g_side = nullptr;
+hipEvent_t g_ev[128];
+int g_nev = 0;
+int ensure_events() {
+  while (g_nev < 128) {
+    hipError_t e = hipEventCreateWithFlags(&g_ev[g_nev], hipEventDisableTiming);
+    if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+    ++g_nev;
+  }
+  return 0;
+}
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rmcl_set_error(hipGetErrorString(_e)); return (int)_e; } } while (0)
+
 }  // namespace
+
+extern "C" int rmcl_set_side_stream(void* stream) { g_side = (hipStream_t)stream; return 0; }
 
 int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* probs, float* scores, int B, int N, int H, int dt,
                             int exact, hipStream_t s) {
@@ -389,58 +409,78 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     RMCL_TRY(rmcl_scatter_rows(dxn, w.dxn_full, B, D, 1, N, 0, 0, s));
     dy = w.dxn_full;
   }
-  void* const lp = dt != RMCL_F32 ? w.dxT : nullptr;   // bf16 copy of dx written by every LN backward
+  // bf16 copy of dx written by every LN backward (ping-pong T[0]/T[1]); with a side stream the weight
+  // gradients of layer l run concurrently with the data-gradient chain, reading the copy the chain no
+  // longer writes (events order the reuse of T / du / dqkv two sub-layers later).
+  const bool lpm = dt != RMCL_F32;
+  const bool use_side = full && lpm && g_side != nullptr;
+  if (use_side) RMCL_TRY(ensure_events());
+  void* T[2] = {lpm ? w.dxT : nullptr, lpm ? (use_side ? w.dxT2 : w.dxT) : nullptr};
+  void* DU[2] = {w.du, use_side ? w.du2 : w.du};
+  void* DQ[2] = {w.dqkv, use_side ? w.dqkv2 : w.dqkv};
+  Ctx cs{c.d, c.P32, c.Plp, c.lay, use_side ? g_side : c.s, c.dt};
+  auto EV = [&](int kind, int l) { return g_ev[(kind * 32 + (l & 31)) & 127]; };   // kind 0: fork, 1: done1, 2: done2
+  int cur = 0;
   RMCL_TRY(rmcl_ln_bwd_lp(dy, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), w.dx, D, 0,
-                          full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, lp, s));
-
-  for (int l = d->layers - 1; l >= 0; --l) {
+                          full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, T[0], s));
+  const int Lr = d->layers;
+  for (int l = Lr - 1; l >= 0; --l) {
     const LayerStash& ls = st.layer[l];
-    const void* dxT = w.dx;
+    void* du = DU[l & 1];
+    void* dqkv = DQ[l & 1];
     // ---- MLP ----
-    if (dt != RMCL_F32) dxT = w.dxT;
+    const void* dxT = lpm ? T[cur] : (const void*)w.dx;
+    if (use_side && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(1, l + 2), 0));          // du buffer free again
     {
-      GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.fc2_w)), w.du, M, mlp, D, D, mlp, mlp);  // du = (dx W2) * gelu'(u)
+      GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.fc2_w)), du, M, mlp, D, D, mlp, mlp);       // du = (dx W2) * gelu'(u)
       g.epi = EPI_DGELU; g.aux = ls.u; g.ld_aux = mlp; g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
     }
     if (full) {
-      RMCL_TRY(gemm_dw(c, dxT, D, ls.h, mlp, Gp(c.L(l, y.fc2_w)), D, mlp, M, dt, w.slab, SLAB_FLOATS(*d)));
-      RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.fc2_b)), M, D, s));
-      RMCL_TRY(gemm_dw(c, w.du, mlp, ls.ln2, D, Gp(c.L(l, y.fc1_w)), mlp, D, M, dt, w.slab, SLAB_FLOATS(*d)));
-      RMCL_TRY(rmcl_colsum(w.du, mlp, dt, Gp(c.L(l, y.fc1_b)), M, mlp, s));
+      if (use_side) { HIP_TRY(hipEventRecord(EV(0, 2 * l), s)); HIP_TRY(hipStreamWaitEvent(cs.s, EV(0, 2 * l), 0)); }
+      RMCL_TRY(gemm_dw(cs, dxT, D, ls.h, mlp, Gp(c.L(l, y.fc2_w)), D, mlp, M, dt, w.slab, SLAB_FLOATS(*d)));
+      RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.fc2_b)), M, D, cs.s));
+      RMCL_TRY(gemm_dw(cs, du, mlp, ls.ln2, D, Gp(c.L(l, y.fc1_w)), mlp, D, M, dt, w.slab, SLAB_FLOATS(*d)));
+      RMCL_TRY(rmcl_colsum(du, mlp, dt, Gp(c.L(l, y.fc1_b)), M, mlp, cs.s));
+      if (use_side) HIP_TRY(hipEventRecord(EV(1, l), cs.s));
     }
     {
-      GemmArgs g = gemm_args(w.du, c.W(c.L(l, y.fc1_w)), w.dln, M, D, mlp, mlp, D, D);   // dln2 = du W1
+      GemmArgs g = gemm_args(du, c.W(c.L(l, y.fc1_w)), w.dln, M, D, mlp, mlp, D, D);        // dln2 = du W1
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
     }
+    if (use_side && l + 1 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 1), 0));           // T[cur^1] free again
     RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
-                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, lp, s));
+                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, T[cur ^ 1], s));
+    cur ^= 1;
     // ---- attention ----
-    dxT = w.dx;
-    if (dt != RMCL_F32) dxT = w.dxT;
+    dxT = lpm ? T[cur] : (const void*)w.dx;
     {
-      GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);        // dao = dx Wproj
+      GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);          // dao = dx Wproj
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
     }
+    if (use_side && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 2), 0));           // dqkv buffer free again
+    RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, co_mask, ls.probs, w.dao, dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
     if (full) {
-      RMCL_TRY(gemm_dw(c, dxT, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
-      RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.proj_b)), M, D, s));
-    }
-    RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, co_mask, ls.probs, w.dao, w.dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
-    if (full) {
-      RMCL_TRY(gemm_dw(c, w.dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
-      RMCL_TRY(rmcl_colsum(w.dqkv, 3 * D, dt, Gp(c.L(l, y.qkv_b)), M, 3 * D, s));
+      if (use_side) { HIP_TRY(hipEventRecord(EV(0, 2 * l + 1), s)); HIP_TRY(hipStreamWaitEvent(cs.s, EV(0, 2 * l + 1), 0)); }
+      RMCL_TRY(gemm_dw(cs, dxT, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
+      RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.proj_b)), M, D, cs.s));
+      RMCL_TRY(gemm_dw(cs, dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
+      RMCL_TRY(rmcl_colsum(dqkv, 3 * D, dt, Gp(c.L(l, y.qkv_b)), M, 3 * D, cs.s));
+      if (use_side) HIP_TRY(hipEventRecord(EV(2, l), cs.s));
     }
     {
-      GemmArgs g = gemm_args(w.dqkv, c.W(c.L(l, y.qkv_w)), w.dln, M, D, 3 * D, 3 * D, D, D);  // dln1 = dqkv Wqkv
+      GemmArgs g = gemm_args(dqkv, c.W(c.L(l, y.qkv_w)), w.dln, M, D, 3 * D, 3 * D, D, D);  // dln1 = dqkv Wqkv
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
     }
+    if (use_side) HIP_TRY(hipStreamWaitEvent(s, EV(1, l), 0));                             // T[cur^1] free again
     RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, RMCL_F32, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
-                            full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, lp, s));
+                            full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, T[cur ^ 1], s));
+    cur ^= 1;
   }
+  if (use_side) HIP_TRY(hipStreamWaitEvent(s, EV(2, 0), 0));                               // join: all side work done
 
   // ---- embeddings ----
   RMCL_TRY(rmcl_image_assemble_bwd(w.dx, w.dpe, dt, full ? Gp(y.pos_img) : nullptr, full ? Gp(y.cls) : nullptr,

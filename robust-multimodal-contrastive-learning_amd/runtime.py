@@ -138,6 +138,9 @@ class Engine:
         self.specs = param_specs(cfg, lay)
         self._bufs: Dict[tuple, PassBuffers] = {}
         self.lp_stale = True
+        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.dw_stream = torch.cuda.Stream(device=self.device)
+        lib.rmcl_set_side_stream(C.c_void_p(self.dw_stream.cuda_stream))
 
     # ---- geometry ------------------------------------------------------------------------------
     def dims(self, B: int) -> L.Dims:

@@ -148,13 +148,22 @@ def compute_moco_contrastive(pl_module, batch):
     B = pb.B
 
     op = eng.make_operand(pb)
-    eng.encoder_forward(pb, key=True, mode=L.MODE_INFER, patchesT=op)      # infer_k under no_grad (:262-265)
-    eng.heads_forward(pb, key=True)
+    # The momentum-encoder forward (infer_k under no_grad, :262-265) and the clean query forward (:267-275)
+    # are independent: they run on two HIP streams so each fills the other's tile-quantisation tails.
+    pk = eng.bufs(B, "key")
+    pk.text_ids, pk.text_mask = pb.text_ids, pb.text_mask
+    main = torch.cuda.current_stream()
+    side = eng.side_stream
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op)
+        eng.heads_forward(pk, key=True)
+    eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)     # clean query
+    eng.heads_forward(pb, key=False)
+    main.wait_stream(side)
+    pb.k.copy_(pk.k)
     k = pb.k
     gather = dist_utils.KeyGather(k.clone()) if pl_module.training else None   # overlaps everything below
-
-    eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)     # clean query (:267-275)
-    eng.heads_forward(pb, key=False)
     eng.infonce(pb, 0.0, want_dq=False)
     prediction_original = pb.rows[:, 1].clone()
     ret["q_original"] = pb.q.clone()

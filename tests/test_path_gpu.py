@@ -192,3 +192,32 @@ def test_itm_wpa_matches_reference_golden(tag):
         mine = digest(params[str(name)].grad)
         assert abs(mine[1] - dg[1]) <= 5e-3 * max(dg[1], 1e-6) + 1e-7, (name, mine[1], dg[1])
         np.testing.assert_allclose(mine[3:], dg[3:], atol=5e-3 * dg[2] + 1e-7, err_msg=str(name))
+
+
+def test_side_stream_weight_gradients_are_race_free():
+    """The weight-gradient GEMMs run on a second stream behind events; the split-K slab reduce is ordered,
+    so weight-matrix gradients must be BITWISE equal with and without the side stream."""
+    import ctypes as C
+    from rmcl_amd._lib import lib
+    ocfg = O.default_config(num_layers=3, num_negative=1024, per_gpu_batchsize=64, adv_steps_img=1)
+    m, p = build_module(ocfg, 5, "bf16")
+    batch = dev_batch(O.synthetic_batch(ocfg, 64, 9))
+    grads = []
+    for side in (True, False):
+        lib.rmcl_set_side_stream(C.c_void_p(m.engine.dw_stream.cuda_stream if side else 0))
+        m.zero_grad()
+        m.queue_ptr = 0
+        m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+        m.shadow_momentum_encoder()
+        loss = m.training_step(batch, 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append(m.engine.g32.clone())
+    lib.rmcl_set_side_stream(C.c_void_p(m.engine.dw_stream.cuda_stream))
+    lay = m.engine.layout
+    for l in range(3):
+        base = lay.layer0 + l * lay.layer_stride
+        for off, n in ((lay.qkv_w, 3 * 768 * 768), (lay.proj_w, 768 * 768), (lay.fc1_w, 3072 * 768), (lay.fc2_w, 3072 * 768)):
+            a, b = grads[0][base + off: base + off + n], grads[1][base + off: base + off + n]
+            assert torch.equal(a, b), (l, off)
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-4 * float(grads[1].abs().max())    # bias grads use float atomics
