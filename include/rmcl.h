@@ -101,12 +101,14 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 
 /* Backward of the above.  dxn: gradient wrt xn, [B*N,D] f32, or [B,D] (row 0 of every sample)
  * when cls_only=1.  dpatches (optional) receives d loss/d patches [B*P,patch_k] in `dtype`
- * (the PGD data gradient, attack/pgd_attack_vilt.py:160-162).  grads32 (mode FULL): gradient
+ * (the PGD data gradient, attack/pgd_attack_vilt.py:160-162).  dtext (optional) receives d loss/d
+ * word-embedding output [B*L, D] f32 (the text-attack saliency, greedy_attack_vilt.py:414-452).
+ * grads32 (mode FULL): gradient
  * arena, accumulated into (+=), same layout as the parameter arena.                              */
 int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
                           const int64_t* text_ids, const void* patches, const int32_t* co_mask,
                           void* stash, void* workspace, const float* dxn, int cls_only,
-                          void* dpatches, float* grads32, void* stream);
+                          void* dpatches, float* dtext, float* grads32, void* stream);
 
 /* Pooler + MoCo head + L2 normalise (vilt/modules/heads.py:10-20,129-143; objectives.py:264-269).
  * pool32: arena that owns the pooler (always the query arena); head32: arena that owns the

@@ -38,7 +38,7 @@ def default_config(**over) -> dict:
         num_negative=65536, momentum=0.999, temperature=0.07,
         text_view=False, image_view=True, augmentation=False,
         adv_steps_img=3, adv_lr_img=0.05, adv_max_norm_img=0.005,
-        num_gpus=1, num_nodes=1, per_gpu_batchsize=64, proj_dim=128,
+        num_gpus=1, num_nodes=1, per_gpu_batchsize=64, proj_dim=128, n_candidates=5, max_loops=10, seed=0,
         loss_names={"moco": 1, "itm": 0},
     )
     cfg.update(over)
@@ -165,10 +165,11 @@ def gelu_erf(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def text_embed(p: Params, pre: str, ids: Tensor) -> Tensor:
+def text_embed(p: Params, pre: str, ids: Tensor, word_embeds: Optional[Tensor] = None) -> Tensor:
     """HF BertEmbeddings (vilt_module.py:26-38,293): LN_{1e-12}(word[id] + type[0] + pos[0:L])."""
     L = ids.shape[1]
-    e = (p[pre + "text_embeddings.word_embeddings.weight"][ids]
+    we = p[pre + "text_embeddings.word_embeddings.weight"][ids] if word_embeds is None else word_embeds
+    e = (we
          + p[pre + "text_embeddings.token_type_embeddings.weight"][0]
          + p[pre + "text_embeddings.position_embeddings.weight"][:L][None])
     return layer_norm(e, p[pre + "text_embeddings.LayerNorm.weight"],
@@ -229,11 +230,11 @@ def block(p: Params, b: str, x: Tensor, mask: Tensor, H: int) -> Tensor:
 
 
 def infer(p: Params, cfg: dict, ids: Tensor, text_masks: Tensor, img: Tensor, key: bool = False,
-          image_token_type_idx: int = 1) -> dict:
+          image_token_type_idx: int = 1, word_embeds: Optional[Tensor] = None) -> dict:
     """ViLTransformerSS.infer (vilt_module.py:275-351) / infer_k (:353-418).
     ``key=True`` uses the k_* momentum copies but the *query* pooler (:405)."""
     pre = "k_" if key else ""
-    te = text_embed(p, pre, ids) + p[pre + "token_type_embeddings.weight"][0]
+    te = text_embed(p, pre, ids, word_embeds) + p[pre + "token_type_embeddings.weight"][0]
     ie, im = visual_embed_dense(p, pre, img, cfg)
     ie = ie + p[pre + "token_type_embeddings.weight"][image_token_type_idx]
     x = torch.cat([te, ie], dim=1)
@@ -313,6 +314,95 @@ def pgd_attack(p: Params, cfg: dict, batch: dict, k: Tensor, queue: Tensor,
     return (delta, steps) if return_steps else delta
 
 
+def infonce_ce_rows(q: Tensor, k: Tensor, queue: Tensor, T: float) -> Tensor:
+    """per-row CE (label 0) of the InfoNCE logits"""
+    lg = infonce_logits(q, k, queue, T)
+    return torch.logsumexp(lg, dim=1) - lg[:, 0]
+
+
+def text_saliency(p: Params, cfg: dict, ids, masks, img, k, queue):
+    """GreedyAttack_moco.get_grad (attack/greedy_attack_vilt.py:406-452): gradient of the batch-mean InfoNCE
+    loss wrt the OUTPUT of word_embeddings [B,L,D] (what the backward hook captures), plus q."""
+    we = p["text_embeddings.word_embeddings.weight"].detach()[ids].clone().requires_grad_(True)
+    pd = {n: t.detach() for n, t in p.items()}
+    with torch.enable_grad():
+        out = infer(pd, cfg, ids, masks, img, word_embeds=we)
+        q = l2_normalize(moco_head(pd, "", out["cls_feats"]))
+        loss = infonce_loss(infonce_logits(q, k, queue, cfg["temperature"]))
+        (g,) = torch.autograd.grad(loss, we)
+    return g, q.detach()
+
+
+def synthetic_candidates(seed: int, n: int, vocab: int):
+    """Deterministic stand-in for the synonym tables (counter-fitted vectors / wordnet are not available
+    offline): n pseudo-random replacement token ids for (loop, sample, position)."""
+    def fn(loop: int, b: int, t: int, ids_row) -> List[int]:
+        g = torch.Generator().manual_seed(seed * 1000003 + loop * 10007 + b * 101 + t)
+        return torch.randint(1000, vocab, (n,), generator=g).tolist()
+    return fn
+
+
+def greedy_text_attack(p: Params, cfg: dict, batch: dict, k: Tensor, queue: Tensor, candidate_fn, max_loops: int,
+                       sep_id: int = 102):
+    """Token-level restatement of GreedyAttack_moco.adv_attack_samples (greedy_attack_vilt.py:494-599) with
+    word := token (the tokenizer / stop-word / synonym resources are unavailable offline).  Per loop and sample:
+    pick the unused position with the largest L1 saliency (:221-228,:280-308) subject to the 20 % change budget,
+    build one sentence per candidate (:312-356), keep the candidate with the largest loss if it beats the current
+    loss AND its index is > 0 (the reference's `selected_idx > 0`, :571)."""
+    ids = batch["text_ids"].clone()
+    masks = batch["text_masks"]
+    img = batch["image"][0]
+    Bn, Lt = ids.shape
+    T = cfg["temperature"]
+    orig = ids.clone()
+    history = [set() for _ in range(Bn)]
+    changes = [0] * Bn
+    pd = {n: t.detach() for n, t in p.items()}
+    for loop in range(max_loops):
+        g, q = text_saliency(p, cfg, ids, masks, img, k, queue)
+        sal = g.abs().sum(-1)                                        # [B, L]
+        ce0 = infonce_ce_rows(q, k, queue, T)
+        cand_ids, owner, pos_of = [], [], []
+        for b in range(Bn):
+            sep = int((ids[b] == sep_id).nonzero()[0])
+            max_len = int(sep * 0.2)
+            order = torch.argsort(sal[b, 1:sep], descending=True, stable=True) + 1     # words = tokens 1..sep-1
+            chosen = None
+            for t in order.tolist():
+                if t in history[b] or changes[b] >= min(max_len, max_loops):
+                    continue
+                chosen = t
+                break
+            if chosen is None:
+                cand_ids.append(ids[b].clone()); owner.append(b); pos_of.append(None)
+                continue
+            history[b].add(chosen)
+            for c in candidate_fn(loop, b, chosen, ids[b]):
+                row = ids[b].clone(); row[chosen] = c
+                cand_ids.append(row); owner.append(b); pos_of.append(chosen)
+        cids = torch.stack(cand_ids)
+        own = torch.tensor(owner)
+        with torch.no_grad():
+            out = infer(pd, cfg, cids, masks[own], img[own])
+            qc = l2_normalize(moco_head(pd, "", out["cls_feats"]))
+            cec = infonce_ce_rows(qc, k[own], queue, T)
+        for b in range(Bn):
+            idx = (own == b).nonzero().flatten().tolist()
+            if pos_of[idx[0]] is None:
+                continue
+            best, best_j = float(ce0[b]), -1
+            for j, r in enumerate(idx):
+                if float(cec[r]) > best:
+                    best, best_j = float(cec[r]), j
+            if best_j > 0:
+                changes[b] += 1
+                ids[b] = cids[idx[best_j]]
+    nchg = [(orig[b] != ids[b]).sum().item() for b in range(Bn)]
+    nwords = [int((orig[b] == sep_id).nonzero()[0]) - 1 for b in range(Bn)]
+    return {"txt_input_ids": ids, "text_masks": masks, "num_changes": sum(nchg) / Bn,
+            "change_rate": sum(c / max(n, 1) for c, n in zip(nchg, nwords)) / Bn, "changes_verification": changes}
+
+
 def ema_update(p: Params, m: float) -> None:
     """_momentum_update_key_layer (objectives.py:219-224,257-260)."""
     for name in list(p.keys()):
@@ -349,6 +439,16 @@ def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, p
     pred0 = logits0.argmax(-1)
     ret = {"k": k, "q_original": q0.detach(), "logits_original": logits0.detach()}
     loss, n = 0.0, 0
+    t_ids = t_masks = None
+    if cfg["text_view"]:                                                   # objectives.py:277-317
+        fn = cfg.get("candidate_fn") or synthetic_candidates(cfg.get("seed", 0), cfg["n_candidates"], cfg["vocab_size"])
+        att = greedy_text_attack(p, cfg, batch, k, neg, fn, cfg["max_loops"])
+        t_ids, t_masks = att["txt_input_ids"], att["text_masks"]
+        qt, _ = encode_q(p, cfg, t_ids, t_masks, img)
+        lt = infonce_logits(qt, k, neg, T)
+        loss, n = loss + infonce_loss(lt), n + 1
+        ret.update({"attacked_text_ids": t_ids, "num_changes": att["num_changes"], "change_rate": att["change_rate"],
+                    "geom_success_rate": (lt.argmax(-1) != pred0).float().mean()})
     if cfg["image_view"]:
         pd = {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in p.items()}
         delta, steps = pgd_attack(pd, cfg, batch, k, neg, return_steps=True)
@@ -367,6 +467,10 @@ def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, p
         ret.update({"delta": delta, "attacked_image": attacked, "q_img_attack": qa.detach(), "logits_img_attack": la.detach(),
                     "pgd_success_rate": (la.argmax(-1) != pred0).float().mean(),
                     "delta_range": delta.norm(dim=1).mean()})          # objectives.py:184
+    if cfg["image_view"] and cfg["text_view"]:                             # objectives.py:356-392
+        qb, _ = encode_q(p, cfg, t_ids, t_masks, ret["attacked_image"])
+        lb = infonce_logits(qb, k, neg, T)
+        loss, n = loss + infonce_loss(lb), n + 1
     if training:
         keys_all = k if gathered_keys is None else gathered_keys
         ptr = enqueue(queue, ptr, keys_all, cfg["num_gpus"] * cfg["num_nodes"] * cfg["per_gpu_batchsize"])

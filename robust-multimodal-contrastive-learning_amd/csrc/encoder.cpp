@@ -80,7 +80,7 @@ size_t carve_stash(const rmcl_dims& d, int mode, void* base, Stash* st) {
   float* mf = b.take<float>(M);
   float* rf = b.take<float>(M);
   float *te = nullptr, *tm = nullptr, *tr = nullptr;
-  if (mode == RMCL_MODE_FULL) {
+  {
     te = b.take<float>((size_t)d.B * d.L * D);
     tm = b.take<float>((size_t)d.B * d.L);
     tr = b.take<float>((size_t)d.B * d.L);
@@ -325,8 +325,8 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 
   float* x0 = keep ? st.layer[0].x_in : w.x_a;
   RMCL_TRY(rmcl_text_embed_fwd((const long*)text_ids, c.V(y.word), c.V(y.pos), c.V(y.btype), c.V(y.eln_w), c.V(y.eln_b),
-                               c.V(y.vtype), 1e-12f, x0, full ? st.text_e : nullptr, full ? st.text_mean : nullptr,
-                               full ? st.text_rstd : nullptr, B, L, N, D, s));
+                               c.V(y.vtype), 1e-12f, x0, keep ? st.text_e : nullptr, keep ? st.text_mean : nullptr,
+                               keep ? st.text_rstd : nullptr, B, L, N, D, s));
   {
     GemmArgs g = gemm_args(patches, c.W(y.patch_w), w.pe, B * P, D, d->patch_k, d->patch_k, d->patch_k, D);
     g.epi = EPI_BIAS; g.bias = c.V(y.patch_b); g.tag = GEMM_TAG_PATCH;
@@ -383,7 +383,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 
 int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
                           const void* patches, const int32_t* co_mask, void* stash, void* workspace, const float* dxn,
-                          int cls_only, void* dpatches, float* G, void* stream) {
+                          int cls_only, void* dpatches, float* dtext, float* G, void* stream) {
   RMCL_TRY(check_dims(d));
   RMCL_REQUIRE(mode == RMCL_MODE_DATA || mode == RMCL_MODE_FULL, "encoder_backward: mode must be DATA or FULL");
   RMCL_REQUIRE(params32 && stash && workspace && dxn && co_mask, "encoder_backward: NULL argument");
@@ -492,12 +492,16 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   if (full) {
     RMCL_TRY(gemm_dw(c, w.dpe, D, patches, d->patch_k, Gp(y.patch_w), D, d->patch_k, B * P, dt, w.slab, SLAB_FLOATS(*d)));
     RMCL_TRY(rmcl_colsum(w.dpe, D, dt, Gp(y.patch_b), B * P, D, s));
-    // text rows: x[b*N+t] = LN(e) + vtype[0]
+  }
+  if (full || dtext) {
+    // text rows: x[b*N+t] = LN(e) + vtype[0];  de = gradient wrt the embedding sum e, i.e. wrt the output of
+    // word_embeddings (the tensor the reference's saliency hook captures, greedy_attack_vilt.py:414-452)
+    float* de = dtext ? dtext : w.de;
     RMCL_TRY(rmcl_gather_rows(w.dx, w.dln, B * L, D, L, N, 0, s));
-    RMCL_TRY(rmcl_colsum(w.dln, D, RMCL_F32, Gp(y.vtype), B * L, D, s));
-    RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, st.text_e, D, st.text_mean, st.text_rstd, c.V(y.eln_w), c.V(y.eln_b), w.de, D, 0,
-                         Gp(y.eln_w), Gp(y.eln_b), B * L, D, 0, s));
-    RMCL_TRY(rmcl_text_embed_scatter((const long*)text_ids, w.de, Gp(y.word), Gp(y.pos), Gp(y.btype), B, L, D, 0, s));
+    if (full) RMCL_TRY(rmcl_colsum(w.dln, D, RMCL_F32, Gp(y.vtype), B * L, D, s));
+    RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, st.text_e, D, st.text_mean, st.text_rstd, c.V(y.eln_w), c.V(y.eln_b), de, D, 0,
+                         full ? Gp(y.eln_w) : nullptr, full ? Gp(y.eln_b) : nullptr, B * L, D, 0, s));
+    if (full) RMCL_TRY(rmcl_text_embed_scatter((const long*)text_ids, de, Gp(y.word), Gp(y.pos), Gp(y.btype), B, L, D, 0, s));
   }
   return 0;
 }

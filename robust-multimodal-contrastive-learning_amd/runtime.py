@@ -190,6 +190,14 @@ class Engine:
         check(lib.rmcl_im2patch_f32(P(img), P(pb.patches32), B, 3, Hh, Ww, ps, 0, stream_ptr()), "im2patch")
         return pb
 
+    def bind_text(self, like: PassBuffers, text_ids: torch.Tensor, text_mask: torch.Tensor, tag: str) -> PassBuffers:
+        """Buffers of another objective/view for the same images (`like.patches32` is shared) with other text."""
+        pv = self.bufs(like.B, tag)
+        pv.text_ids = text_ids.to(self.device, torch.int64).contiguous()
+        pv.text_mask = text_mask.to(self.device, torch.int64).contiguous()
+        pv.patches32 = like.patches32
+        return pv
+
     def patches_to_image(self, pat: torch.Tensor, B: int) -> torch.Tensor:
         S = self.cfg["image_size"]
         out = torch.empty(B, 3, S, S, dtype=torch.float32, device=self.device)
@@ -230,10 +238,10 @@ class Engine:
                                       P(pb.dcls), P(self.g32 if with_grads else None), P(pb.workspace), stream_ptr()),
               "heads_backward")
 
-    def encoder_backward(self, pb: PassBuffers, mode: int, patchesT, dxn, cls_only: bool, dpatches):
+    def encoder_backward(self, pb: PassBuffers, mode: int, patchesT, dxn, cls_only: bool, dpatches, dtext=None):
         stash = pb.stash_data if mode == L.MODE_DATA else pb.stash_full
         check(lib.rmcl_encoder_backward(C.byref(pb.d), mode, P(self.q32), P(self.q_lp), P(pb.text_ids), P(patchesT),
-                                        P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), int(cls_only), P(dpatches),
+                                        P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), int(cls_only), P(dpatches), P(dtext),
                                         P(self.g32 if mode == L.MODE_FULL else None), stream_ptr()), "encoder_backward")
 
     def pgd_step(self, pb: PassBuffers, lr: float, eps: float):

@@ -41,6 +41,49 @@ def compute_pgd(pl_module, batch, loss_name, k_modality=None):
     return batch
 
 
+def compute_geometric(pl_module, batch, loss_name, k_modality=None):
+    """objectives.py:190-215."""
+    attack_words = pl_module.greedy_attacker.adv_attack_samples(pl_module, batch, k_modality)
+    batch["text"] = attack_words["text"]
+    batch["text_ids"] = attack_words["txt_input_ids"]
+    batch["text_masks"] = attack_words["text_masks"]
+    phase = "train" if pl_module.training else "val"
+    pl_module.log(f"{loss_name}_attack/{phase}/num_changes", attack_words["num_changes"])
+    pl_module.log(f"{loss_name}_attack/{phase}/change_rate", attack_words["change_rate"])
+    return batch
+
+
+def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_original, ret, phase):
+    """One attacked view (objectives.py:287-317 / :324-354 / :362-392): encoder forward on `op` with the text in
+    `pv`, InfoNCE against the queue, metrics, and a loss tensor whose backward runs the HIP backward."""
+    eng = pl_module.engine
+    B = pv.B
+    need_grad = torch.is_grad_enabled() and pl_module.training
+    if pv.k.data_ptr() != k.data_ptr():
+        pv.k.copy_(k)
+    eng.encoder_forward(pv, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op)
+    eng.heads_forward(pv, key=False)
+    eng.infonce(pv, 1.0 / B, want_dq=need_grad)
+    rows = pv.rows
+    if phase == "train":
+        pl_module.log(f"moco_attack/{success_name}", (rows[:, 1] != prediction_original).float().mean())
+    for j, name in ((3, "pos_dist"), (4, "pos_cosine"), (5, "pos_dot"), (6, "neg_dist"), (7, "neg_cosine"), (8, "neg_dot")):
+        ret[f"{name}_attacked_{suffix}"] = rows[:, j].mean()
+    ret[f"q_{suffix}_attack"] = pv.q.clone()
+    value = _scalar(pv.loss_sum.clone())
+    if not need_grad:
+        return value
+    dq_saved = pv.dq.clone()
+
+    def backward(grad_out, pv=pv, dq_saved=dq_saved, op=op):
+        dq = dq_saved * grad_out.to(dq_saved.dtype)
+        eng.heads_backward(pv, dq, None, with_grads=True)
+        eng.encoder_backward(pv, L.MODE_FULL, op, pv.dcls, cls_only=True, dpatches=None)
+        pl_module.after_backward()
+
+    return _DeferredBackward.apply(pl_module.grad_anchor, value, backward)
+
+
 def compute_itm_wpa(pl_module, batch):
     """objectives.compute_itm_wpa (:714-787): ITM head + CE, and the word-patch-alignment OT distance
     (cosine cost :24-34, IPOT :46-76 with beta=0.5 / 50 iterations, trace :37-43)."""
@@ -136,8 +179,6 @@ def compute_moco_contrastive(pl_module, batch):
     eng = pl_module.engine
     if not (pl_module.image_view or pl_module.text_view):
         raise ZeroDivisionError("division by zero: loss / loss_num with both views off (objectives.py:250-251,397)")
-    if pl_module.text_view:
-        raise NotImplementedError("text view (greedy synonym attack) needs nltk/counter-fitted resources; SURVEY 8(f4)")
     if pl_module.augmentation:
         raise NotImplementedError("augmentation views are out of scope (SURVEY 2.1 #17)")
     phase = "train" if pl_module.training else "val"
@@ -170,40 +211,35 @@ def compute_moco_contrastive(pl_module, batch):
 
     loss = 0
     loss_num = 0
-    if pl_module.image_view:
+    txt_ids = txt_masks = None
+    if pl_module.text_view:                                                 # :277-317
+        aug = compute_geometric(pl_module, copy(batch), "moco", k_modality=k)
+        txt_ids, txt_masks = aug["text_ids"], aug["text_masks"]
+        pt = eng.bind_text(pb, txt_ids, txt_masks, tag="moco_txt")
+        op_t = eng.make_operand(pb, out=pt.patchesT_full)                   # clean image, attacked text
+        loss_t = _attacked_view(pl_module, pt, op_t, k, "txt", "Geom_success_rate", prediction_original, ret, phase)
+        pl_module.log("moco_loss/attacked_txt_loss", loss_t.detach())
+        loss = loss + loss_t
+        loss_num += 1
+    if pl_module.image_view:                                                # :319-354
         pl_module.pgd_attacker.attack_patches(pl_module, pb, k)            # compute_pgd (:319-323)
         check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3,
                                           pb.d.patch_k // 3, stream_ptr()), "delta_norm")
         pl_module.log(f"moco_attack/{phase}/delta", _scalar(pb.loss_sum / float(pb.delta.numel() // 3)))
-        need_grad = torch.is_grad_enabled() and pl_module.training
         # attacked view = img + delta_{K-1} + delta_K  (pgd_attack_vilt.py:144 + objectives.py:176)
         op_att = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pb.patchesT_full)
-        eng.encoder_forward(pb, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op_att)
-        eng.heads_forward(pb, key=False)
-        eng.infonce(pb, 1.0 / B, want_dq=need_grad)
-        rows = pb.rows
-        if phase == "train":
-            pl_module.log("moco_attack/PGD_success_rate", (rows[:, 1] != prediction_original).float().mean())
-        for j, name in ((3, "pos_dist"), (4, "pos_cosine"), (5, "pos_dot"), (6, "neg_dist"), (7, "neg_cosine"), (8, "neg_dot")):
-            ret[f"{name}_attacked_img"] = rows[:, j].mean()
-        ret["q_img_attack"] = pb.q.clone()
-        ret["logit_pos_img_attack"] = rows[:, 2].clone()
-        ret["lse_img_attack"] = rows[:, 9].clone()
-        value = _scalar(pb.loss_sum.clone())
-        if need_grad:
-            dq_saved = pb.dq.clone()
-
-            def backward(grad_out, pb=pb, dq_saved=dq_saved, op_att=op_att):
-                dq = dq_saved * grad_out.to(dq_saved.dtype)
-                eng.heads_backward(pb, dq, None, with_grads=True)
-                eng.encoder_backward(pb, L.MODE_FULL, op_att, pb.dcls, cls_only=True, dpatches=None)
-                pl_module.after_backward()
-
-            loss_attacked_img = _DeferredBackward.apply(pl_module.grad_anchor, value, backward)
-        else:
-            loss_attacked_img = value
-        pl_module.log("moco_loss/attacked_img_loss", loss_attacked_img.detach())
-        loss = loss + loss_attacked_img
+        loss_i = _attacked_view(pl_module, pb, op_att, k, "img", "PGD_success_rate", prediction_original, ret, phase)
+        ret["logit_pos_img_attack"] = pb.rows[:, 2].clone()
+        ret["lse_img_attack"] = pb.rows[:, 9].clone()
+        pl_module.log("moco_loss/attacked_img_loss", loss_i.detach())
+        loss = loss + loss_i
+        loss_num += 1
+    if pl_module.image_view and pl_module.text_view:                        # :356-392 attacked image AND attacked text
+        pbo = eng.bind_text(pb, txt_ids, txt_masks, tag="moco_both")
+        op_b = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pbo.patchesT_full)
+        loss_b = _attacked_view(pl_module, pbo, op_b, k, "both", "Both_success_rate", prediction_original, ret, phase)
+        pl_module.log("moco_loss/attacked_both_loss", loss_b.detach())
+        loss = loss + loss_b
         loss_num += 1
 
     if pl_module.training:                                                  # _dequeue_and_enqueue (:394-395)
@@ -217,10 +253,12 @@ def compute_moco_contrastive(pl_module, batch):
     ret["moco_loss"] = loss / loss_num
     ret["k"] = k.clone()
     pl_module.log(f"moco_loss/step/{phase}", ret["moco_loss"].detach())
-    if pl_module.image_view:
+    views = (["img"] if pl_module.image_view else []) + (["txt"] if pl_module.text_view else []) + \
+            (["both"] if pl_module.image_view and pl_module.text_view else [])
+    for v in views:                                                         # :402-445
         for kind, tag in (("dist", "L2"), ("cosine", "Cosine"), ("dot", "Dot")):
-            pos, neg = ret[f"pos_{kind}_attacked_img"], ret[f"neg_{kind}_attacked_img"]
-            pl_module.log(f"moco_dist_{phase}_{tag}/Pos_attacked_img", pos)
-            pl_module.log(f"moco_dist_{phase}_{tag}/Neg_attacked_img", neg)
-            pl_module.log(f"moco_dist_{phase}_{tag}/Neg-Pos_attacked_img", neg - pos)
+            pos, neg = ret[f"pos_{kind}_attacked_{v}"], ret[f"neg_{kind}_attacked_{v}"]
+            pl_module.log(f"moco_dist_{phase}_{tag}/Pos_attacked_{v}", pos)
+            pl_module.log(f"moco_dist_{phase}_{tag}/Neg_attacked_{v}", neg)
+            pl_module.log(f"moco_dist_{phase}_{tag}/Neg-Pos_attacked_{v}", neg - pos)
     return ret

@@ -13,6 +13,7 @@ import torch.nn as nn
 from ... import _lib as L
 from ...runtime import Engine, EMA_GROUPS
 from ...attack.pgd_attack_vilt import PGDAttack_moco
+from ...attack.greedy_attack_vilt import GreedyAttack_moco
 from . import objectives, vilt_utils, dist_utils
 
 
@@ -71,6 +72,8 @@ class ViLTransformerSS(nn.Module):
             self._queue_ptr_host = 0
             if self.image_view and not self.augmentation:
                 self.pgd_attacker = PGDAttack_moco(config)
+            if self.text_view and not self.augmentation:
+                self.greedy_attacker = GreedyAttack_moco(config)
         self.grad_anchor = torch.zeros((), device=eng.device, requires_grad=True)
         self.sync_grads = True
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._after_load())

@@ -221,3 +221,43 @@ def test_side_stream_weight_gradients_are_race_free():
             a, b = grads[0][base + off: base + off + n], grads[1][base + off: base + off + n]
             assert torch.equal(a, b), (l, off)
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-4 * float(grads[1].abs().max())    # bias grads use float atomics
+
+
+def test_text_attack_and_three_view_step_match_oracle():
+    """BASELINE configs[4] tensor side (text view + image view + both view).  The reference's linguistic
+    resources are unavailable offline, so there is no reference golden for this row ("parity unpinned");
+    the HIP path is checked against the oracle's restatement with the same synthetic candidate generator."""
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=3, text_view=True, image_view=True,
+                            adv_steps_img=2, max_loops=2, n_candidates=5, seed=0)
+    cfg = task_moco(num_layers=2, num_negative=1024, per_gpu_batchsize=3, drop_rate=0.0, image_view=True, text_view=True,
+                    adv_steps_img=2, max_loops=2, n_candidates=5, seed=0, num_gpus=1, num_nodes=1)
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype="f32")
+    p = O.init_params(ocfg, 3)
+    m.load_state_dict({n: t.to(DEV) for n, t in p.items()}, strict=False)
+    queue = O.init_queue(ocfg, 0)
+    m.proj_queue.copy_(queue.to(DEV))
+    m.train()
+    batch = O.synthetic_batch(ocfg, 3, 4, ragged_text=True)
+    # the attack alone: identical token substitutions
+    with torch.no_grad():
+        k = O.l2_normalize(O.moco_head(p, "k_", O.infer(p, ocfg, batch["text_ids"], batch["text_masks"], batch["image"][0], key=True)["cls_feats"]))
+    ref_att = O.greedy_text_attack(p, ocfg, batch, k, queue, O.synthetic_candidates(0, 5, ocfg["vocab_size"]), 2)
+    att = m.greedy_attacker.adv_attack_samples(m, dev_batch(batch), k.to(DEV))
+    assert torch.equal(att["txt_input_ids"].cpu(), ref_att["txt_input_ids"])
+    assert att["changes_verification"] == ref_att["changes_verification"]
+    assert abs(att["num_changes"] - ref_att["num_changes"]) < 1e-9 and abs(att["change_rate"] - ref_att["change_rate"]) < 1e-9
+    # the full three-view step
+    for n, t in p.items():
+        if not n.startswith("k_"):
+            t.requires_grad_(True)
+    ref = O.compute_moco_contrastive(p, ocfg, batch, queue, 0, training=True)
+    ref["moco_loss"].backward()
+    m.zero_grad()
+    loss = m.training_step(dev_batch(batch), 0)
+    assert abs(float(loss) - float(ref["moco_loss"])) < 1e-3
+    loss.backward()
+    params = dict(m.named_parameters())
+    for name in ("transformer.blocks.0.attn.qkv.weight", "text_embeddings.word_embeddings.weight", "pooler.dense.weight",
+                 "transformer.patch_embed.proj.weight", "moco_head.projector.3.weight"):
+        a, b = params[name].grad.cpu(), p[name].grad
+        assert float((a - b).abs().max()) <= 5e-3 * float(b.abs().max()) + 1e-8, name
