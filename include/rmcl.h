@@ -73,6 +73,10 @@ int rmcl_tune_set(int key, int value);
  * concurrently with the data-gradient chain, fork/joined with events on `stream`.  NULL disables it.     */
 int rmcl_set_side_stream(void* stream);
 
+/* Test hook: x[i] *= dropout_mask(site seed of (drop_seed, layer, site), i), i < n (x pre-filled with ones gives the mask).
+ * sites: 0 proj, 1 mlp hidden, 2 fc2, 3 text embeddings, 4 image embeddings (layer 0 for the last two).   */
+int rmcl_dropout_mask_apply(float* x, int64_t n, uint32_t drop_seed, int layer, int site, float drop_p, void* stream);
+
 int rmcl_prof_begin(int tag_mask, int max_launches);
 int rmcl_prof_end(double* ms_total, int64_t* launches, double* flops_total);
 
@@ -94,10 +98,14 @@ int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* ou
 /* One joint text+image encoder forward up to transformer.norm: replaces ViLTransformerSS.infer /
  * infer_k (vilt_module.py:275-418) minus the pooler.  params32: fp32 arena; params_lp: bf16
  * shadow arena (NULL when dtype is F32).  text_ids/text_mask [B,L] int64; patches [B*P,patch_k]
- * in `dtype`; co_mask out [B,N] int32 (N = L+1+P); xn out [B*N, D] f32.                          */
+ * in `dtype`; co_mask out [B,N] int32 (N = L+1+P); xn out [B*N, D] f32.
+ * drop_p > 0 enables the reference's dropout sites (BertEmbeddings dropout, pos_drop, proj_drop, both Mlp
+ * drops; vision_transformer.py:279-285,330-331,667) with a counter-based RNG: masks are a pure function
+ * of (drop_seed, site, element), so the backward, given the same seed, regenerates them.            */
 int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
                          const int64_t* text_ids, const int64_t* text_mask, const void* patches,
-                         int32_t* co_mask, void* stash, void* workspace, float* xn, void* stream);
+                         int32_t* co_mask, void* stash, void* workspace, float* xn,
+                         uint32_t drop_seed, float drop_p, void* stream);
 
 /* Backward of the above.  dxn: gradient wrt xn, [B*N,D] f32, or [B,D] (row 0 of every sample)
  * when cls_only=1.  dpatches (optional) receives d loss/d patches [B*P,patch_k] in `dtype`
@@ -108,7 +116,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
                           const int64_t* text_ids, const void* patches, const int32_t* co_mask,
                           void* stash, void* workspace, const float* dxn, int cls_only,
-                          void* dpatches, float* dtext, float* grads32, void* stream);
+                          void* dpatches, float* dtext, float* grads32, uint32_t drop_seed, float drop_p, void* stream);
 
 /* Pooler + MoCo head + L2 normalise (vilt/modules/heads.py:10-20,129-143; objectives.py:264-269).
  * pool32: arena that owns the pooler (always the query arena); head32: arena that owns the

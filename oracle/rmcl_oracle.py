@@ -191,7 +191,7 @@ def patch_mask(img: Tensor, P: int) -> Tensor:
     return m[:, ::P, ::P].reshape(img.shape[0], -1).to(torch.int64)
 
 
-def visual_embed_dense(p: Params, pre: str, img: Tensor, cfg: dict) -> Tuple[Tensor, Tensor]:
+def visual_embed_dense(p: Params, pre: str, img: Tensor, cfg: dict, drop_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Dense fixed-order visual_embed (vision_transformer.py:559-677) for full-size images
     (every patch valid, G*G <= max_image_len).  The reference permutes patch order with a
     CPU multinomial (:633-636); the encoder is permutation-equivariant so cls/logits are
@@ -203,6 +203,8 @@ def visual_embed_dense(p: Params, pre: str, img: Tensor, cfg: dict) -> Tuple[Ten
     B = img.shape[0]
     cls = p[pre + "transformer.cls_token"].expand(B, -1, -1)
     x = torch.cat([cls, x], dim=1) + p[pre + "transformer.pos_embed"]
+    if drop_mask is not None:                              # pos_drop (vision_transformer.py:667)
+        x = x * drop_mask
     m = torch.cat([torch.ones(B, 1, dtype=torch.int64), patch_mask(img, P)], dim=1)
     return x, m
 
@@ -221,26 +223,36 @@ def attention(p: Params, b: str, x: Tensor, mask: Tensor, H: int) -> Tensor:
     return o @ p[b + "attn.proj.weight"].t() + p[b + "attn.proj.bias"]
 
 
-def block(p: Params, b: str, x: Tensor, mask: Tensor, H: int) -> Tensor:
-    """Block.forward (vision_transformer.py:371-375), drop_path=0, eps 1e-6 (:466)."""
-    x = x + attention(p, b, layer_norm(x, p[b + "norm1.weight"], p[b + "norm1.bias"], 1e-6), mask, H)
+def block(p: Params, b: str, x: Tensor, mask: Tensor, H: int, drop: Optional[dict] = None) -> Tensor:
+    """Block.forward (vision_transformer.py:371-375), drop_path=0, eps 1e-6 (:466).  ``drop`` (optional):
+    explicit dropout scale masks {"proj", "hidden", "fc2"} for proj_drop (:331) and the two Mlp drops (:282,:284)."""
+    d = drop or {}
+    a = attention(p, b, layer_norm(x, p[b + "norm1.weight"], p[b + "norm1.bias"], 1e-6), mask, H)
+    x = x + (a * d["proj"] if "proj" in d else a)
     h = layer_norm(x, p[b + "norm2.weight"], p[b + "norm2.bias"], 1e-6)
     h = gelu_erf(h @ p[b + "mlp.fc1.weight"].t() + p[b + "mlp.fc1.bias"])
-    return x + h @ p[b + "mlp.fc2.weight"].t() + p[b + "mlp.fc2.bias"]
+    if "hidden" in d:
+        h = h * d["hidden"]
+    o = h @ p[b + "mlp.fc2.weight"].t() + p[b + "mlp.fc2.bias"]
+    return x + (o * d["fc2"] if "fc2" in d else o)
 
 
 def infer(p: Params, cfg: dict, ids: Tensor, text_masks: Tensor, img: Tensor, key: bool = False,
-          image_token_type_idx: int = 1, word_embeds: Optional[Tensor] = None) -> dict:
+          image_token_type_idx: int = 1, word_embeds: Optional[Tensor] = None, drop: Optional[dict] = None) -> dict:
     """ViLTransformerSS.infer (vilt_module.py:275-351) / infer_k (:353-418).
     ``key=True`` uses the k_* momentum copies but the *query* pooler (:405)."""
     pre = "k_" if key else ""
-    te = text_embed(p, pre, ids, word_embeds) + p[pre + "token_type_embeddings.weight"][0]
-    ie, im = visual_embed_dense(p, pre, img, cfg)
+    drop = drop or {}
+    te = text_embed(p, pre, ids, word_embeds)
+    if "text" in drop:                                     # BertEmbeddings.dropout
+        te = te * drop["text"]
+    te = te + p[pre + "token_type_embeddings.weight"][0]
+    ie, im = visual_embed_dense(p, pre, img, cfg, drop.get("image"))
     ie = ie + p[pre + "token_type_embeddings.weight"][image_token_type_idx]
     x = torch.cat([te, ie], dim=1)
     m = torch.cat([text_masks, im], dim=1)
     for i in range(cfg["num_layers"]):
-        x = block(p, f"{pre}transformer.blocks.{i}.", x, m, cfg["num_heads"])
+        x = block(p, f"{pre}transformer.blocks.{i}.", x, m, cfg["num_heads"], drop.get(i))
     x = layer_norm(x, p[pre + "transformer.norm.weight"], p[pre + "transformer.norm.bias"], 1e-6)
     L = ids.shape[1]
     cls = torch.tanh(x[:, 0] @ p["pooler.dense.weight"].t() + p["pooler.dense.bias"])  # heads.py:16-20

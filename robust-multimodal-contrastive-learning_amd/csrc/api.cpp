@@ -97,6 +97,12 @@ int rmcl_prof_end(double* ms_total, int64_t* launches, double* flops_total) {
 }
 int rmcl_version(void) { return 1; }
 
+int rmcl_dropout_mask_apply(float* x, int64_t n, uint32_t drop_seed, int layer, int site, float drop_p, void* stream) {
+  RMCL_REQUIRE(x && drop_p >= 0.f && drop_p < 1.f, "dropout_mask_apply: bad argument");
+  if (drop_p == 0.f) return 0;
+  return rmcl_dropout_apply(x, n, rmcl_site_seed(drop_seed, layer, site), (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p),
+                            (hipStream_t)stream);
+}
 int rmcl_tune_set(int key, int value) {
   if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }
   rmcl_set_error("tune_set: unknown key");

@@ -12,7 +12,8 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const long* __restr
                                                              const float* __restrict__ g, const float* __restrict__ beta,
                                                              const float* __restrict__ vtype0, float eps, float* __restrict__ x,
                                                              float* __restrict__ e_save, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, int B, int L, int N, int D) {
+                                                             float* __restrict__ rstd, int B, int L, int N, int D,
+                                                             uint32_t dseed, uint32_t dthresh, float dinv) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= B * L) return;
   const int b = r / L, t = r % L;
@@ -50,19 +51,24 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const long* __restr
     if (c < D) {
       const float4 ww = *reinterpret_cast<const float4*>(g + c), bb = *reinterpret_cast<const float4*>(beta + c);
       const float4 tt = *reinterpret_cast<const float4*>(vtype0 + c);
-      *reinterpret_cast<float4*>(xr + c) =
-          make_float4((v[i].x - mu) * rs * ww.x + bb.x + tt.x, (v[i].y - mu) * rs * ww.y + bb.y + tt.y,
-                      (v[i].z - mu) * rs * ww.z + bb.z + tt.z, (v[i].w - mu) * rs * ww.w + bb.w + tt.w);
+      float4 o = make_float4((v[i].x - mu) * rs * ww.x + bb.x, (v[i].y - mu) * rs * ww.y + bb.y,
+                             (v[i].z - mu) * rs * ww.z + bb.z, (v[i].w - mu) * rs * ww.w + bb.w);
+      if (dthresh) {                                          // BertEmbeddings.dropout, before the ViLT token type
+        const uint32_t di = (uint32_t)((long)r * D + c);
+        o.x *= drop_scale(dseed, di, dthresh, dinv); o.y *= drop_scale(dseed, di + 1, dthresh, dinv);
+        o.z *= drop_scale(dseed, di + 2, dthresh, dinv); o.w *= drop_scale(dseed, di + 3, dthresh, dinv);
+      }
+      *reinterpret_cast<float4*>(xr + c) = make_float4(o.x + tt.x, o.y + tt.y, o.z + tt.z, o.w + tt.w);
     }
   }
 }
 
 int rmcl_text_embed_fwd(const long* ids, const float* word, const float* pos, const float* btype0, const float* g,
                         const float* beta, const float* vtype0, float eps, float* x, float* e_save, float* mean, float* rstd,
-                        int B, int L, int N, int D, hipStream_t s) {
+                        int B, int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0 && D <= 1024, "text_embed: D must be a multiple of 4 and <= 1024");
   RMCL_LAUNCH(text_embed_fwd_kernel, dim3(cdiv((long)B * L, 4)), dim3(256), 0, s, ids, word, pos, btype0, g, beta, vtype0,
-                     eps, x, e_save, mean, rstd, B, L, N, D);
+                     eps, x, e_save, mean, rstd, B, L, N, D, dseed, dthresh, dinv);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -135,7 +141,8 @@ int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, l
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void image_assemble_fwd_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                                                  const float* __restrict__ pos, const float* __restrict__ vtype1,
-                                                                 float* __restrict__ x, int B, int P, int L, int N, int D) {
+                                                                 float* __restrict__ x, int B, int P, int L, int N, int D,
+                                                                 uint32_t dseed, uint32_t dthresh, float dinv) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int dv = D / 4;
   if (i >= (long)B * (P + 1) * dv) return;
@@ -145,12 +152,19 @@ __global__ __launch_bounds__(256) void image_assemble_fwd_kernel(const float* __
                             : *reinterpret_cast<const float4*>(pe + ((long)b * P + tok - 1) * D + c);
   const float4 p = *reinterpret_cast<const float4*>(pos + (long)tok * D + c);
   const float4 t = *reinterpret_cast<const float4*>(vtype1 + c);
-  *reinterpret_cast<float4*>(x + ((long)b * N + L + tok) * D + c) = make_float4(a.x + p.x + t.x, a.y + p.y + t.y, a.z + p.z + t.z, a.w + p.w + t.w);
+  float4 o = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+  if (dthresh) {                                              // pos_drop (vision_transformer.py:667), before the token type
+    const uint32_t di = (uint32_t)(((long)b * (P + 1) + tok) * D + c);
+    o.x *= drop_scale(dseed, di, dthresh, dinv); o.y *= drop_scale(dseed, di + 1, dthresh, dinv);
+    o.z *= drop_scale(dseed, di + 2, dthresh, dinv); o.w *= drop_scale(dseed, di + 3, dthresh, dinv);
+  }
+  *reinterpret_cast<float4*>(x + ((long)b * N + L + tok) * D + c) = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
 }
 int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos, const float* vtype1, float* x, int B, int P,
-                            int L, int N, int D, hipStream_t s) {
+                            int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0, "image_assemble: D%4");
-  RMCL_LAUNCH(image_assemble_fwd_kernel, dim3(cdiv((long)B * (P + 1) * (D / 4), 256)), dim3(256), 0, s, pe, cls, pos, vtype1, x, B, P, L, N, D);
+  RMCL_LAUNCH(image_assemble_fwd_kernel, dim3(cdiv((long)B * (P + 1) * (D / 4), 256)), dim3(256), 0, s, pe, cls, pos, vtype1, x, B, P, L, N, D,
+              dseed, dthresh, dinv);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -160,26 +174,29 @@ int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos,
 template <typename T>
 __global__ __launch_bounds__(256) void image_assemble_bwd_kernel(const float* __restrict__ dx, T* __restrict__ dpe,
                                                                  float* __restrict__ dpos, float* __restrict__ dcls,
-                                                                 float* __restrict__ dvtype1, int B, int P, int L, int N, int D) {
+                                                                 float* __restrict__ dvtype1, int B, int P, int L, int N, int D,
+                                                                 uint32_t dseed, uint32_t dthresh, float dinv) {
   const int tok = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
   if (c >= D) return;
-  float acc = 0.f;
+  float acc = 0.f, acc_raw = 0.f;
   for (int b = 0; b < B; ++b) {
-    const float v = dx[((long)b * N + L + tok) * D + c];
+    const float raw = dx[((long)b * N + L + tok) * D + c];
+    const float v = dthresh ? raw * drop_scale(dseed, (uint32_t)(((long)b * (P + 1) + tok) * D + c), dthresh, dinv) : raw;
     acc += v;
+    acc_raw += raw;
     if (tok > 0) dpe[((long)b * P + tok - 1) * D + c] = from_f32<T>(v);
   }
   if (dpos) {
     atomicAdd(dpos + (long)tok * D + c, acc);
-    atomicAdd(dvtype1 + c, acc);
+    atomicAdd(dvtype1 + c, acc_raw);                         // the token type is added after pos_drop
     if (tok == 0) atomicAdd(dcls + c, acc);
   }
 }
 int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,
-                            int N, int D, hipStream_t s) {
+                            int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
   dim3 grid(P + 1, cdiv(D, 256));
-  if (dt == RMCL_F32) RMCL_LAUNCH(image_assemble_bwd_kernel<float>, grid, dim3(256), 0, s, dx, (float*)dpe, dpos, dcls, dvtype1, B, P, L, N, D);
-  else RMCL_LAUNCH(image_assemble_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dx, (bf16_t*)dpe, dpos, dcls, dvtype1, B, P, L, N, D);
+  if (dt == RMCL_F32) RMCL_LAUNCH(image_assemble_bwd_kernel<float>, grid, dim3(256), 0, s, dx, (float*)dpe, dpos, dcls, dvtype1, B, P, L, N, D, dseed, dthresh, dinv);
+  else RMCL_LAUNCH(image_assemble_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dx, (bf16_t*)dpe, dpos, dcls, dvtype1, B, P, L, N, D, dseed, dthresh, dinv);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -467,6 +484,17 @@ int rmcl_adamw(float* p, const float* g, float* m, float* v, void* p_lp, const l
   const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
   RMCL_LAUNCH(adamw_kernel, dim3(std::min<long>(cdiv(n / 4, 256), 4096)), dim3(256), 0, s, p, g, m, v, (bf16_t*)p_lp, seg_end,
                      seg_lr_mult, seg_wd, nseg, lr, b1, b2, eps, bc1, bc2s, n / 4, grad_scale);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// x[i] *= mask(seed, i)  (in place; with x pre-filled with ones this materialises a site's mask for the tests)
+__global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ x, long n, uint32_t dseed, uint32_t dthresh, float dinv) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= drop_scale(dseed, (uint32_t)i, dthresh, dinv);
+}
+int rmcl_dropout_apply(float* x, long n, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
+  if (n <= 0 || dthresh == 0) return 0;
+  RMCL_LAUNCH(dropout_apply_kernel, dim3(std::min<long>(cdiv(n, 256), 4096)), dim3(256), 0, s, x, n, dseed, dthresh, dinv);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

@@ -307,7 +307,7 @@ int64_t rmcl_workspace_bytes(const rmcl_dims* d) { return (int64_t)carve_work(*d
 
 int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
                          const int64_t* text_mask, const void* patches, int32_t* co_mask, void* stash, void* workspace,
-                         float* xn, void* stream) {
+                         float* xn, uint32_t drop_seed, float drop_p, void* stream) {
   RMCL_TRY(check_dims(d));
   RMCL_REQUIRE(params32 && text_ids && text_mask && patches && co_mask && workspace && xn, "encoder_forward: NULL argument");
   RMCL_REQUIRE(d->dtype == RMCL_F32 || params_lp, "encoder_forward: bf16 mode needs the bf16 shadow arena");
@@ -322,17 +322,24 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
   const int B = d->B, L = d->L, P = d->P, N = L + 1 + P, D = d->D, M = B * N, dt = d->dtype;
   const bool keep = mode != RMCL_MODE_INFER, full = mode == RMCL_MODE_FULL;
   hipStream_t s = c.s;
+  RMCL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "encoder_forward: dropout probability must be in [0,1)");
+  const uint32_t dth = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+  const float dinv = 1.0f / (1.0f - drop_p);
+  auto with_drop = [&](GemmArgs& g, int layer, int site) {
+    if (dth) { g.epi |= EPI_DROPOUT; g.drop_seed = rmcl_site_seed(drop_seed, layer, site); g.drop_thresh = dth; g.drop_inv_keep = dinv; }
+  };
 
   float* x0 = keep ? st.layer[0].x_in : w.x_a;
   RMCL_TRY(rmcl_text_embed_fwd((const long*)text_ids, c.V(y.word), c.V(y.pos), c.V(y.btype), c.V(y.eln_w), c.V(y.eln_b),
                                c.V(y.vtype), 1e-12f, x0, keep ? st.text_e : nullptr, keep ? st.text_mean : nullptr,
-                               keep ? st.text_rstd : nullptr, B, L, N, D, s));
+                               keep ? st.text_rstd : nullptr, B, L, N, D, rmcl_site_seed(drop_seed, 0, DROP_SITE_TEXT), dth, dinv, s));
   {
     GemmArgs g = gemm_args(patches, c.W(y.patch_w), w.pe, B * P, D, d->patch_k, d->patch_k, d->patch_k, D);
     g.epi = EPI_BIAS; g.bias = c.V(y.patch_b); g.tag = GEMM_TAG_PATCH;
     RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
   }
-  RMCL_TRY(rmcl_image_assemble_fwd(w.pe, c.V(y.cls), c.V(y.pos_img), c.V(y.vtype) + D, x0, B, P, L, N, D, s));
+  RMCL_TRY(rmcl_image_assemble_fwd(w.pe, c.V(y.cls), c.V(y.pos_img), c.V(y.vtype) + D, x0, B, P, L, N, D,
+                                   rmcl_site_seed(drop_seed, 0, DROP_SITE_IMAGE), dth, dinv, s));
   RMCL_TRY(rmcl_co_mask((const long*)text_mask, patches, dt, co_mask, B, L, P, 3, d->patch_k / 3, s));
 
   float* x = x0;
@@ -361,17 +368,20 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     {
       GemmArgs g = gemm_args(ao, c.W(c.L(l, y.proj_w)), x_mid, M, D, D, D, D, D);
       g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = D; g.tag = GEMM_TAG_PROJ;
+      with_drop(g, l, DROP_SITE_PROJ);
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
     }
     RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2, D, dt, m2, r2, M, D, 0, s));
     {
       GemmArgs g = gemm_args(ln2, c.W(c.L(l, y.fc1_w)), h, M, d->mlp, D, D, D, d->mlp);
       g.epi = EPI_BIAS | EPI_GELU | (u ? EPI_SAVE_PREACT : 0); g.bias = c.V(c.L(l, y.fc1_b)); g.C2 = u; g.tag = GEMM_TAG_FC1;
+      with_drop(g, l, DROP_SITE_HIDDEN);
       RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
     }
     {
       GemmArgs g = gemm_args(h, c.W(c.L(l, y.fc2_w)), x_out, M, D, d->mlp, d->mlp, d->mlp, D);
       g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.fc2_b)); g.aux = x_mid; g.ld_aux = D; g.tag = GEMM_TAG_FC2;
+      with_drop(g, l, DROP_SITE_FC2);
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
     }
     x = x_out;
@@ -383,7 +393,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 
 int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
                           const void* patches, const int32_t* co_mask, void* stash, void* workspace, const float* dxn,
-                          int cls_only, void* dpatches, float* dtext, float* G, void* stream) {
+                          int cls_only, void* dpatches, float* dtext, float* G, uint32_t drop_seed, float drop_p, void* stream) {
   RMCL_TRY(check_dims(d));
   RMCL_REQUIRE(mode == RMCL_MODE_DATA || mode == RMCL_MODE_FULL, "encoder_backward: mode must be DATA or FULL");
   RMCL_REQUIRE(params32 && stash && workspace && dxn && co_mask, "encoder_backward: NULL argument");
@@ -412,7 +422,10 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   // bf16 copy of dx written by every LN backward (ping-pong T[0]/T[1]); with a side stream the weight
   // gradients of layer l run concurrently with the data-gradient chain, reading the copy the chain no
   // longer writes (events order the reuse of T / du / dqkv two sub-layers later).
-  const bool lpm = dt != RMCL_F32;
+  RMCL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "encoder_backward: dropout probability must be in [0,1)");
+  const uint32_t dth = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
+  const float dinv = 1.0f / (1.0f - drop_p);
+  const bool lpm = dt != RMCL_F32 || dth != 0;      // a (masked) copy of dx in the GEMM operand type is needed
   const bool use_side = full && lpm && g_side != nullptr;
   if (use_side) RMCL_TRY(ensure_events());
   void* T[2] = {lpm ? w.dxT : nullptr, lpm ? (use_side ? w.dxT2 : w.dxT) : nullptr};
@@ -422,7 +435,8 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   auto EV = [&](int kind, int l) { return g_ev[(kind * 32 + (l & 31)) & 127]; };   // kind 0: fork, 1: done1, 2: done2
   int cur = 0;
   RMCL_TRY(rmcl_ln_bwd_lp(dy, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), w.dx, D, 0,
-                          full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, T[0], s));
+                          full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, T[0], dt,
+                          rmcl_site_seed(drop_seed, d->layers - 1, DROP_SITE_FC2), dth, dinv, s));
   const int Lr = d->layers;
   for (int l = Lr - 1; l >= 0; --l) {
     const LayerStash& ls = st.layer[l];
@@ -434,6 +448,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     {
       GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.fc2_w)), du, M, mlp, D, D, mlp, mlp);       // du = (dx W2) * gelu'(u)
       g.epi = EPI_DGELU; g.aux = ls.u; g.ld_aux = mlp; g.tag = GEMM_TAG_DX;
+      if (dth) { g.epi |= EPI_DROP_BWD; g.drop_seed = rmcl_site_seed(drop_seed, l, DROP_SITE_HIDDEN); g.drop_thresh = dth; g.drop_inv_keep = dinv; }
       RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
     }
     if (full) {
@@ -451,7 +466,8 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     }
     if (use_side && l + 1 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 1), 0));           // T[cur^1] free again
     RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
-                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, T[cur ^ 1], s));
+                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, T[cur ^ 1], dt,
+                            rmcl_site_seed(drop_seed, l, DROP_SITE_PROJ), dth, dinv, s));
     cur ^= 1;
     // ---- attention ----
     dxT = lpm ? T[cur] : (const void*)w.dx;
@@ -477,14 +493,15 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     }
     if (use_side) HIP_TRY(hipStreamWaitEvent(s, EV(1, l), 0));                             // T[cur^1] free again
     RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, RMCL_F32, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
-                            full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, T[cur ^ 1], s));
+                            full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, T[cur ^ 1], dt,
+                            rmcl_site_seed(drop_seed, l - 1, DROP_SITE_FC2), l > 0 ? dth : 0u, dinv, s));
     cur ^= 1;
   }
   if (use_side) HIP_TRY(hipStreamWaitEvent(s, EV(2, 0), 0));                               // join: all side work done
 
   // ---- embeddings ----
   RMCL_TRY(rmcl_image_assemble_bwd(w.dx, w.dpe, dt, full ? Gp(y.pos_img) : nullptr, full ? Gp(y.cls) : nullptr,
-                                   full ? Gp(y.vtype) + D : nullptr, B, P, L, N, D, s));
+                                   full ? Gp(y.vtype) + D : nullptr, B, P, L, N, D, rmcl_site_seed(drop_seed, 0, DROP_SITE_IMAGE), dth, dinv, s));
   if (dpatches) {
     GemmArgs g = gemm_args(w.dpe, c.W(y.patch_w), dpatches, B * P, d->patch_k, D, D, d->patch_k, d->patch_k);
     RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
@@ -499,6 +516,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     float* de = dtext ? dtext : w.de;
     RMCL_TRY(rmcl_gather_rows(w.dx, w.dln, B * L, D, L, N, 0, s));
     if (full) RMCL_TRY(rmcl_colsum(w.dln, D, RMCL_F32, Gp(y.vtype), B * L, D, s));
+    RMCL_TRY(rmcl_dropout_apply(w.dln, (long)B * L * D, rmcl_site_seed(drop_seed, 0, DROP_SITE_TEXT), dth, dinv, s));
     RMCL_TRY(rmcl_ln_bwd(w.dln, D, RMCL_F32, st.text_e, D, st.text_mean, st.text_rstd, c.V(y.eln_w), c.V(y.eln_b), de, D, 0,
                          full ? Gp(y.eln_w) : nullptr, full ? Gp(y.eln_b) : nullptr, B * L, D, 0, s));
     if (full) RMCL_TRY(rmcl_text_embed_scatter((const long*)text_ids, de, Gp(y.word), Gp(y.pos), Gp(y.btype), B, L, D, 0, s));

@@ -22,7 +22,9 @@ enum {
   EPI_ATOMIC = 32,      // split-K: atomicAdd into fp32 C (C must be fp32, pre-zeroed or accumulating)
   EPI_ACCUM = 64,       // C += result (fp32 or bf16 read-modify-write; not with split-K)
   EPI_TANH = 128,       // tanh on the result
-  EPI_COLSUM = 256,     // TN only: blocks with blockIdx.y==0 atomically add column sums of A (= bias grad) into bias_grad[m]
+  EPI_COLSUM = 256,
+  EPI_DROPOUT = 512,    // dropout on the result (after bias / GELU, before the residual add): mask(drop_seed, m*ldc+n)
+  EPI_DROP_BWD = 1024,  // with EPI_DGELU: also multiply by the forward dropout mask of the hidden activation     // TN only: blocks with blockIdx.y==0 atomically add column sums of A (= bias grad) into bias_grad[m]
 };
 
 enum {
@@ -47,6 +49,8 @@ struct GemmArgs {
   int nb1, nb2;           // batch = nb1*nb2 (blockIdx.z = b1*nb2 + b2) when splitk == 1
   long sA1, sA2, sB1, sB2, sC1, sC2;  // element strides per batch level
   int tag;                // profiling class (GEMM_TAG_*), 0 = untagged
+  uint32_t drop_seed, drop_thresh;   // dropout site seed, p * 2^32
+  float drop_inv_keep;               // 1 / (1 - p)
 };
 
 #ifdef __cplusplus

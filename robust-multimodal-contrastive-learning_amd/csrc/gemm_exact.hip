@@ -171,12 +171,14 @@ __global__ __launch_bounds__(256) void gemm_exact_kernel(GemmArgs g) {
         if (row < g.M && col < g.N) {
           float v = g.alpha * acc[i][j][r];
           if ((epi & EPI_BIAS) && first_slice) v += g.bias[col];
-          if (epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(aux)[(long)row * g.ld_aux + col];
+          if (epi & EPI_DROP_BWD) v *= drop_scale(g.drop_seed, (uint32_t)((long)row * g.ld_aux + col), g.drop_thresh, g.drop_inv_keep);
           if (epi & EPI_DGELU) v *= gelu_erf_grad(to_f32<TI>(reinterpret_cast<const TI*>(aux)[(long)row * g.ld_aux + col]));
           const long ci = (long)row * g.ldc + col;
           if (epi & EPI_SAVE_PREACT) C2[ci] = from_f32<TO>(v);
           if (epi & EPI_GELU) v = gelu_erf(v);
           if (epi & EPI_TANH) v = tanhf(v);
+          if (epi & EPI_DROPOUT) v *= drop_scale(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep);
+          if (epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(aux)[(long)row * g.ld_aux + col];
           if (epi & EPI_ATOMIC) {
             if constexpr (sizeof(TO) == 4) atomicAdd(reinterpret_cast<float*>(C) + ci, v);
           } else if (epi & EPI_ACCUM) {

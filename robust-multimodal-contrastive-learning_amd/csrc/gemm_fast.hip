@@ -26,6 +26,7 @@
 #define FBM 128
 #define FBN 128
 #define FBK 64
+#define GROUP_M 8
 #define A_BYTES (FBM * FBK * 2)
 #define STAGE_BYTES ((FBM + FBN) * FBK * 2)
 
@@ -95,8 +96,17 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmArgs& g, int vt, int 
     const int xcd = t & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (t >> 3);
   }
-  c.m0 = (t / tiles_n) * FBM;
-  c.n0 = (t % tiles_n) * FBN;
+  {
+    // grouped (super-tile) order inside the XCD's run: 8 row-panels x all column tiles per group, rows
+    // fastest, so the ~64 tiles an XCD works on at a time touch 8 A-panels + 8 B-panels (3 MB at K=768,
+    // fits the 4 MiB L2) instead of 3 A-panels + every B-panel (measured: 28 % of the LDS-DMA bytes of
+    // the fc1 GEMM were missing L2 with the plain n-fastest order).
+    const int tiles_m = nwg / tiles_n, per_group = GROUP_M * tiles_n;
+    const int group = t / per_group, first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M), r = t - group * per_group;
+    c.m0 = (first_m + r % gsz) * FBM;
+    c.n0 = (r / gsz) * FBN;
+  }
   c.kbeg = 0;
   int kend = g.K;
   c.zoff = 0;
@@ -110,7 +120,9 @@ __device__ __forceinline__ TileCoord decode_tile(const GemmArgs& g, int vt, int 
   return c;
 }
 
-template <bool A_KC, bool B_KC, typename TO>
+// DROP: dropout epilogues compiled in (a separate instantiation: their extra live state costs >100 spilled
+// VGPRs in the common no-dropout kernels otherwise).
+template <bool A_KC, bool B_KC, typename TO, bool DROP>
 __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles_n, int nwg, int total) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -151,21 +163,19 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles
       if (!dbg_nomma) {
         const char* at = smem + buf * STAGE_BYTES;
         const char* bt = at + A_BYTES;
-        bf16x8 af[2][4], bf[2][4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {                        // all 16 fragment reads of the k-tile are issued up front:
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 af[4], bf[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) af[s][i] = load_frag<A_KC>(at, wm * 64 + i * 16, s, lane);
+          for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KC>(at, wm * 64 + i * 16, s, lane);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bf[s][j] = load_frag<B_KC>(bt, wn * 64 + j * 16, s, lane);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)                          // the reads of k-step 1 land under the MFMAs of k-step 0
+          for (int j = 0; j < 4; ++j) bf[j] = load_frag<B_KC>(bt, wn * 64 + j * 16, s, lane);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[s][j], af[s][i], acc[i][j], 0, 0, 0);   // swapped: D[n][m]
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);   // swapped: D[n][m]
+        }
       }
       if (last) {
         // epilogue (registers -> global only, so it overlaps the in-flight prefetch):
@@ -185,9 +195,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles
               const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
               v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
             }
-            if (epi & EPI_RESIDUAL) {
-              const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + (long)m * g.ld_aux + n);
-              v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            if (DROP && (epi & EPI_DROP_BWD)) {
+              const uint32_t di = (uint32_t)((long)m * g.ld_aux + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, di + r, g.drop_thresh, g.drop_inv_keep);
             }
             if (epi & EPI_DGELU) {
               const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ld_aux + n);
@@ -209,6 +220,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
             }
+            if (DROP && (epi & EPI_DROPOUT)) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, (uint32_t)ci + r, g.drop_thresh, g.drop_inv_keep);
+            }
+            if (epi & EPI_RESIDUAL) {
+              const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + (long)m * g.ld_aux + n);
+              v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            }
             if constexpr (sizeof(TO) == 2) {
               uint2 pk;
               pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
@@ -221,6 +240,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles
               }
               *reinterpret_cast<float4*>(C + ci) = make_float4(v[0], v[1], v[2], v[3]);
             }
+            // keep the 16 per-tile epilogues from being interleaved: hoisting every tile's bias / residual /
+            // aux loads to the top costs > 160 live VGPRs and spills (121 spilled registers measured)
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -269,20 +291,20 @@ bool rmcl_gemm_fast_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc
   return true;
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool DROP>
 static int launch_fast(const GemmArgs& g, int dt_out, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, float, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, bf16_t, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
     attr = true;
   }
   const int tm = cdiv(g.M, FBM), tn = g.N / FBN, nwg = tm * tn;
   const int total = nwg * (g.splitk > 1 ? g.splitk : 1);
   int per_cu = (g_gemm_cfg >= 1 && g_gemm_cfg <= 4) ? g_gemm_cfg : 2;
   const int grid = std::min(total, 256 * per_cu);             // multiple of 8 whenever it is < total
-  if (dt_out == RMCL_F32) RMCL_LAUNCH((gemm_fast_kernel<A_KC, B_KC, float>), dim3(grid), dim3(256), 2 * STAGE_BYTES, s, g, tn, nwg, total);
-  else RMCL_LAUNCH((gemm_fast_kernel<A_KC, B_KC, bf16_t>), dim3(grid), dim3(256), 2 * STAGE_BYTES, s, g, tn, nwg, total);
+  if (dt_out == RMCL_F32) RMCL_LAUNCH((gemm_fast_kernel<A_KC, B_KC, float, DROP>), dim3(grid), dim3(256), 2 * STAGE_BYTES, s, g, tn, nwg, total);
+  else RMCL_LAUNCH((gemm_fast_kernel<A_KC, B_KC, bf16_t, DROP>), dim3(grid), dim3(256), 2 * STAGE_BYTES, s, g, tn, nwg, total);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -295,9 +317,10 @@ int rmcl_launch_gemm_fast(const GemmArgs& g0, int dt_out, int a_kc, int b_kc, hi
     const int kt = g.K / FBK, per = (kt + g.splitk - 1) / g.splitk;
     g.splitk = (kt + per - 1) / per;
   }
-  if (a_kc && b_kc) return launch_fast<true, true>(g, dt_out, s);
-  if (a_kc && !b_kc) return launch_fast<true, false>(g, dt_out, s);
-  return launch_fast<false, false>(g, dt_out, s);
+  const bool drop = g.epi & (EPI_DROPOUT | EPI_DROP_BWD);
+  if (a_kc && b_kc) return drop ? launch_fast<true, true, true>(g, dt_out, s) : launch_fast<true, true, false>(g, dt_out, s);
+  if (a_kc && !b_kc) return drop ? launch_fast<true, false, true>(g, dt_out, s) : launch_fast<true, false, false>(g, dt_out, s);
+  return launch_fast<false, false, false>(g, dt_out, s);
 }
 
 // dW[M=Nout, N=Kin] += A^T B over K tokens with split-K partial slabs (slab: splitk*M*N floats)

@@ -18,7 +18,7 @@ int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, 
                 int relu, hipStream_t s);
 int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
                    const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
-                   int relu, void* dx_lp, hipStream_t s);
+                   int relu, void* dx_copy, int copy_dt, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
 int rmcl_softmax_fwd(const float* S, long lds, const int* mask, void* P, long ldp, int dt, int Z, int N, int H, hipStream_t s);
 int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* dS, long ldds, int dt, int Z, int N,
                      float scale, hipStream_t s);
@@ -29,15 +29,16 @@ int rmcl_colsum(const void* X, long ld, int dt, float* out, int M, int N, hipStr
 
 int rmcl_text_embed_fwd(const long* ids, const float* word, const float* pos, const float* btype0, const float* g,
                         const float* beta, const float* vtype0, float eps, float* x, float* e_save, float* mean, float* rstd,
-                        int B, int L, int N, int D, hipStream_t s);
+                        int B, int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
+int rmcl_dropout_apply(float* x, long n, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
 int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, float* dpos, float* dbtype0, int B, int L, int D,
                             long pad_id, hipStream_t s);
 int rmcl_gather_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, hipStream_t s);
 int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, int add, hipStream_t s);
 int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos, const float* vtype1, float* x, int B, int P,
-                            int L, int N, int D, hipStream_t s);
+                            int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
 int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,
-                            int N, int D, hipStream_t s);
+                            int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
 int rmcl_im2patch(const float* img, float* pat, int B, int C, int Hh, int Ww, int ps, int to_image, hipStream_t s);
 int rmcl_k_add_cast(const float* a, const float* d1, const float* d2, void* out, int dt, long n, hipStream_t s);
 int rmcl_cast(const float* in, void* out, int dt, long n, hipStream_t s);

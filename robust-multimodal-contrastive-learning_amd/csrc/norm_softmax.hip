@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
                                                      const float* __restrict__ w, const float* __restrict__ b,
                                                      float* __restrict__ dx, long lddx, int add, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int D, int relu,
-                                                     bf16_t* __restrict__ dx_lp) {
+                                                     void* __restrict__ dx_copy, int copy_f32, uint32_t dseed, uint32_t dthresh,
+                                                     float dinv) {
   __shared__ float red[2][4][64 * 4 * LN_MAXV];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 gw[LN_MAXV], gb[LN_MAXV], ww[LN_MAXV], bb[LN_MAXV];
@@ -152,11 +153,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
           o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
         }
         *reinterpret_cast<float4*>(p) = o;
-        if (dx_lp) {   // bf16 copy of the updated residual-stream gradient = A operand of the next dX GEMM
-          uint2 pk;
-          pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
-          pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
-          *reinterpret_cast<uint2*>(dx_lp + (long)row * lddx + c) = pk;
+        if (dx_copy) {   // copy of the updated residual-stream gradient = A operand of the next dX / dW GEMMs,
+                         // already multiplied by the dropout mask of the branch output it flows into
+          if (dthresh) {
+            const uint32_t di = (uint32_t)((long)row * lddx + c);
+            o.x *= drop_scale(dseed, di, dthresh, dinv); o.y *= drop_scale(dseed, di + 1, dthresh, dinv);
+            o.z *= drop_scale(dseed, di + 2, dthresh, dinv); o.w *= drop_scale(dseed, di + 3, dthresh, dinv);
+          }
+          if (copy_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(dx_copy) + (long)row * lddx + c) = o;
+          } else {
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
+            pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(dx_copy) + (long)row * lddx + c) = pk;
+          }
         }
       }
     }
@@ -181,19 +192,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
 int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
                 const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
                 int relu, hipStream_t s) {
-  return rmcl_ln_bwd_lp(dy, lddy, dt_dy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, nullptr, s);
+  return rmcl_ln_bwd_lp(dy, lddy, dt_dy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, nullptr, RMCL_BF16, 0, 0,
+                        1.0f, s);
 }
 
 int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
                    const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
-                   int relu, void* dx_lp, hipStream_t s) {
+                   int relu, void* dx_copy, int copy_dt, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0 && D <= 256 * LN_MAXV && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm bwd: bad D/ld");
   if (M <= 0) return 0;
   dim3 grid(cdiv(M, 4 * LNB_ITERS));
   if (dt_dy == RMCL_F32)
-    RMCL_LAUNCH(ln_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, (bf16_t*)dx_lp);
+    RMCL_LAUNCH(ln_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv);
   else
-    RMCL_LAUNCH(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, (bf16_t*)dx_lp);
+    RMCL_LAUNCH(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

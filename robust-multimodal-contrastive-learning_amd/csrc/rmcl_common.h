@@ -56,6 +56,21 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
   return c + x * 0.39894228040143268f * e;
 }
 
+// Counter-based dropout RNG: keep/scale factor of element `idx` of a dropout site is a pure function of
+// (site seed, idx), so the backward regenerates the forward's mask instead of storing it.
+__host__ __device__ __forceinline__ uint32_t rmcl_rng_hash(uint32_t seed, uint32_t idx) {
+  uint32_t x = idx * 0x9E3779B1u ^ seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t rmcl_site_seed(uint32_t seed, int layer, int site) {
+  return rmcl_rng_hash(seed ^ 0xA511E9B3u, (uint32_t)(layer * 8 + site + 1));
+}
+__device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
+  return rmcl_rng_hash(seed, idx) >= thresh ? inv_keep : 0.f;
+}
+enum { DROP_SITE_PROJ = 0, DROP_SITE_HIDDEN = 1, DROP_SITE_FC2 = 2, DROP_SITE_TEXT = 3, DROP_SITE_IMAGE = 4 };
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

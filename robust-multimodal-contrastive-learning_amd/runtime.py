@@ -114,6 +114,7 @@ class PassBuffers:
         self.nce_ws = u8(lib.rmcl_infonce_ws_bytes(B, I64(eng.num_negative)))
         self.text_ids = None
         self.text_mask = None
+        self.drop = {L.MODE_INFER: (0, 0.0), L.MODE_DATA: (0, 0.0), L.MODE_FULL: (0, 0.0)}
 
 
 class Engine:
@@ -138,6 +139,10 @@ class Engine:
         self.specs = param_specs(cfg, lay)
         self._bufs: Dict[tuple, PassBuffers] = {}
         self.lp_stale = True
+        self.drop_p = float(cfg.get("drop_rate", 0.0))
+        self.dropout_on = False            # set by the module per step (self.training)
+        self.seed_base = int(cfg.get("seed", 0)) + 1
+        self.pass_counter = 0
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.dw_stream = torch.cuda.Stream(device=self.device)
         lib.rmcl_set_side_stream(C.c_void_p(self.dw_stream.cuda_stream))
@@ -215,10 +220,17 @@ class Engine:
     def encoder_forward(self, pb: PassBuffers, key: bool, mode: int, patchesT: torch.Tensor):
         if self.lp_stale:
             self.refresh_shadows()
+        # dropout (reference: live in every train-mode forward incl. the key encoder and the PGD copies, SURVEY
+        # quirk 6): a fresh seed per pass, remembered per stash so the matching backward regenerates the masks
+        self.pass_counter += 1
+        seed = (self.seed_base * 2654435761 + self.pass_counter * 40503) & 0xFFFFFFFF
+        p = self.drop_p if self.dropout_on else 0.0
+        pb.drop[mode] = (seed, p)
         p32, plp = (self.k32, self.k_lp) if key else (self.q32, self.q_lp)
         stash = {L.MODE_INFER: None, L.MODE_DATA: pb.stash_data, L.MODE_FULL: pb.stash_full}[mode]
         check(lib.rmcl_encoder_forward(C.byref(pb.d), mode, P(p32), P(plp), P(pb.text_ids), P(pb.text_mask), P(patchesT),
-                                       P(pb.co_mask), P(stash), P(pb.workspace), P(pb.xn), stream_ptr()), "encoder_forward")
+                                       P(pb.co_mask), P(stash), P(pb.workspace), P(pb.xn), C.c_uint32(seed), F(p), stream_ptr()),
+              "encoder_forward")
 
     def heads_forward(self, pb: PassBuffers, key: bool, want_q: bool = True):
         head = self.k32 if key else self.q32
@@ -240,9 +252,10 @@ class Engine:
 
     def encoder_backward(self, pb: PassBuffers, mode: int, patchesT, dxn, cls_only: bool, dpatches, dtext=None):
         stash = pb.stash_data if mode == L.MODE_DATA else pb.stash_full
+        seed, p = pb.drop[mode]
         check(lib.rmcl_encoder_backward(C.byref(pb.d), mode, P(self.q32), P(self.q_lp), P(pb.text_ids), P(patchesT),
                                         P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), int(cls_only), P(dpatches), P(dtext),
-                                        P(self.g32 if mode == L.MODE_FULL else None), stream_ptr()), "encoder_backward")
+                                        P(self.g32 if mode == L.MODE_FULL else None), C.c_uint32(seed), F(p), stream_ptr()), "encoder_backward")
 
     def pgd_step(self, pb: PassBuffers, lr: float, eps: float):
         per = pb.d.P * pb.d.patch_k

@@ -36,8 +36,6 @@ class ViLTransformerSS(nn.Module):
         super().__init__()
         self.hparams = types.SimpleNamespace(config=config)
         self.config = config
-        if config.get("drop_rate", 0.0) != 0.0:
-            raise NotImplementedError("dropout is not built yet: set drop_rate=0 (SURVEY quirk 6)")
         self.engine = Engine(config, device, compute_dtype, exact)
         eng = self.engine
         self.current_tasks = []
@@ -144,6 +142,7 @@ class ViLTransformerSS(nn.Module):
         if image_token_type_idx != 1:
             raise NotImplementedError("image_token_type_idx != 1 (NLVR2) is outside the RMCL hot path")
         eng = self.engine
+        eng.dropout_on = self.training and eng.drop_p > 0
         text_ids, text_masks = batch["text_ids"], batch["text_masks"]
         pb = eng.bind_batch(text_ids, text_masks, batch["image"][0])
         op = eng.make_operand(pb)
@@ -179,6 +178,7 @@ class ViLTransformerSS(nn.Module):
         return self._infer(batch, True, mask_text, mask_image, image_token_type_idx, image_embeds, image_masks)
 
     def forward(self, batch):
+        self.engine.dropout_on = self.training and self.engine.drop_p > 0
         ret = dict()
         if len(self.current_tasks) == 0:
             ret.update(self.infer(batch))

@@ -261,3 +261,74 @@ def test_text_attack_and_three_view_step_match_oracle():
                  "transformer.patch_embed.proj.weight", "moco_head.projector.3.weight"):
         a, b = params[name].grad.cpu(), p[name].grad
         assert float((a - b).abs().max()) <= 5e-3 * float(b.abs().max()) + 1e-8, name
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_dropout_forward_backward_match_oracle_with_same_masks(dtype):
+    """Dropout (reference default drop_rate=0.1; BertEmbeddings dropout, pos_drop, proj_drop, both Mlp drops).
+    torch's RNG stream cannot be reproduced, so parity is checked the other way round: the HIP path's counter-based
+    masks are materialised (rmcl_dropout_mask_apply) and fed to the oracle as explicit masks; forward AND backward
+    must then agree like the deterministic path does."""
+    import ctypes as C
+    from rmcl_amd import _lib as L
+    from rmcl_amd._lib import lib, check, P, I64, F
+    from rmcl_amd.runtime import stream_ptr
+    pdrop, Bn = 0.25, 3
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=Bn)
+    cfg = task_moco(num_layers=2, num_negative=1024, per_gpu_batchsize=Bn, drop_rate=pdrop, image_view=True, num_gpus=1, num_nodes=1)
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype=dtype)
+    p = O.init_params(ocfg, 3)
+    m.load_state_dict({n: t.to(DEV) for n, t in p.items()}, strict=False)
+    queue = O.init_queue(ocfg, 0)
+    m.proj_queue.copy_(queue.to(DEV))
+    batch = O.synthetic_batch(ocfg, Bn, 4, ragged_text=True)
+    eng = m.engine
+    pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], batch["image"][0])
+    op = eng.make_operand(pb, out=pb.patchesT_full)
+    k = torch.nn.functional.normalize(torch.randn(Bn, 128, generator=torch.Generator().manual_seed(1)), dim=1)
+    pb.k.copy_(k.to(DEV))
+    # eval mode: dropout off -> identical to the deterministic forward
+    eng.dropout_on = False
+    eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)
+    xn_eval = pb.xn.clone()
+    eng.dropout_on = True
+    eng.zero_grads()
+    eng.encoder_forward(pb, key=False, mode=L.MODE_FULL, patchesT=op)
+    seed, pp = pb.drop[L.MODE_FULL]
+    assert pp == pdrop and not torch.equal(pb.xn, xn_eval)
+    eng.heads_forward(pb, key=False)
+    eng.infonce(pb, 1.0 / Bn, want_dq=True)
+    loss = float(pb.loss_sum)
+    eng.heads_backward(pb, pb.dq, None, with_grads=True)
+    dpat = torch.empty_like(pb.patchesT_full)
+    eng.encoder_backward(pb, L.MODE_FULL, op, pb.dcls, cls_only=True, dpatches=dpat)
+    torch.cuda.synchronize()
+
+    def mask(shape, layer, site):
+        x = torch.ones(shape, device=DEV)
+        check(lib.rmcl_dropout_mask_apply(P(x), I64(x.numel()), C.c_uint32(seed), layer, site, F(pdrop), stream_ptr()))
+        return x.cpu()
+    N, D = 185, 768
+    drop = {"text": mask((Bn, 40, D), 0, 3), "image": mask((Bn, 145, D), 0, 4)}
+    for l in range(2):
+        drop[l] = {"proj": mask((Bn, N, D), l, 0), "hidden": mask((Bn, N, 4 * D), l, 1), "fc2": mask((Bn, N, D), l, 2)}
+    keep = float((drop[0]["hidden"] != 0).float().mean())
+    assert abs(keep - (1 - pdrop)) < 5e-3 and abs(float(drop[0]["hidden"].max()) - 1 / (1 - pdrop)) < 1e-6
+    for n, t in p.items():
+        if not n.startswith("k_"):
+            t.requires_grad_(True)
+    img = batch["image"][0].clone().requires_grad_(True)
+    out = O.infer(p, ocfg, batch["text_ids"], batch["text_masks"], img, drop=drop)
+    q = O.l2_normalize(O.moco_head(p, "", out["cls_feats"]))
+    ref = O.infonce_loss(O.infonce_logits(q, k, queue, ocfg["temperature"]))
+    ref.backward()
+    tol_l, tol_g = (1e-3, 5e-3) if dtype == "f32" else (0.5, 0.2)
+    assert abs(loss - float(ref)) < tol_l
+    params = dict(m.named_parameters())
+    for name in ("transformer.blocks.1.mlp.fc2.weight", "transformer.blocks.0.mlp.fc1.weight", "transformer.blocks.0.attn.proj.bias",
+                 "transformer.blocks.0.attn.qkv.weight", "transformer.pos_embed", "transformer.cls_token", "token_type_embeddings.weight",
+                 "text_embeddings.LayerNorm.weight", "text_embeddings.position_embeddings.weight", "transformer.patch_embed.proj.weight"):
+        a, b = params[name].grad.cpu(), p[name].grad
+        assert float((a - b).abs().max()) <= tol_g * float(b.abs().max()) + 1e-8, name
+    g_img = O.patchify(img.grad, 32).reshape(Bn * 144, 3072)
+    assert float((dpat.float().cpu() - g_img).abs().max()) <= tol_g * float(g_img.abs().max()) + 1e-9
