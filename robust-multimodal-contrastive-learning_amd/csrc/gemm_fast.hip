@@ -309,8 +309,15 @@ static int launch_fast(const GemmArgs& g, int dt_out, hipStream_t s) {
   return 0;
 }
 
+bool rmcl_gemm_big_supported(const GemmArgs& g, int a_kc, int b_kc);
+int rmcl_launch_gemm_big(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s);
+
 int rmcl_launch_gemm_fast(const GemmArgs& g0, int dt_out, int a_kc, int b_kc, hipStream_t s) {
   GemmArgs g = g0;
+  // 256x256 tiles where they measure faster (MI355X, M = 11840): narrow outputs with a long reduction
+  const bool big_wins = a_kc && g.splitk <= 1 && g.N <= 1024 && g.K >= 2048 && cdiv(g.M, 256) * (g.N / 256) >= 128;
+  if ((g_gemm_cfg == 30 || (g_gemm_cfg < 0 && big_wins)) && rmcl_gemm_big_supported(g, a_kc, b_kc))
+    return rmcl_launch_gemm_big(g, dt_out, a_kc, b_kc, s);
   if (g_gemm_cfg == 10) g.tag |= 1 << 30;
   if (g_gemm_cfg == 11) g.tag |= 1 << 29;
   if (g.splitk > 1) {                                          // no empty K slices (the k-tile stream assumes nk >= 1)

@@ -84,7 +84,9 @@ int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float 
 // in registers over LNB_ITERS rows, then across the 4 waves through LDS, then one atomic per column.
 // ---------------------------------------------------------------------------------------------
 #define LNB_ITERS 8
-template <typename TG>
+// WG: accumulate dgamma/dbeta (weight-gradient backward only); RELU: mask dy with the ReLU after the LN (MoCo head).
+// The data-gradient-only instantiation (PGD backward, 3/4 of all calls) carries 32 fewer accumulator registers.
+template <typename TG, bool WG, bool RELU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const float* __restrict__ b,
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
     const int c = (lane + 64 * i) * 4;
     if (c < D) {
       ww[i] = *reinterpret_cast<const float4*>(w + c);
-      bb[i] = relu ? *reinterpret_cast<const float4*>(b + c) : make_float4(0, 0, 0, 0);
+      bb[i] = RELU ? *reinterpret_cast<const float4*>(b + c) : make_float4(0, 0, 0, 0);
     }
   }
   for (int it = 0; it < LNB_ITERS; ++it) {
@@ -126,14 +128,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
           d[2] = __uint_as_float(t.y << 16); d[3] = __uint_as_float(t.y & 0xffff0000u);
         }
         xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-        if (relu) {
+        if (RELU) {
           if (xh[i].x * ww[i].x + bb[i].x <= 0.f) d[0] = 0.f;
           if (xh[i].y * ww[i].y + bb[i].y <= 0.f) d[1] = 0.f;
           if (xh[i].z * ww[i].z + bb[i].z <= 0.f) d[2] = 0.f;
           if (xh[i].w * ww[i].w + bb[i].w <= 0.f) d[3] = 0.f;
         }
-        gb[i].x += d[0]; gb[i].y += d[1]; gb[i].z += d[2]; gb[i].w += d[3];
-        gw[i].x += d[0] * xh[i].x; gw[i].y += d[1] * xh[i].y; gw[i].z += d[2] * xh[i].z; gw[i].w += d[3] * xh[i].w;
+        if (WG) {
+          gb[i].x += d[0]; gb[i].y += d[1]; gb[i].z += d[2]; gb[i].w += d[3];
+          gw[i].x += d[0] * xh[i].x; gw[i].y += d[1] * xh[i].y; gw[i].z += d[2] * xh[i].z; gw[i].w += d[3] * xh[i].w;
+        }
         g[i] = make_float4(d[0] * ww[i].x, d[1] * ww[i].y, d[2] * ww[i].z, d[3] * ww[i].w);
         s1 += g[i].x + g[i].y + g[i].z + g[i].w;
         s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
       }
     }
   }
-  if (dgamma) {
+  if (WG && dgamma) {
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = (lane + 64 * i) * 4;
@@ -202,10 +206,18 @@ int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ld
   RMCL_REQUIRE(D % 4 == 0 && D <= 256 * LN_MAXV && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm bwd: bad D/ld");
   if (M <= 0) return 0;
   dim3 grid(cdiv(M, 4 * LNB_ITERS));
-  if (dt_dy == RMCL_F32)
-    RMCL_LAUNCH(ln_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv);
-  else
-    RMCL_LAUNCH(ln_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv);
+#define LN_BWD_LAUNCH(TG, WGv, RLv) \
+  RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
+              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv)
+  const bool wg = dgamma != nullptr;
+  if (dt_dy == RMCL_F32) {
+    if (relu) { if (wg) LN_BWD_LAUNCH(float, true, true); else LN_BWD_LAUNCH(float, false, true); }
+    else { if (wg) LN_BWD_LAUNCH(float, true, false); else LN_BWD_LAUNCH(float, false, false); }
+  } else {
+    if (relu) { if (wg) LN_BWD_LAUNCH(bf16_t, true, true); else LN_BWD_LAUNCH(bf16_t, false, true); }
+    else { if (wg) LN_BWD_LAUNCH(bf16_t, true, false); else LN_BWD_LAUNCH(bf16_t, false, false); }
+  }
+#undef LN_BWD_LAUNCH
   RMCL_CHECK_LAUNCH();
   return 0;
 }
