@@ -156,7 +156,9 @@ def main():
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / elapsed
-        step_flops = (5 + 2 * K) * F_PER_PAIR * B               # algorithmic, per GPU per step
+        # algorithmic FLOPs per GPU per step: SURVEY 8(d) counts (5+2K)F; with dropout off the clean query forward
+        # and PGD step 0's forward are the same computation and run once -> (4+2K)F are executed and credited
+        step_flops = ((4 if args.drop_rate == 0 else 5) + 2 * K) * F_PER_PAIR * B
         kern_tf = (fl.value / max(n.value, 1)) / (ms.value / max(n.value, 1) * 1e-3) / 1e12 if n.value else 0.0
         out = {
             "metric": "image-text pairs/sec, ViLT-B/32 RMCL step (PGD K=3)", "value": round(value, 2), "unit": "pairs/s",

@@ -25,14 +25,19 @@ class PGDAttack_moco(PGDAttack):
     def __init__(self, config):
         super().__init__(config, "moco")
 
-    def attack_patches(self, pl_module, pb, k: torch.Tensor):
+    def attack_patches(self, pl_module, pb, k, before_first_loss=None, clean_out=None):
         """K-step attack in patch layout.  Leaves delta_K in ``pb.delta`` and delta_{K-1} in
-        ``pb.delta_prev`` (needed for the reference's attacked view, see compute_pgd)."""
+        ``pb.delta_prev`` (needed for the reference's attacked view, see compute_pgd).
+
+        ``before_first_loss``: callback run once between the first encoder forward and the first InfoNCE (the
+        caller joins the key-encoder stream there).  ``clean_out``: dict that receives the clean-query statistics:
+        step 0 evaluates the query encoder at img + delta_0 = img, i.e. it IS the clean forward of
+        objectives.py:267-275, so that forward is not computed twice when dropout is off."""
         eng = pl_module.engine
         K = self.adv_steps_img
         pb.delta.zero_()                                      # pgd_attack_vilt.py:136
         pb.delta_prev.zero_()
-        if k.data_ptr() != pb.k.data_ptr():
+        if k is not None and k.data_ptr() != pb.k.data_ptr():
             pb.k.copy_(k)
         for step in range(K):
             if step == K - 1 and K > 1:
@@ -40,8 +45,13 @@ class PGDAttack_moco(PGDAttack):
             op = eng.make_operand(pb, pb.delta)               # img_init + img_delta (:144)
             eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
             eng.heads_forward(pb, key=False)
+            if step == 0 and before_first_loss is not None:
+                before_first_loss()
             # CE(label 0) / K, mean over the batch (:152-158); gradient wrt q only
             eng.infonce(pb, grad_scale=1.0 / (pb.B * K), want_dq=True)
+            if step == 0 and clean_out is not None:
+                clean_out["prediction"] = pb.rows[:, 1].clone()
+                clean_out["q"] = pb.q.clone()
             eng.heads_backward(pb, pb.dq, None, with_grads=False)
             eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=pb.gpatch)
             eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img)   # :162-173

@@ -199,15 +199,26 @@ def compute_moco_contrastive(pl_module, batch):
     with torch.cuda.stream(side):
         eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op)
         eng.heads_forward(pk, key=True)
-    eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)     # clean query
-    eng.heads_forward(pb, key=False)
-    main.wait_stream(side)
-    pb.k.copy_(pk.k)
+    gather_box = {}
+
+    def join_key_stream():
+        main.wait_stream(side)
+        pb.k.copy_(pk.k)
+        # asynchronous key all-gather (RCCL's own stream): overlaps everything until the enqueue
+        gather_box["g"] = dist_utils.KeyGather(pb.k.clone()) if pl_module.training else None
+
     k = pb.k
-    gather = dist_utils.KeyGather(k.clone()) if pl_module.training else None   # overlaps everything below
-    eng.infonce(pb, 0.0, want_dq=False)
-    prediction_original = pb.rows[:, 1].clone()
-    ret["q_original"] = pb.q.clone()
+    # PGD step 0 runs the query encoder on img + delta_0 = img: with dropout off that IS the clean query forward
+    # (:267-275), so it is computed once (common sub-expression) and its logits give prediction_original.
+    fuse_clean = pl_module.image_view and not pl_module.text_view and not eng.dropout_on
+    clean = {}
+    if not fuse_clean:
+        eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)     # clean query
+        eng.heads_forward(pb, key=False)
+        join_key_stream()
+        eng.infonce(pb, 0.0, want_dq=False)
+        clean = {"prediction": pb.rows[:, 1].clone(), "q": pb.q.clone()}
+    prediction_original = clean.get("prediction")
 
     loss = 0
     loss_num = 0
@@ -222,7 +233,11 @@ def compute_moco_contrastive(pl_module, batch):
         loss = loss + loss_t
         loss_num += 1
     if pl_module.image_view:                                                # :319-354
-        pl_module.pgd_attacker.attack_patches(pl_module, pb, k)            # compute_pgd (:319-323)
+        if fuse_clean:
+            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, before_first_loss=join_key_stream, clean_out=clean)
+            prediction_original = clean["prediction"]
+        else:
+            pl_module.pgd_attacker.attack_patches(pl_module, pb, k)        # compute_pgd (:319-323)
         check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3,
                                           pb.d.patch_k // 3, stream_ptr()), "delta_norm")
         pl_module.log(f"moco_attack/{phase}/delta", _scalar(pb.loss_sum / float(pb.delta.numel() // 3)))
@@ -243,7 +258,7 @@ def compute_moco_contrastive(pl_module, batch):
         loss_num += 1
 
     if pl_module.training:                                                  # _dequeue_and_enqueue (:394-395)
-        keys_all = gather.wait()
+        keys_all = gather_box["g"].wait()
         do, new_ptr = dist_utils.queue_advance(pl_module.queue_ptr, keys_all.shape[0], pl_module.num_negative,
                                                pl_module.per_step_bs)
         if do:
@@ -252,6 +267,7 @@ def compute_moco_contrastive(pl_module, batch):
 
     ret["moco_loss"] = loss / loss_num
     ret["k"] = k.clone()
+    ret["q_original"] = clean["q"]
     pl_module.log(f"moco_loss/step/{phase}", ret["moco_loss"].detach())
     views = (["img"] if pl_module.image_view else []) + (["txt"] if pl_module.text_view else []) + \
             (["both"] if pl_module.image_view and pl_module.text_view else [])

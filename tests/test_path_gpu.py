@@ -332,3 +332,31 @@ def test_dropout_forward_backward_match_oracle_with_same_masks(dtype):
         assert float((a - b).abs().max()) <= tol_g * float(b.abs().max()) + 1e-8, name
     g_img = O.patchify(img.grad, 32).reshape(Bn * 144, 3072)
     assert float((dpat.float().cpu() - g_img).abs().max()) <= tol_g * float(g_img.abs().max()) + 1e-9
+
+
+def test_short_training_run_reduces_loss_and_keeps_state_consistent():
+    """End-to-end: 12 optimizer steps (bf16, fused AdamW, EMA, enqueue) on a fixed synthetic batch: the loss falls,
+    everything stays finite, the momentum encoder trails the query encoder, the queue pointer wraps as in the reference."""
+    ocfg = O.default_config(num_layers=2, num_negative=256, per_gpu_batchsize=32, adv_steps_img=1)
+    cfg = task_moco(num_layers=2, num_negative=256, per_gpu_batchsize=32, adv_steps_img=1, drop_rate=0.0, image_view=True,
+                    num_gpus=1, num_nodes=1, learning_rate=2e-4, warmup_steps=2, max_steps=100)
+    torch.manual_seed(0)
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype="bf16")
+    m.train()
+    (opt,), (sched,) = m.configure_optimizers()
+    batch = dev_batch(O.synthetic_batch(ocfg, 32, 3))
+    losses = []
+    for i in range(12):
+        loss = m.training_step(batch, i)
+        loss.backward()
+        opt.step()
+        sched["scheduler"].step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0] - 0.5, losses
+    assert m.queue_ptr == (12 * 32) % 256                                   # 256 % 32 == 0: wraps cleanly
+    e = m.engine
+    diff = float((e.q32[: e.layout.ema_end] - e.k32).abs().max())
+    assert 0 < diff < 0.1                                                   # k trails q (m = 0.999), never equal after updates
+    assert torch.equal(e.q_lp.float()[:1000], e.q32[:1000].to(torch.bfloat16).float())   # bf16 shadow refreshed by AdamW
