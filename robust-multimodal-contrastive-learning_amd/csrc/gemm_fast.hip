@@ -309,11 +309,20 @@ static int launch_fast(const GemmArgs& g, int dt_out, hipStream_t s) {
   return 0;
 }
 
+int rmcl_launch_gemm_pp(const GemmArgs& g, int dt_out, hipStream_t s);
+int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s);
+double rmcl_gemm_st_fill(const GemmArgs& g);
+bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc);
+bool rmcl_gemm_pp_supported(const GemmArgs& g, int a_kc, int b_kc);
 bool rmcl_gemm_big_supported(const GemmArgs& g, int a_kc, int b_kc);
 int rmcl_launch_gemm_big(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s);
 
 int rmcl_launch_gemm_fast(const GemmArgs& g0, int dt_out, int a_kc, int b_kc, hipStream_t s) {
   GemmArgs g = g0;
+  // 192x192 ping-pong tiles for the activation GEMMs (M = B*185 rows) whenever they fill the CU rounds
+  if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc))
+    return rmcl_launch_gemm_st(g, dt_out, b_kc, s);
+  if (g_gemm_cfg == 50 && rmcl_gemm_pp_supported(g, a_kc, b_kc)) return rmcl_launch_gemm_pp(g, dt_out, s);
   // 256x256 tiles where they measure faster (MI355X, M = 11840): narrow outputs with a long reduction
   const bool big_wins = a_kc && g.splitk <= 1 && g.N <= 1024 && g.K >= 2048 && cdiv(g.M, 256) * (g.N / 256) >= 128;
   if ((g_gemm_cfg == 30 || (g_gemm_cfg < 0 && big_wins)) && rmcl_gemm_big_supported(g, a_kc, b_kc))

@@ -1,0 +1,273 @@
+// bf16 MFMA GEMM with 192x192x64 block tiles, one workgroup (8 waves) per CU, three 48 KiB LDS stages.
+//
+// Why this tile: the activations of one RMCL step have M = B * 185 rows (185 tokens per sample) and N = 768,
+// 2304 or 3072 = 4, 12, 16 x 192 columns.  With `rows_per_tile` = 185 (each row tile = one sample, 7 of the 192
+// tile rows idle) B = 64 gives 64 x {4, 12, 16} = 256, 768, 1024 tiles = exactly 1, 3, 4 rounds over the 256 CUs,
+// where 128x128 / 256x256 tiles leave 13-45 % of the chip idle in the last round.
+//
+// Schedule ("ping-pong", cf. gemm_pp.hip): waves 0-3 (group 0, wave rows 0..95) and waves 4-7 (group 1, rows
+// 96..191) run half a phase apart - group 1 executes one extra s_barrier first - so that one group's 18-MFMA
+// cluster overlaps the other's 9 ds_read_b128 + LDS-DMA issue.  A k-tile is two phases (k-steps of 32):
+//     P1: read fragments of k-step 0;                          barrier, 18 MFMA, barrier
+//     P2: read fragments of k-step 1; stage tile t+2 (6 LDS-DMA per wave) into stage (t+2)%3, whose last read was
+//         (t-1,P2) two phases earlier; s_waitcnt vmcnt(6) -> tile t+1 has landed, first read one phase later.
+// Barriers are raw s_barrier, so the DMA of tile t+2 stays in flight across them.
+#include "rmcl_common.h"
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+#define ST_T 192
+#define ST_OP_BYTES (ST_T * 128)            // one operand tile: 192 rows x 64 bf16 = 24 KiB
+#define ST_STAGE (2 * ST_OP_BYTES)          // 48 KiB
+#define ST_LDS (3 * ST_STAGE)               // 144 KiB
+
+template <int N>
+__device__ __forceinline__ void st_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one operand tile = 24 wave-instructions of 1 KiB; this wave issues instructions wave*3 .. wave*3+2
+// (koff = uniform element offset of the k-tile: k0 for a [rows][K] operand, k0 * ld for a [K][cols] operand)
+__device__ __forceinline__ void st_stage_op(const bf16_t* base, const uint32_t (&off)[3], long koff, char* lds_op, int wave) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + koff + off[q]), (lds_void*)(lds_op + (wave * 3 + q) * 1024), 16, 0, 0);
+}
+
+// B stored [K][N] (n contiguous): LDS image [64 k][384 B]; the 32-byte column chunk c of k-row k sits at chunk c ^ g(k),
+// g(k) = bit1(k) | bit3(k) << 1.  With 384-byte rows the bank of a row start alternates 0 / 32 with k & 1, so the eight
+// 32-byte pieces one half-wave of ds_read_b64_tr_b16 touches (k-rows q, q+8; q = 0..3) land on eight different 8-bank sets.
+__device__ __forceinline__ int st_gk(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 st_ld_b(const char* lds_b, int off, int s) {
+  if (KC) {
+    return *reinterpret_cast<const bf16x8*>(lds_b + off);          // (off already holds the k-step swizzle)
+  } else {
+    union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_b + off + s * (32 * 384) + h * (4 * 384)));
+    return u.v;
+  }
+}
+
+#define ST_PHASE_BEGIN()                                  \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_setprio(1)
+#define ST_PHASE_END()                                    \
+  __builtin_amdgcn_s_setprio(0);                          \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  __builtin_amdgcn_sched_barrier(0)
+
+struct STCtx {
+  const bf16_t* A;
+  const bf16_t* B;
+  uint32_t oa[3], ob[3];
+  int aoff[2], boff[2], boffj[3];
+  long kstep_b;                   // element stride of one k-tile in B: 64 ([N][K]) or 64 * ldb ([K][N])
+  int wave;
+};
+
+// MODE 0: steady state (stage tile t+2, vmcnt(6)); 1: second-to-last tile (no stage, vmcnt(0)); 2: last tile (no stage, no wait)
+template <int MODE, bool B_KC>
+__device__ __forceinline__ void st_tile(f32x4 (&acc)[6][3], const STCtx& c, const char* cur, char* nxt2, int t2) {
+  bf16x8 a[6], b[3];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) b[j] = B_KC ? st_ld_b<true>(cur + ST_OP_BYTES, j * 2048 + c.boff[s], s) : st_ld_b<false>(cur + ST_OP_BYTES, c.boffj[j], s);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cur + i * 2048 + c.aoff[s]);
+    if (s == 1) {
+      if (MODE == 0) {
+        st_stage_op(c.A, c.oa, (long)t2 * 64, nxt2, c.wave);
+        st_stage_op(c.B, c.ob, (long)t2 * c.kstep_b, nxt2 + ST_OP_BYTES, c.wave);
+        st_wait_vm<6>();
+      } else if (MODE == 1) {
+        st_wait_vm<0>();
+      }
+    }
+    ST_PHASE_BEGIN();
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    ST_PHASE_END();
+  }
+}
+
+template <bool B_KC, typename TO>
+__global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tr = bid / tiles_n, tc = bid - tr * tiles_n;
+  const int m0 = tr * rows_per_tile, n0 = tc * ST_T;
+  const int m_end = min(g.M, m0 + rows_per_tile);
+  const int nk = g.K / 64;
+
+  STCtx c;
+  c.A = reinterpret_cast<const bf16_t*>(g.A);
+  c.B = reinterpret_cast<const bf16_t*>(g.B);
+  c.wave = wave;
+  c.kstep_b = B_KC ? 64 : 64 * g.ldb;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int row = (wave * 3 + q) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    c.oa[q] = (uint32_t)min(m0 + row, g.M - 1) * (uint32_t)g.lda + chunk * 8;
+    if (B_KC) {
+      c.ob[q] = (uint32_t)min(n0 + row, g.N - 1) * (uint32_t)g.ldb + chunk * 8;
+    } else {
+      const int lin = (wave * 3 + q) * 64 + lane;            // 16-byte chunk index in the [64][24] image
+      const int k = lin / 24, c16 = (lin - k * 24) ^ (st_gk(k) << 1);
+      c.ob[q] = (uint32_t)k * (uint32_t)g.ldb + n0 + c16 * 8;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int sw = ((4 * s + (lane >> 4)) ^ (lane & 7)) * 16;
+    c.aoff[s] = (wm * 96 + (lane & 15)) * 128 + sw;
+    c.boff[s] = (wn * 48 + (lane & 15)) * 128 + sw;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int k = 8 * (lane >> 4) + q;                       // + 32 s + 4 h: neither changes g(k)
+    const int c8 = (wn * 48 + j * 16) / 4 + p;
+    c.boffj[j] = k * 384 + (((c8 >> 1) ^ (st_gk(k) << 1)) * 16) + (c8 & 1) * 8;
+  }
+
+  f32x4 acc[6][3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: tiles 0 and 1
+  st_stage_op(c.A, c.oa, 0, smem, wave);
+  st_stage_op(c.B, c.ob, 0, smem + ST_OP_BYTES, wave);
+  st_stage_op(c.A, c.oa, 64, smem + ST_STAGE, wave);
+  st_stage_op(c.B, c.ob, c.kstep_b, smem + ST_STAGE + ST_OP_BYTES, wave);
+  st_wait_vm<6>();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wm == 1) __builtin_amdgcn_s_barrier();                 // skew: group 1 runs one barrier behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  int sc = 0, sn = 2;                                        // stage of tile it / of tile it+2
+  int it = 0;
+  for (; it + 2 < nk; ++it) {
+    st_tile<0, B_KC>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, it + 2);
+    sc = sc == 2 ? 0 : sc + 1;
+    sn = sn == 2 ? 0 : sn + 1;
+  }
+  st_tile<1, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+  sc = sc == 2 ? 0 : sc + 1;
+  st_tile<2, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+
+  // epilogue (order: alpha, bias, gelu'(aux), save pre-activation, gelu, residual, accumulate; as gemm_fast.hip)
+  const int epi = g.epi;
+  TO* C = reinterpret_cast<TO*>(g.C);
+  TO* C2 = reinterpret_cast<TO*>(g.C2);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int m = m0 + wm * 96 + i * 16 + (lane & 15);
+    if (m >= m_end) continue;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int n = n0 + wn * 48 + j * 16 + 4 * (lane >> 4);
+      float v[4] = {g.alpha * acc[i][j][0], g.alpha * acc[i][j][1], g.alpha * acc[i][j][2], g.alpha * acc[i][j][3]};
+      if (epi & EPI_BIAS) {
+        const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (epi & EPI_DGELU) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ld_aux + n);
+        v[0] *= gelu_fast_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_fast_grad(__uint_as_float(u.x & 0xffff0000u));
+        v[2] *= gelu_fast_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_fast_grad(__uint_as_float(u.y & 0xffff0000u));
+      }
+      const long ci = (long)m * g.ldc + n;
+      if (epi & EPI_SAVE_PREACT) {
+        if constexpr (sizeof(TO) == 2) {
+          uint2 pk;
+          pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(C2 + ci) = pk;
+        } else {
+          *reinterpret_cast<float4*>(C2 + ci) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      if (epi & EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      }
+      if (epi & EPI_RESIDUAL) {
+        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + (long)m * g.ld_aux + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      if constexpr (sizeof(TO) == 2) {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(C + ci) = pk;
+      } else {
+        if (epi & EPI_ACCUM) {
+          const float4 o = *reinterpret_cast<const float4*>(C + ci);
+          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
+        *reinterpret_cast<float4*>(C + ci) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
+  if (!a_kc || g.splitk > 1 || g.nb1 > 1 || g.nb2 > 1) return false;
+  if (g.N % ST_T != 0 || g.K % 64 != 0 || g.K < 128) return false;
+  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_ACCUM)) return false;
+  if ((long)g.M * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
+  return true;
+}
+
+// how full the CU rounds of a launch are (1 = every round uses all 256 CUs)
+double rmcl_gemm_st_fill(const GemmArgs& g) {
+  const long tiles = (long)cdiv(g.M, ST_T) * (g.N / ST_T);
+  return (double)tiles / (double)(cdiv(tiles, 256L) * 256L);
+}
+
+template <bool B_KC>
+static int launch_st(const GemmArgs& g, int dt_out, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<B_KC, float>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<B_KC, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    attr = true;
+  }
+  // a tile costs the same whether 185 or 192 of its rows are live, so the fewest row tiles win; they share M evenly
+  const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = cdiv(g.M, tm);
+  if (dt_out == RMCL_F32) RMCL_LAUNCH((gemm_st_kernel<B_KC, float>), dim3(tm * tn), dim3(512), ST_LDS, s, g, tm, tn, rows);
+  else RMCL_LAUNCH((gemm_st_kernel<B_KC, bf16_t>), dim3(tm * tn), dim3(512), ST_LDS, s, g, tm, tn, rows);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s) {
+  return b_kc ? launch_st<true>(g, dt_out, s) : launch_st<false>(g, dt_out, s);
+}

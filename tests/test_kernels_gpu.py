@@ -222,8 +222,8 @@ def test_im2patch_roundtrip():
 
 
 # ------------------------------------------------------------------ bf16 MFMA GEMM (fast path)
-@pytest.mark.parametrize("cfg", [-1, 1, 30])
-@pytest.mark.parametrize("shape", [(11840, 768, 768), (300, 128, 64), (1000, 3072, 768), (256, 768, 3072)])
+@pytest.mark.parametrize("cfg", [-1, 1, 30, 60])
+@pytest.mark.parametrize("shape", [(11840, 768, 768), (300, 128, 64), (1000, 3072, 768), (256, 768, 3072), (555, 192, 128), (9216, 2304, 192)])
 def test_gemm_fast_bf16_layouts(shape, cfg):
     """exact=0 routes to the glds/tr-read MFMA kernel; reference = fp64 matmul of the same bf16 inputs,
     tolerance = fp32 accumulation-order noise only (products of bf16 are exact in fp32)."""
@@ -259,6 +259,33 @@ def test_gemm_fast_epilogues_match_exact_kernel():
             a, f = (a, f) if isinstance(a, tuple) else ((a,), (f,))
             for x, y in zip(a, f):
                 assert rel_err(y, x) < (2e-5 if dto == L.F32 else 1e-2)
+
+
+@pytest.mark.parametrize("b_kc", [1, 0])
+def test_gemm_sample_tile_epilogues_match_exact_kernel(b_kc):
+    """The 192x192 ping-pong kernel (tune cfg 60; rows per tile 185 for M = 2 * 185 + 7) against the exact-f32 kernel."""
+    M, N, K = 377, 384, 320
+    X, W, b = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2, scale=0.1).to(torch.bfloat16), rnd(N, seed=3)
+    Wm = W if b_kc else W.t().contiguous()
+    R = rnd(M, N, seed=4)
+    U = rnd(M, N, seed=6).to(torch.bfloat16)
+    base = rnd(M, N, seed=7)
+    cases = [(1, dict(bias=b)), (1 | 2 | 4, dict(bias=b, want_c2=True)), (1 | 8, dict(bias=b, aux=R, ld_aux=N)), (16, dict(aux=U, ld_aux=N))]
+    try:
+        for epi, kw in cases:
+            for dto in (L.F32, L.BF16):
+                lib.rmcl_tune_set(0, -1)
+                a = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, dto, epi=epi, exact=1, **kw)
+                lib.rmcl_tune_set(0, 60)
+                f = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, dto, epi=epi, exact=0, **kw)
+                a, f = (a, f) if isinstance(a, tuple) else ((a,), (f,))
+                for x, y in zip(a, f):
+                    assert rel_err(y, x) < (2e-5 if dto == L.F32 else 1e-2), (epi, dto)
+        lib.rmcl_tune_set(0, 60)
+        out = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, L.F32, exact=0, epi=64, C_init=base)           # accumulate
+        assert rel_err(out, X.double() @ W.double().t() + base.double()) < 2e-5
+    finally:
+        lib.rmcl_tune_set(0, -1)
 
 
 def test_gemm_skinny_heads_shapes():
