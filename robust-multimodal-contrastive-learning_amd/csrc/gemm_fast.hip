@@ -274,7 +274,11 @@ int rmcl_slab_reduce(const float* slab, float* out, long n, int nz, hipStream_t 
 
 // cfg (rmcl_tune_set key 0): persistent grid size in workgroups per CU (default 2); 10 / 11 = ablations
 static int g_gemm_cfg = -1;
-void rmcl_gemm_fast_set_cfg(int cfg) { g_gemm_cfg = cfg; }
+extern int g_st_xflags;
+void rmcl_gemm_fast_set_cfg(int cfg) {
+  if (cfg > 60 && cfg < 70) { g_st_xflags = cfg - 60; cfg = 60; } else { g_st_xflags = 0; }
+  g_gemm_cfg = cfg;
+}
 
 bool rmcl_gemm_fast_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc) {
   if (dt_in != RMCL_BF16) return false;

@@ -1,4 +1,4 @@
-// bf16 MFMA GEMM with 192x192x64 block tiles, one workgroup (8 waves) per CU, three 48 KiB LDS stages.
+// bf16 MFMA GEMM with 192x192x64 block tiles, one PERSISTENT workgroup (8 waves) per CU, three 48 KiB LDS stages.
 //
 // Why this tile: the activations of one RMCL step have M = B * 185 rows (185 tokens per sample) and N = 768,
 // 2304 or 3072 = 4, 12, 16 x 192 columns.  With `rows_per_tile` = 185 (each row tile = one sample, 7 of the 192
@@ -12,6 +12,10 @@
 //     P2: read fragments of k-step 1; stage tile t+2 (6 LDS-DMA per wave) into stage (t+2)%3, whose last read was
 //         (t-1,P2) two phases earlier; s_waitcnt vmcnt(6) -> tile t+1 has landed, first read one phase later.
 // Barriers are raw s_barrier, so the DMA of tile t+2 stays in flight across them.
+//
+// Persistence: a workgroup walks its output tiles (round r: tile r * grid + xcd-aware slot) as ONE stream of k-tiles -
+// the last two k-tiles of an output tile already stage the first two k-tiles of the next one, so the epilogue
+// (bias / GELU / residual / stores) of tile n runs while the operands of tile n+1 land.
 #include "rmcl_common.h"
 #include "kernels.h"
 
@@ -77,7 +81,7 @@ struct STCtx {
 };
 
 // MODE 0: steady state (stage tile t+2, vmcnt(6)); 1: second-to-last tile (no stage, vmcnt(0)); 2: last tile (no stage, no wait)
-template <int MODE, bool B_KC>
+template <int MODE, bool B_KC, int W = 6>
 __device__ __forceinline__ void st_tile(f32x4 (&acc)[6][3], const STCtx& c, const char* cur, char* nxt2, int t2) {
   bf16x8 a[6], b[3];
 #pragma unroll
@@ -90,7 +94,7 @@ __device__ __forceinline__ void st_tile(f32x4 (&acc)[6][3], const STCtx& c, cons
       if (MODE == 0) {
         st_stage_op(c.A, c.oa, (long)t2 * 64, nxt2, c.wave);
         st_stage_op(c.B, c.ob, (long)t2 * c.kstep_b, nxt2 + ST_OP_BYTES, c.wave);
-        st_wait_vm<6>();
+        st_wait_vm<W>();
       } else if (MODE == 1) {
         st_wait_vm<0>();
       }
@@ -104,21 +108,127 @@ __device__ __forceinline__ void st_tile(f32x4 (&acc)[6][3], const STCtx& c, cons
   }
 }
 
-template <bool B_KC, typename TO>
-__global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile) {
+enum { ST_AUX_NONE = 0, ST_AUX_RES = 1, ST_AUX_DGELU = 2 };
+
+struct STTile {
+  uint32_t oa[3], ob[3];
+  int m0, n0, m_end;
+};
+
+// tile of workgroup b in round r (grid G workgroups, T tiles): slots of one XCD (b & 7) are consecutive tile ids
+__device__ __forceinline__ int st_tile_id(int b, int r, int G, int T) {
+  const int n_r = min(G, T - r * G);
+  if (n_r <= 0) return -1;
+  const int x = b & 7, s = b >> 3, q = n_r >> 3, e = n_r & 7;
+  if (s >= q + (x < e ? 1 : 0)) return -1;
+  return r * G + (x < e ? x * (q + 1) : e * (q + 1) + (x - e) * q) + s;
+}
+
+template <bool B_KC>
+__device__ __forceinline__ void st_tile_setup(STTile& T, const GemmArgs& g, int id, int tiles_m, int tiles_n, int rows_per_tile, int wave, int lane,
+                                              int xflags) {
+  // tile order: bands of 4 column tiles, row tiles inside a band, the band's 4 column tiles innermost - the 32 consecutive
+  // tiles one XCD works on in a round are 8 A panels x 4 B panels (12 x 192 x K x 2 B: fits its 4 MiB L2 for K = 768)
+  int tr, tc;
+  if (!(xflags & 2) && tiles_n % 4 == 0) {
+    const int band = id / (tiles_m * 4), rem = id - band * (tiles_m * 4);
+    tr = rem >> 2;
+    tc = band * 4 + (rem & 3);
+  } else {
+    tr = id / tiles_n;
+    tc = id - tr * tiles_n;
+  }
+  T.m0 = tr * rows_per_tile;
+  T.n0 = tc * ST_T;
+  T.m_end = min(g.M, T.m0 + rows_per_tile);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int row = (wave * 3 + q) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    T.oa[q] = (uint32_t)min(T.m0 + row, g.M - 1) * (uint32_t)g.lda + chunk * 8;
+    if (B_KC) {
+      T.ob[q] = (uint32_t)min(T.n0 + row, g.N - 1) * (uint32_t)g.ldb + chunk * 8;
+    } else {
+      const int lin = (wave * 3 + q) * 64 + lane;            // 16-byte chunk index in the [64][24] image
+      const int k = lin / 24, c16 = (lin - k * 24) ^ (st_gk(k) << 1);
+      T.ob[q] = (uint32_t)k * (uint32_t)g.ldb + T.n0 + c16 * 8;
+    }
+  }
+}
+
+template <typename TO>
+__device__ __forceinline__ void st_store4(TO* p, const float (&v)[4]) {
+  if constexpr (sizeof(TO) == 2) {
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = pk;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// epilogue (order: alpha, bias, gelu'(aux), save pre-activation, gelu, residual, accumulate; as gemm_fast.hip).  All
+// loads of the tile are issued first (rows past the tile end read a clamped row), only the stores are predicated.
+template <int AUX, typename TO>
+__device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const GemmArgs& g, const STTile& T, int wm, int wn, int lane) {
+  const int epi = g.epi;
+  TO* C = reinterpret_cast<TO*>(g.C);
+  TO* C2 = reinterpret_cast<TO*>(g.C2);
+  const int nb = T.n0 + wn * 48 + 4 * (lane >> 4);
+  const int mb = T.m0 + wm * 96 + (lane & 15);
+  float4 bias[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 res[AUX == ST_AUX_RES ? 6 : 1][3];
+  uint2 pre[AUX == ST_AUX_DGELU ? 6 : 1][3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const long mr = min(mb + i * 16, g.M - 1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (AUX == ST_AUX_RES) res[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+      if (AUX == ST_AUX_DGELU) pre[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int m = mb + i * 16;
+    const bool live = m < T.m_end;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float v[4] = {g.alpha * acc[i][j][0] + bias[j].x, g.alpha * acc[i][j][1] + bias[j].y, g.alpha * acc[i][j][2] + bias[j].z,
+                    g.alpha * acc[i][j][3] + bias[j].w};
+      if (AUX == ST_AUX_DGELU) {
+        const uint2 u = pre[i][j];
+        v[0] *= gelu_fast_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_fast_grad(__uint_as_float(u.x & 0xffff0000u));
+        v[2] *= gelu_fast_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_fast_grad(__uint_as_float(u.y & 0xffff0000u));
+      }
+      const long ci = (long)m * g.ldc + nb + j * 16;
+      if ((epi & EPI_SAVE_PREACT) && live) st_store4<TO>(C2 + ci, v);
+      if (epi & EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+      }
+      if (AUX == ST_AUX_RES) { v[0] += res[i][j].x; v[1] += res[i][j].y; v[2] += res[i][j].z; v[3] += res[i][j].w; }
+      if constexpr (sizeof(TO) == 4) {
+        if ((epi & EPI_ACCUM) && live) {
+          const float4 o = *reinterpret_cast<const float4*>(C + ci);
+          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
+      }
+      if (live) st_store4<TO>(C + ci, v);
+    }
+  }
+}
+
+template <bool B_KC, int AUX, typename TO>
+__global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile, int xflags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tr = bid / tiles_n, tc = bid - tr * tiles_n;
-  const int m0 = tr * rows_per_tile, n0 = tc * ST_T;
-  const int m_end = min(g.M, m0 + rows_per_tile);
+  const int ntiles = tiles_m * tiles_n, G = gridDim.x, bidx = blockIdx.x;
   const int nk = g.K / 64;
 
   STCtx c;
@@ -126,19 +236,6 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
   c.B = reinterpret_cast<const bf16_t*>(g.B);
   c.wave = wave;
   c.kstep_b = B_KC ? 64 : 64 * g.ldb;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int row = (wave * 3 + q) * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ (row & 7);
-    c.oa[q] = (uint32_t)min(m0 + row, g.M - 1) * (uint32_t)g.lda + chunk * 8;
-    if (B_KC) {
-      c.ob[q] = (uint32_t)min(n0 + row, g.N - 1) * (uint32_t)g.ldb + chunk * 8;
-    } else {
-      const int lin = (wave * 3 + q) * 64 + lane;            // 16-byte chunk index in the [64][24] image
-      const int k = lin / 24, c16 = (lin - k * 24) ^ (st_gk(k) << 1);
-      c.ob[q] = (uint32_t)k * (uint32_t)g.ldb + n0 + c16 * 8;
-    }
-  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int sw = ((4 * s + (lane >> 4)) ^ (lane & 7)) * 16;
@@ -153,13 +250,14 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
     c.boffj[j] = k * 384 + (((c8 >> 1) ^ (st_gk(k) << 1)) * 16) + (c8 & 1) * 8;
   }
 
-  f32x4 acc[6][3];
+  int id = st_tile_id(bidx, 0, G, ntiles);
+  if (id < 0) return;                                        // (whole workgroup: id is uniform)
+  STTile cur, nxt;
+  st_tile_setup<B_KC>(cur, g, id, tiles_m, tiles_n, rows_per_tile, wave, lane, xflags);
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < 3; ++q) { c.oa[q] = cur.oa[q]; c.ob[q] = cur.ob[q]; }
 
-  // prologue: tiles 0 and 1
+  // prologue: k-tiles 0 and 1 of the first output tile
   st_stage_op(c.A, c.oa, 0, smem, wave);
   st_stage_op(c.B, c.ob, 0, smem + ST_OP_BYTES, wave);
   st_stage_op(c.A, c.oa, 64, smem + ST_STAGE, wave);
@@ -170,78 +268,47 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
   if (wm == 1) __builtin_amdgcn_s_barrier();                 // skew: group 1 runs one barrier behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
-  int sc = 0, sn = 2;                                        // stage of tile it / of tile it+2
-  int it = 0;
-  for (; it + 2 < nk; ++it) {
-    st_tile<0, B_KC>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, it + 2);
-    sc = sc == 2 ? 0 : sc + 1;
-    sn = sn == 2 ? 0 : sn + 1;
-  }
-  st_tile<1, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
-  sc = sc == 2 ? 0 : sc + 1;
-  st_tile<2, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
-  if (wm == 0) __builtin_amdgcn_s_barrier();
-
-  // epilogue (order: alpha, bias, gelu'(aux), save pre-activation, gelu, residual, accumulate; as gemm_fast.hip)
-  const int epi = g.epi;
-  TO* C = reinterpret_cast<TO*>(g.C);
-  TO* C2 = reinterpret_cast<TO*>(g.C2);
+  int sc = 0, sn = 2;                                        // LDS stage of the current k-tile / of the k-tile two ahead
+  for (int r = 0;; ++r) {
+    const int nid = st_tile_id(bidx, r + 1, G, ntiles);
+    f32x4 acc[6][3];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int m = m0 + wm * 96 + i * 16 + (lane & 15);
-    if (m >= m_end) continue;
+    for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int n = n0 + wn * 48 + j * 16 + 4 * (lane >> 4);
-      float v[4] = {g.alpha * acc[i][j][0], g.alpha * acc[i][j][1], g.alpha * acc[i][j][2], g.alpha * acc[i][j][3]};
-      if (epi & EPI_BIAS) {
-        const float4 b = *reinterpret_cast<const float4*>(g.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (epi & EPI_DGELU) {
-        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ld_aux + n);
-        v[0] *= gelu_fast_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_fast_grad(__uint_as_float(u.x & 0xffff0000u));
-        v[2] *= gelu_fast_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_fast_grad(__uint_as_float(u.y & 0xffff0000u));
-      }
-      const long ci = (long)m * g.ldc + n;
-      if (epi & EPI_SAVE_PREACT) {
-        if constexpr (sizeof(TO) == 2) {
-          uint2 pk;
-          pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(C2 + ci) = pk;
-        } else {
-          *reinterpret_cast<float4*>(C2 + ci) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      }
-      if (epi & EPI_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
-      }
-      if (epi & EPI_RESIDUAL) {
-        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + (long)m * g.ld_aux + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      }
-      if constexpr (sizeof(TO) == 2) {
-        uint2 pk;
-        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2*>(C + ci) = pk;
-      } else {
-        if (epi & EPI_ACCUM) {
-          const float4 o = *reinterpret_cast<const float4*>(C + ci);
-          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-        }
-        *reinterpret_cast<float4*>(C + ci) = make_float4(v[0], v[1], v[2], v[3]);
-      }
+      for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int it = 0;
+    for (; it + 2 < nk; ++it) {
+      st_tile<0, B_KC>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, it + 2);
+      sc = sc == 2 ? 0 : sc + 1;
+      sn = sn == 2 ? 0 : sn + 1;
     }
+    if (nid >= 0) {                                          // the stream continues with the next output tile
+      st_tile_setup<B_KC>(nxt, g, nid, tiles_m, tiles_n, rows_per_tile, wave, lane, xflags);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { c.oa[q] = nxt.oa[q]; c.ob[q] = nxt.ob[q]; }
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        st_tile<0, B_KC>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, e);
+        sc = sc == 2 ? 0 : sc + 1;
+        sn = sn == 2 ? 0 : sn + 1;
+      }
+    } else {
+      st_tile<1, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+      sc = sc == 2 ? 0 : sc + 1;
+      st_tile<2, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+    }
+    st_epilogue<AUX, TO>(acc, g, cur, wm, wn, lane);
+    if (nid < 0) break;
+    cur = nxt;
   }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
 }
 
 bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
   if (!a_kc || g.splitk > 1 || g.nb1 > 1 || g.nb2 > 1) return false;
   if (g.N % ST_T != 0 || g.K % 64 != 0 || g.K < 128) return false;
   if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_ACCUM)) return false;
+  if ((g.epi & EPI_RESIDUAL) && (g.epi & EPI_DGELU)) return false;
   if ((long)g.M * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
   return true;
 }
@@ -252,20 +319,42 @@ double rmcl_gemm_st_fill(const GemmArgs& g) {
   return (double)tiles / (double)(cdiv(tiles, 256L) * 256L);
 }
 
-template <bool B_KC>
-static int launch_st(const GemmArgs& g, int dt_out, hipStream_t s) {
+int g_st_xflags = 0;                 // experiment switch (rmcl_tune_set key 0, values 61.. -> xflags = value - 60)
+
+static int st_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <bool B_KC, int AUX, typename TO>
+static int launch_st3(const GemmArgs& g, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<B_KC, float>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<B_KC, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<B_KC, AUX, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
     attr = true;
   }
   // a tile costs the same whether 185 or 192 of its rows are live, so the fewest row tiles win; they share M evenly
   const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = cdiv(g.M, tm);
-  if (dt_out == RMCL_F32) RMCL_LAUNCH((gemm_st_kernel<B_KC, float>), dim3(tm * tn), dim3(512), ST_LDS, s, g, tm, tn, rows);
-  else RMCL_LAUNCH((gemm_st_kernel<B_KC, bf16_t>), dim3(tm * tn), dim3(512), ST_LDS, s, g, tm, tn, rows);
+  const int grid = min(tm * tn, st_num_cus());
+  RMCL_LAUNCH((gemm_st_kernel<B_KC, AUX, TO>), dim3(grid), dim3(512), ST_LDS, s, g, tm, tn, rows, g_st_xflags);
   RMCL_CHECK_LAUNCH();
   return 0;
+}
+
+template <bool B_KC, int AUX>
+static int launch_st2(const GemmArgs& g, int dt_out, hipStream_t s) {
+  return dt_out == RMCL_F32 ? launch_st3<B_KC, AUX, float>(g, s) : launch_st3<B_KC, AUX, bf16_t>(g, s);
+}
+
+template <bool B_KC>
+static int launch_st(const GemmArgs& g, int dt_out, hipStream_t s) {
+  if (g.epi & EPI_RESIDUAL) return launch_st2<B_KC, ST_AUX_RES>(g, dt_out, s);
+  if (g.epi & EPI_DGELU) return launch_st2<B_KC, ST_AUX_DGELU>(g, dt_out, s);
+  return launch_st2<B_KC, ST_AUX_NONE>(g, dt_out, s);
 }
 
 int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s) {
