@@ -177,6 +177,15 @@ int gemm_dw(const Ctx& c, const void* dY, long lddy, const void* X, long ldx, fl
   if (!c.d.exact && dt_in == RMCL_BF16 && slab) {
     // bf16 MFMA path: split-K over tokens into fp32 slabs + ordered reduce (no float atomics)
     GemmArgs probe = g;
+    const int cfg = rmcl_gemm_fast_get_cfg();                       // tune cfg 1..4 pins the 128x128 kernel (tests A/B the two paths)
+    if ((cfg < 1 || cfg > 4) && rmcl_gemm_st_supported(probe, 0, 0) && tokens >= 1024) {
+      // 192x192 ping-pong tiles, one (tile, K-slice) work item per CU
+      const int tiles = (Nout / 192) * (Kin / 192);
+      int sk = std::max(1, 256 / tiles);
+      sk = std::min<int>(sk, std::max<size_t>(1, slab_floats / ((size_t)Nout * Kin)));
+      g.splitk = sk; g.tag = GEMM_TAG_DW;
+      return rmcl_launch_gemm_st_slab(g, slab, dW, c.s);
+    }
     if (rmcl_gemm_fast_supported(probe, dt_in, RMCL_F32, 0, 0)) {
       const int tiles = (Nout / 128) * (Kin / 128);
       int sk = std::max(1, std::min(8, (256 + tiles - 1) / tiles));

@@ -274,6 +274,7 @@ int rmcl_slab_reduce(const float* slab, float* out, long n, int nz, hipStream_t 
 
 // cfg (rmcl_tune_set key 0): persistent grid size in workgroups per CU (default 2); 10 / 11 = ablations
 static int g_gemm_cfg = -1;
+int rmcl_gemm_fast_get_cfg() { return g_gemm_cfg; }
 extern int g_st_xflags;
 void rmcl_gemm_fast_set_cfg(int cfg) {
   if (cfg > 60 && cfg < 70) { g_st_xflags = cfg - 60; cfg = 60; } else { g_st_xflags = 0; }
@@ -314,7 +315,7 @@ static int launch_fast(const GemmArgs& g, int dt_out, hipStream_t s) {
 }
 
 int rmcl_launch_gemm_pp(const GemmArgs& g, int dt_out, hipStream_t s);
-int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s);
+int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s);
 double rmcl_gemm_st_fill(const GemmArgs& g);
 bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc);
 bool rmcl_gemm_pp_supported(const GemmArgs& g, int a_kc, int b_kc);
@@ -325,7 +326,7 @@ int rmcl_launch_gemm_fast(const GemmArgs& g0, int dt_out, int a_kc, int b_kc, hi
   GemmArgs g = g0;
   // 192x192 ping-pong tiles for the activation GEMMs (M = B*185 rows) whenever they fill the CU rounds
   if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc))
-    return rmcl_launch_gemm_st(g, dt_out, b_kc, s);
+    return rmcl_launch_gemm_st(g, dt_out, a_kc, b_kc, s);
   if (g_gemm_cfg == 50 && rmcl_gemm_pp_supported(g, a_kc, b_kc)) return rmcl_launch_gemm_pp(g, dt_out, s);
   // 256x256 tiles where they measure faster (MI355X, M = 11840): narrow outputs with a long reduction
   const bool big_wins = a_kc && g.splitk <= 1 && g.N <= 1024 && g.K >= 2048 && cdiv(g.M, 256) * (g.N / 256) >= 128;

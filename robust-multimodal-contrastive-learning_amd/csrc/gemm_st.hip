@@ -75,13 +75,27 @@ struct STCtx {
   const bf16_t* A;
   const bf16_t* B;
   uint32_t oa[3], ob[3];
-  int aoff[2], boff[2], boffj[3];
-  long kstep_b;                   // element stride of one k-tile in B: 64 ([N][K]) or 64 * ldb ([K][N])
+  int aoff[2], aoffi[6], boff[2], boffj[3];
+  long kstep_a, kstep_b;          // element stride of one k-tile: 64 ([rows][K] operand) or 64 * ld ([K][cols] operand)
   int wave;
 };
 
+template <typename TO>
+__device__ __forceinline__ void st_store4(TO* p, const float (&v)[4]) {
+  if constexpr (sizeof(TO) == 2) {
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = pk;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+enum { ST_AUX_NONE = 0, ST_AUX_RES = 1, ST_AUX_DGELU = 2 };
+
 // MODE 0: steady state (stage tile t+2, vmcnt(6)); 1: second-to-last tile (no stage, vmcnt(0)); 2: last tile (no stage, no wait)
-template <int MODE, bool B_KC, int W = 6>
+template <int MODE, bool A_KC, bool B_KC>
 __device__ __forceinline__ void st_tile(f32x4 (&acc)[6][3], const STCtx& c, const char* cur, char* nxt2, int t2) {
   bf16x8 a[6], b[3];
 #pragma unroll
@@ -89,12 +103,12 @@ __device__ __forceinline__ void st_tile(f32x4 (&acc)[6][3], const STCtx& c, cons
 #pragma unroll
     for (int j = 0; j < 3; ++j) b[j] = B_KC ? st_ld_b<true>(cur + ST_OP_BYTES, j * 2048 + c.boff[s], s) : st_ld_b<false>(cur + ST_OP_BYTES, c.boffj[j], s);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cur + i * 2048 + c.aoff[s]);
+    for (int i = 0; i < 6; ++i) a[i] = A_KC ? st_ld_b<true>(cur, i * 2048 + c.aoff[s], s) : st_ld_b<false>(cur, c.aoffi[i], s);
     if (s == 1) {
       if (MODE == 0) {
-        st_stage_op(c.A, c.oa, (long)t2 * 64, nxt2, c.wave);
+        st_stage_op(c.A, c.oa, (long)t2 * c.kstep_a, nxt2, c.wave);
         st_stage_op(c.B, c.ob, (long)t2 * c.kstep_b, nxt2 + ST_OP_BYTES, c.wave);
-        st_wait_vm<W>();
+        st_wait_vm<6>();
       } else if (MODE == 1) {
         st_wait_vm<0>();
       }
@@ -108,11 +122,11 @@ __device__ __forceinline__ void st_tile(f32x4 (&acc)[6][3], const STCtx& c, cons
   }
 }
 
-enum { ST_AUX_NONE = 0, ST_AUX_RES = 1, ST_AUX_DGELU = 2 };
-
 struct STTile {
   uint32_t oa[3], ob[3];
   int m0, n0, m_end;
+  int kt0, nk;                    // k-tile range of this work item (split-K: a slice of K)
+  long zoff;                      // element offset of the item's output slab (split-K), else 0
 };
 
 // tile of workgroup b in round r (grid G workgroups, T tiles): slots of one XCD (b & 7) are consecutive tile ids
@@ -124,9 +138,18 @@ __device__ __forceinline__ int st_tile_id(int b, int r, int G, int T) {
   return r * G + (x < e ? x * (q + 1) : e * (q + 1) + (x - e) * q) + s;
 }
 
-template <bool B_KC>
-__device__ __forceinline__ void st_tile_setup(STTile& T, const GemmArgs& g, int id, int tiles_m, int tiles_n, int rows_per_tile, int wave, int lane,
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void st_tile_setup(STTile& T, const GemmArgs& g, int item, int tiles_m, int tiles_n, int rows_per_tile, int wave, int lane,
                                               int xflags) {
+  asm volatile("" : "+v"(lane));   // recompute the lane-derived offsets per tile instead of keeping them live across the k-loops
+  // split-K: item = split * tiles + tile; each split owns `per` k-tiles (the last one the remainder, >= 2 by construction)
+  const int ntile = tiles_m * tiles_n, split = item / ntile, id = item - split * ntile;
+  {
+    const int kts = g.K / 64, per = (kts + max(g.splitk, 1) - 1) / max(g.splitk, 1);
+    T.kt0 = split * per;
+    T.nk = min(per, kts - T.kt0);
+    T.zoff = (long)split * g.M * g.ldc;
+  }
   // tile order: bands of 4 column tiles, row tiles inside a band, the band's 4 column tiles innermost - the 32 consecutive
   // tiles one XCD works on in a round are 8 A panels x 4 B panels (12 x 192 x K x 2 B: fits its 4 MiB L2 for K = 768)
   int tr, tc;
@@ -145,26 +168,12 @@ __device__ __forceinline__ void st_tile_setup(STTile& T, const GemmArgs& g, int 
   for (int q = 0; q < 3; ++q) {
     const int row = (wave * 3 + q) * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ (row & 7);
-    T.oa[q] = (uint32_t)min(T.m0 + row, g.M - 1) * (uint32_t)g.lda + chunk * 8;
-    if (B_KC) {
-      T.ob[q] = (uint32_t)min(T.n0 + row, g.N - 1) * (uint32_t)g.ldb + chunk * 8;
-    } else {
-      const int lin = (wave * 3 + q) * 64 + lane;            // 16-byte chunk index in the [64][24] image
-      const int k = lin / 24, c16 = (lin - k * 24) ^ (st_gk(k) << 1);
-      T.ob[q] = (uint32_t)k * (uint32_t)g.ldb + T.n0 + c16 * 8;
-    }
-  }
-}
-
-template <typename TO>
-__device__ __forceinline__ void st_store4(TO* p, const float (&v)[4]) {
-  if constexpr (sizeof(TO) == 2) {
-    uint2 pk;
-    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    *reinterpret_cast<uint2*>(p) = pk;
-  } else {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    const int lin = (wave * 3 + q) * 64 + lane;              // 16-byte chunk index in the [64][24] image of a [K][cols] operand
+    const int k = lin / 24, c16 = (lin - k * 24) ^ (st_gk(k) << 1);
+    if (A_KC) T.oa[q] = (uint32_t)min(T.m0 + row, g.M - 1) * (uint32_t)g.lda + chunk * 8;
+    else T.oa[q] = (uint32_t)k * (uint32_t)g.lda + T.m0 + c16 * 8;
+    if (B_KC) T.ob[q] = (uint32_t)min(T.n0 + row, g.N - 1) * (uint32_t)g.ldb + chunk * 8;
+    else T.ob[q] = (uint32_t)k * (uint32_t)g.ldb + T.n0 + c16 * 8;
   }
 }
 
@@ -173,7 +182,7 @@ __device__ __forceinline__ void st_store4(TO* p, const float (&v)[4]) {
 template <int AUX, typename TO>
 __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const GemmArgs& g, const STTile& T, int wm, int wn, int lane) {
   const int epi = g.epi;
-  TO* C = reinterpret_cast<TO*>(g.C);
+  TO* C = reinterpret_cast<TO*>(g.C) + T.zoff;
   TO* C2 = reinterpret_cast<TO*>(g.C2);
   const int nb = T.n0 + wn * 48 + 4 * (lane >> 4);
   const int mb = T.m0 + wm * 96 + (lane & 15);
@@ -201,14 +210,14 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
                     g.alpha * acc[i][j][3] + bias[j].w};
       if (AUX == ST_AUX_DGELU) {
         const uint2 u = pre[i][j];
-        v[0] *= gelu_fast_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_fast_grad(__uint_as_float(u.x & 0xffff0000u));
-        v[2] *= gelu_fast_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_fast_grad(__uint_as_float(u.y & 0xffff0000u));
+        v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
+        v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
       }
       const long ci = (long)m * g.ldc + nb + j * 16;
       if ((epi & EPI_SAVE_PREACT) && live) st_store4<TO>(C2 + ci, v);
       if (epi & EPI_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
       }
       if (AUX == ST_AUX_RES) { v[0] += res[i][j].x; v[1] += res[i][j].y; v[2] += res[i][j].z; v[3] += res[i][j].w; }
       if constexpr (sizeof(TO) == 4) {
@@ -222,20 +231,27 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
   }
 }
 
-template <bool B_KC, int AUX, typename TO>
+template <bool A_KC, bool B_KC, int AUX, typename TO>
 __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile, int xflags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int ntiles = tiles_m * tiles_n, G = gridDim.x, bidx = blockIdx.x;
-  const int nk = g.K / 64;
+  const int ntiles = tiles_m * tiles_n * max(g.splitk, 1), G = gridDim.x, bidx = blockIdx.x;   // work items
 
   STCtx c;
   c.A = reinterpret_cast<const bf16_t*>(g.A);
   c.B = reinterpret_cast<const bf16_t*>(g.B);
   c.wave = wave;
+  c.kstep_a = A_KC ? 64 : 64 * g.lda;
   c.kstep_b = B_KC ? 64 : 64 * g.ldb;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int k = 8 * (lane >> 4) + q;
+    const int c8 = (wm * 96 + i * 16) / 4 + p;
+    c.aoffi[i] = k * 384 + (((c8 >> 1) ^ (st_gk(k) << 1)) * 16) + (c8 & 1) * 8;
+  }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int sw = ((4 * s + (lane >> 4)) ^ (lane & 7)) * 16;
@@ -253,15 +269,15 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
   int id = st_tile_id(bidx, 0, G, ntiles);
   if (id < 0) return;                                        // (whole workgroup: id is uniform)
   STTile cur, nxt;
-  st_tile_setup<B_KC>(cur, g, id, tiles_m, tiles_n, rows_per_tile, wave, lane, xflags);
+  st_tile_setup<A_KC, B_KC>(cur, g, id, tiles_m, tiles_n, rows_per_tile, wave, lane, xflags);
 #pragma unroll
   for (int q = 0; q < 3; ++q) { c.oa[q] = cur.oa[q]; c.ob[q] = cur.ob[q]; }
 
-  // prologue: k-tiles 0 and 1 of the first output tile
-  st_stage_op(c.A, c.oa, 0, smem, wave);
-  st_stage_op(c.B, c.ob, 0, smem + ST_OP_BYTES, wave);
-  st_stage_op(c.A, c.oa, 64, smem + ST_STAGE, wave);
-  st_stage_op(c.B, c.ob, c.kstep_b, smem + ST_STAGE + ST_OP_BYTES, wave);
+  // prologue: the first two k-tiles of the first work item
+  st_stage_op(c.A, c.oa, (long)cur.kt0 * c.kstep_a, smem, wave);
+  st_stage_op(c.B, c.ob, (long)cur.kt0 * c.kstep_b, smem + ST_OP_BYTES, wave);
+  st_stage_op(c.A, c.oa, (long)(cur.kt0 + 1) * c.kstep_a, smem + ST_STAGE, wave);
+  st_stage_op(c.B, c.ob, (long)(cur.kt0 + 1) * c.kstep_b, smem + ST_STAGE + ST_OP_BYTES, wave);
   st_wait_vm<6>();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -276,26 +292,26 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
     for (int i = 0; i < 6; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int it = 0;
-    for (; it + 2 < nk; ++it) {
-      st_tile<0, B_KC>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, it + 2);
+    const int nk = cur.nk;
+    for (int it = 0; it + 2 < nk; ++it) {
+      st_tile<0, A_KC, B_KC>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, cur.kt0 + it + 2);
       sc = sc == 2 ? 0 : sc + 1;
       sn = sn == 2 ? 0 : sn + 1;
     }
-    if (nid >= 0) {                                          // the stream continues with the next output tile
-      st_tile_setup<B_KC>(nxt, g, nid, tiles_m, tiles_n, rows_per_tile, wave, lane, xflags);
+    if (nid >= 0) {                                          // the stream continues with the next work item
+      st_tile_setup<A_KC, B_KC>(nxt, g, nid, tiles_m, tiles_n, rows_per_tile, wave, lane, xflags);
 #pragma unroll
       for (int q = 0; q < 3; ++q) { c.oa[q] = nxt.oa[q]; c.ob[q] = nxt.ob[q]; }
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        st_tile<0, B_KC>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, e);
+        st_tile<0, A_KC, B_KC>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, nxt.kt0 + e);
         sc = sc == 2 ? 0 : sc + 1;
         sn = sn == 2 ? 0 : sn + 1;
       }
     } else {
-      st_tile<1, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+      st_tile<1, A_KC, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
       sc = sc == 2 ? 0 : sc + 1;
-      st_tile<2, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+      st_tile<2, A_KC, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
     }
     st_epilogue<AUX, TO>(acc, g, cur, wm, wn, lane);
     if (nid < 0) break;
@@ -305,17 +321,22 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
 }
 
 bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
-  if (!a_kc || g.splitk > 1 || g.nb1 > 1 || g.nb2 > 1) return false;
+  if (g.nb1 > 1 || g.nb2 > 1) return false;
   if (g.N % ST_T != 0 || g.K % 64 != 0 || g.K < 128) return false;
+  if ((long)(a_kc ? g.M : g.K) * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
+  if (g.splitk > 1) return false;                                // (split-K: rmcl_launch_gemm_st_slab)
+  if (!a_kc) {                                                   // [K][M] x [K][N] (weight gradients): plain or slab output only
+    if (b_kc || g.M % ST_T != 0 || (g.epi & ~EPI_ACCUM)) return false;
+    return true;
+  }
   if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_ACCUM)) return false;
   if ((g.epi & EPI_RESIDUAL) && (g.epi & EPI_DGELU)) return false;
-  if ((long)g.M * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
   return true;
 }
 
 // how full the CU rounds of a launch are (1 = every round uses all 256 CUs)
 double rmcl_gemm_st_fill(const GemmArgs& g) {
-  const long tiles = (long)cdiv(g.M, ST_T) * (g.N / ST_T);
+  const long tiles = (long)cdiv(g.M, ST_T) * (g.N / ST_T) * (g.splitk > 1 ? g.splitk : 1);
   return (double)tiles / (double)(cdiv(tiles, 256L) * 256L);
 }
 
@@ -330,24 +351,25 @@ static int st_num_cus() {
   return n;
 }
 
-template <bool B_KC, int AUX, typename TO>
+template <bool A_KC, bool B_KC, int AUX, typename TO>
 static int launch_st3(const GemmArgs& g, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<B_KC, AUX, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<A_KC, B_KC, AUX, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
     attr = true;
   }
   // a tile costs the same whether 185 or 192 of its rows are live, so the fewest row tiles win; they share M evenly
-  const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = cdiv(g.M, tm);
-  const int grid = min(tm * tn, st_num_cus());
-  RMCL_LAUNCH((gemm_st_kernel<B_KC, AUX, TO>), dim3(grid), dim3(512), ST_LDS, s, g, tm, tn, rows, g_st_xflags);
+  const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = A_KC ? cdiv(g.M, tm) : ST_T;
+  const int items = tm * tn * (g.splitk > 1 ? g.splitk : 1);
+  const int grid = min(items, st_num_cus());
+  RMCL_LAUNCH((gemm_st_kernel<A_KC, B_KC, AUX, TO>), dim3(grid), dim3(512), ST_LDS, s, g, tm, tn, rows, g_st_xflags);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
 
 template <bool B_KC, int AUX>
 static int launch_st2(const GemmArgs& g, int dt_out, hipStream_t s) {
-  return dt_out == RMCL_F32 ? launch_st3<B_KC, AUX, float>(g, s) : launch_st3<B_KC, AUX, bf16_t>(g, s);
+  return dt_out == RMCL_F32 ? launch_st3<true, B_KC, AUX, float>(g, s) : launch_st3<true, B_KC, AUX, bf16_t>(g, s);
 }
 
 template <bool B_KC>
@@ -357,6 +379,29 @@ static int launch_st(const GemmArgs& g, int dt_out, hipStream_t s) {
   return launch_st2<B_KC, ST_AUX_NONE>(g, dt_out, s);
 }
 
-int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s) {
+int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s) {
+  if (!a_kc) {
+    RMCL_REQUIRE(dt_out == RMCL_F32 && !b_kc, "gemm_st: the [K][M] x [K][N] form writes fp32");
+    return launch_st3<false, false, ST_AUX_NONE, float>(g, s);
+  }
   return b_kc ? launch_st<true>(g, dt_out, s) : launch_st<false>(g, dt_out, s);
+}
+
+// dW-style GEMM: split K into `splitk` slices written as fp32 slabs [splitk][M][N], then reduced (ordered) into `out` (+=).
+// Every slice gets at least 2 k-tiles (the k-tile stream's minimum).
+int rmcl_launch_gemm_st_slab(const GemmArgs& g0, float* slab, float* out, hipStream_t s) {
+  GemmArgs g = g0;
+  const int kts = g.K / 64;
+  int sk = max(1, min(g.splitk, kts / 2));
+  for (;; --sk) {                                                // no empty / single-k-tile last slice
+    const int per = cdiv(kts, sk), used = cdiv(kts, per);
+    if (used == sk && kts - (sk - 1) * per >= 2) break;
+    if (sk == 1) break;
+  }
+  g.splitk = sk;
+  g.C = slab;
+  g.ldc = g.N;
+  g.epi = 0;
+  RMCL_TRY(rmcl_launch_gemm_st(g, RMCL_F32, 0, 0, s));
+  return rmcl_slab_reduce(slab, out, (long)g.M * g.N, sk, s);
 }

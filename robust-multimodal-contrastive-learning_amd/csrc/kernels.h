@@ -10,6 +10,10 @@ int rmcl_launch_gemm_fast(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hip
 bool rmcl_gemm_fast_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc);
 int rmcl_launch_gemm_fast_slab(const GemmArgs& g, float* slab, float* out, hipStream_t s);
 int rmcl_slab_reduce(const float* slab, float* out, long n, int nz, hipStream_t s);
+int rmcl_gemm_fast_get_cfg();
+bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc);
+int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s);
+int rmcl_launch_gemm_st_slab(const GemmArgs& g, float* slab, float* out, hipStream_t s);
 
 int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float eps, void* y, long ldy, int dt_out,
                 float* mean, float* rstd, int M, int D, int relu, hipStream_t s);

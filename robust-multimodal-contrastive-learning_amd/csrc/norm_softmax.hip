@@ -83,10 +83,11 @@ int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float 
 // Rows handled per block: LNB_ROWS waves x LNB_ITERS rows, so dgamma/dbeta partials are reduced
 // in registers over LNB_ITERS rows, then across the 4 waves through LDS, then one atomic per column.
 // ---------------------------------------------------------------------------------------------
-#define LNB_ITERS 8
+#define LNB_ITERS(WG) ((WG) ? 4 : 2)   // rows per wave: fewer -> more workgroups in flight (the data-gradient form has no block reduction to amortise)
 // WG: accumulate dgamma/dbeta (weight-gradient backward only); RELU: mask dy with the ReLU after the LN (MoCo head).
 // The data-gradient-only instantiation (PGD backward, 3/4 of all calls) carries 32 fewer accumulator registers.
-template <typename TG, bool WG, bool RELU>
+// NV = float4 per lane (row width <= 256 * NV): 3 for the encoder width 768, LN_MAXV otherwise.
+template <typename TG, bool WG, bool RELU, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const float* __restrict__ b,
@@ -94,11 +95,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
                                                      float* __restrict__ dbeta, int M, int D, int relu,
                                                      void* __restrict__ dx_copy, int copy_f32, uint32_t dseed, uint32_t dthresh,
                                                      float dinv) {
-  __shared__ float red[2][4][64 * 4 * LN_MAXV];
+  __shared__ float red[WG ? 2 : 1][WG ? 4 : 1][WG ? 64 * 4 * NV : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float4 gw[LN_MAXV], gb[LN_MAXV], ww[LN_MAXV], bb[LN_MAXV];
+  float4 gw[NV], gb[NV], ww[NV], bb[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     gw[i] = make_float4(0, 0, 0, 0);
     gb[i] = make_float4(0, 0, 0, 0);
     const int c = (lane + 64 * i) * 4;
@@ -107,14 +108,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
       bb[i] = RELU ? *reinterpret_cast<const float4*>(b + c) : make_float4(0, 0, 0, 0);
     }
   }
-  for (int it = 0; it < LNB_ITERS; ++it) {
-    const int row = (blockIdx.x * LNB_ITERS + it) * 4 + wave;
+  for (int it = 0; it < LNB_ITERS(WG); ++it) {
+    const int row = (blockIdx.x * LNB_ITERS(WG) + it) * 4 + wave;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
-    float4 xh[LN_MAXV], g[LN_MAXV];
+    float4 xh[NV], g[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < D) {
         const float4 xv = *reinterpret_cast<const float4*>(x + (long)row * ldx + c);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
     s1 = wave_sum(s1) / D;
     s2 = wave_sum(s2) / D;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < D) {
         float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
   }
   if (WG && dgamma) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < D) {
         *reinterpret_cast<float4*>(&red[0][wave][c]) = gw[i];
@@ -205,11 +206,13 @@ int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ld
                    int relu, void* dx_copy, int copy_dt, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0 && D <= 256 * LN_MAXV && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm bwd: bad D/ld");
   if (M <= 0) return 0;
-  dim3 grid(cdiv(M, 4 * LNB_ITERS));
-#define LN_BWD_LAUNCH(TG, WGv, RLv) \
-  RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
-              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv)
   const bool wg = dgamma != nullptr;
+  dim3 grid(cdiv(M, 4 * LNB_ITERS(wg)));
+#define LN_BWD_LAUNCH(TG, WGv, RLv) \
+  do { if (D <= 768) RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, 3>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
+              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv); \
+       else RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, LN_MAXV>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
+              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv); } while (0)
   if (dt_dy == RMCL_F32) {
     if (relu) { if (wg) LN_BWD_LAUNCH(float, true, true); else LN_BWD_LAUNCH(float, false, true); }
     else { if (wg) LN_BWD_LAUNCH(float, true, false); else LN_BWD_LAUNCH(float, false, false); }
@@ -309,9 +312,42 @@ int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* 
 // ---------------------------------------------------------------------------------------------
 // Column sums (bias gradients): out[n] += sum_m X[m*ld + n].  Block = 64 columns x 4 row-lanes.
 // ---------------------------------------------------------------------------------------------
-#define CS_ROWS 256
+#define CS_ROWS 128
+// column sums (bias gradients): a lane owns 4 adjacent columns (8- or 16-byte loads, 512 B - 1 KiB per wave-row), a wave
+// walks every 4th row of a 128-row slab; the four waves combine through LDS and issue one f32 atomic per column and slab.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, long ld, float* __restrict__ out, int M, int N) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 4;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < N) {
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += 4) {
+      if constexpr (sizeof(T) == 2) {
+        const uint2 u = *reinterpret_cast<const uint2*>(X + (long)r * ld + c);
+        acc.x += __uint_as_float(u.x << 16); acc.y += __uint_as_float(u.x & 0xffff0000u);
+        acc.z += __uint_as_float(u.y << 16); acc.w += __uint_as_float(u.y & 0xffff0000u);
+      } else {
+        const float4 u = *reinterpret_cast<const float4*>(X + (long)r * ld + c);
+        acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+      }
+    }
+  }
+  red[rl][lane] = acc;
+  __syncthreads();
+  if (rl == 0 && c < N) {
+    const float4 a = red[0][lane], b = red[1][lane], d = red[2][lane], e = red[3][lane];
+    atomicAdd(out + c, a.x + b.x + d.x + e.x);
+    atomicAdd(out + c + 1, a.y + b.y + d.y + e.y);
+    atomicAdd(out + c + 2, a.z + b.z + d.z + e.z);
+    atomicAdd(out + c + 3, a.w + b.w + d.w + e.w);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_any_kernel(const T* __restrict__ X, long ld, float* __restrict__ out, int M, int N) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
@@ -325,9 +361,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, lo
 
 int rmcl_colsum(const void* X, long ld, int dt, float* out, int M, int N, hipStream_t s) {
   if (M <= 0 || N <= 0) return 0;
-  dim3 grid(cdiv(N, 64), cdiv(M, CS_ROWS));
-  if (dt == RMCL_F32) RMCL_LAUNCH(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ld, out, M, N);
-  else RMCL_LAUNCH(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ld, out, M, N);
+  const int esz = dt == RMCL_F32 ? 4 : 2;
+  if (N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)X % (4 * esz)) == 0) {
+    dim3 grid(cdiv(N, 256), cdiv(M, CS_ROWS));
+    if (dt == RMCL_F32) RMCL_LAUNCH(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ld, out, M, N);
+    else RMCL_LAUNCH(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ld, out, M, N);
+  } else {
+    dim3 grid(cdiv(N, 64), cdiv(M, CS_ROWS));
+    if (dt == RMCL_F32) RMCL_LAUNCH(colsum_any_kernel<float>, grid, dim3(256), 0, s, (const float*)X, ld, out, M, N);
+    else RMCL_LAUNCH(colsum_any_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)X, ld, out, M, N);
+  }
   RMCL_CHECK_LAUNCH();
   return 0;
 }

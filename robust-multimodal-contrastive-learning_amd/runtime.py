@@ -14,6 +14,7 @@ torch is used for allocation, streams and torch.distributed only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -145,7 +146,8 @@ class Engine:
         self.pass_counter = 0
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.dw_stream = torch.cuda.Stream(device=self.device)
-        lib.rmcl_set_side_stream(C.c_void_p(self.dw_stream.cuda_stream))
+        if os.environ.get("RMCL_NO_DW_STREAM", "0") != "1":          # weight-gradient GEMMs concurrent with the dX chain
+            lib.rmcl_set_side_stream(C.c_void_p(self.dw_stream.cuda_stream))
 
     # ---- geometry ------------------------------------------------------------------------------
     def dims(self, B: int) -> L.Dims:

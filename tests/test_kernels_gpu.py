@@ -279,8 +279,9 @@ def test_gemm_sample_tile_epilogues_match_exact_kernel(b_kc):
                 lib.rmcl_tune_set(0, 60)
                 f = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, dto, epi=epi, exact=0, **kw)
                 a, f = (a, f) if isinstance(a, tuple) else ((a,), (f,))
+                tol = 2e-4 if epi & (2 | 16) else 2e-5                 # GELU / GELU': polynomial erf, |err| <= 1.3e-4 (rmcl_common.h)
                 for x, y in zip(a, f):
-                    assert rel_err(y, x) < (2e-5 if dto == L.F32 else 1e-2), (epi, dto)
+                    assert rel_err(y, x) < (tol if dto == L.F32 else 1e-2), (epi, dto)
         lib.rmcl_tune_set(0, 60)
         out = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, L.F32, exact=0, epi=64, C_init=base)           # accumulate
         assert rel_err(out, X.double() @ W.double().t() + base.double()) < 2e-5
