@@ -286,15 +286,25 @@ int rmcl_co_mask(const long* text_mask, const void* pat, int dt, int* co, int B,
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ g, unsigned* __restrict__ amax_bits, long per_sample) {
+  __shared__ float red[4];
   const int b = blockIdx.y;
   const T* p = g + (long)b * per_sample;
   float m = 0.f;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 1024) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(to_f32<T>(p[i + j])));
+    if constexpr (sizeof(T) == 2) {                          // per_sample % 4 == 0 (checked by the launcher): 8-byte loads
+      const uint2 u = *reinterpret_cast<const uint2*>(p + i);
+      m = fmaxf(fmaxf(m, fabsf(__uint_as_float(u.x << 16))), fabsf(__uint_as_float(u.x & 0xffff0000u)));
+      m = fmaxf(fmaxf(m, fabsf(__uint_as_float(u.y << 16))), fabsf(__uint_as_float(u.y & 0xffff0000u)));
+    } else {
+      const float4 u = *reinterpret_cast<const float4*>(p + i);
+      m = fmaxf(fmaxf(m, fabsf(u.x)), fmaxf(fabsf(u.y), fmaxf(fabsf(u.z), fabsf(u.w))));
+    }
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits + b, __float_as_uint(m));  // non-negative floats order like uints
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)                                      // one atomic per block; non-negative floats order like uints
+    atomicMax(amax_bits + b, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 template <typename T>
 __global__ __launch_bounds__(256) void pgd_update_kernel(const T* __restrict__ g, const unsigned* __restrict__ amax_bits,

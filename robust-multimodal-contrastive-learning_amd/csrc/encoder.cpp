@@ -447,6 +447,9 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
                           full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, T[0], dt,
                           rmcl_site_seed(drop_seed, d->layers - 1, DROP_SITE_FC2), dth, dinv, s));
   const int Lr = d->layers;
+  // gradient w.r.t. the LayerNorm outputs (dX GEMM -> LN backward): in the operand dtype, like du / dqkv / dao (bf16 mode
+  // halves the 36 MB write + read per LayerNorm); fp32 mode is unchanged
+  const int dln_dt = lpm ? dt : RMCL_F32;
   for (int l = Lr - 1; l >= 0; --l) {
     const LayerStash& ls = st.layer[l];
     void* du = DU[l & 1];
@@ -471,10 +474,10 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     {
       GemmArgs g = gemm_args(du, c.W(c.L(l, y.fc1_w)), w.dln, M, D, mlp, mlp, D, D);        // dln2 = du W1
       g.tag = GEMM_TAG_DX;
-      RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
+      RMCL_TRY(gemm(c, g, dt, dln_dt, 1, 0));
     }
     if (use_side && l + 1 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 1), 0));           // T[cur^1] free again
-    RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
+    RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, dln_dt, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
                             full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, T[cur ^ 1], dt,
                             rmcl_site_seed(drop_seed, l, DROP_SITE_PROJ), dth, dinv, s));
     cur ^= 1;
@@ -498,10 +501,10 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     {
       GemmArgs g = gemm_args(dqkv, c.W(c.L(l, y.qkv_w)), w.dln, M, D, 3 * D, 3 * D, D, D);  // dln1 = dqkv Wqkv
       g.tag = GEMM_TAG_DX;
-      RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 0));
+      RMCL_TRY(gemm(c, g, dt, dln_dt, 1, 0));
     }
     if (use_side) HIP_TRY(hipStreamWaitEvent(s, EV(1, l), 0));                             // T[cur^1] free again
-    RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, RMCL_F32, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
+    RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, dln_dt, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
                             full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, T[cur ^ 1], dt,
                             rmcl_site_seed(drop_seed, l - 1, DROP_SITE_FC2), l > 0 ? dth : 0u, dinv, s));
     cur ^= 1;

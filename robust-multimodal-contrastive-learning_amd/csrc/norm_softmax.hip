@@ -83,6 +83,8 @@ int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float 
 // Rows handled per block: LNB_ROWS waves x LNB_ITERS rows, so dgamma/dbeta partials are reduced
 // in registers over LNB_ITERS rows, then across the 4 waves through LDS, then one atomic per column.
 // ---------------------------------------------------------------------------------------------
+#define LN_REP 32
+#define LN_REP_LD 1024
 #define LNB_ITERS(WG) ((WG) ? 4 : 2)   // rows per wave: fewer -> more workgroups in flight (the data-gradient form has no block reduction to amortise)
 // WG: accumulate dgamma/dbeta (weight-gradient backward only); RELU: mask dy with the ReLU after the LN (MoCo head).
 // The data-gradient-only instantiation (PGD backward, 3/4 of all calls) carries 32 fewer accumulator registers.
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
                                                      float* __restrict__ dx, long lddx, int add, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int D, int relu,
                                                      void* __restrict__ dx_copy, int copy_f32, uint32_t dseed, uint32_t dthresh,
-                                                     float dinv) {
+                                                     float dinv, float* __restrict__ rep) {
   __shared__ float red[WG ? 2 : 1][WG ? 4 : 1][WG ? 64 * 4 * NV : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 gw[NV], gb[NV], ww[NV], bb[NV];
@@ -187,11 +189,45 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
       }
     }
     __syncthreads();
+    // hundreds of blocks adding into the same 2 D addresses serialise in the memory-side atomic units: spread them
+    // over LN_REP replicas (summed into dgamma/dbeta by ln_rep_finish_kernel) when the caller provides the buffer
+    float* tg = rep ? rep + (blockIdx.x % LN_REP) * (2 * LN_REP_LD) : dgamma;
+    float* tb = rep ? tg + LN_REP_LD : dbeta;
     for (int c = threadIdx.x; c < D; c += 256) {
-      atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-      atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+      atomicAdd(tg + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+      atomicAdd(tb + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
   }
+}
+
+// dgamma/dbeta += sum of the replicas; leaves the replicas zeroed for the next call
+__global__ __launch_bounds__(256) void ln_rep_finish_kernel(float* __restrict__ rep, float* __restrict__ dgamma, float* __restrict__ dbeta, int D) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float sg = 0.f, sb = 0.f;
+#pragma unroll 8
+  for (int r = 0; r < LN_REP; ++r) {
+    float* p = rep + r * (2 * LN_REP_LD);
+    sg += p[c]; sb += p[LN_REP_LD + c];
+    p[c] = 0.f; p[LN_REP_LD + c] = 0.f;
+  }
+  dgamma[c] += sg;
+  dbeta[c] += sb;
+}
+
+// replica buffer (one per process and device; the LayerNorm backward of the encoder runs on one stream)
+static float* ln_rep_buffer() {
+  static float* buf[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!buf[dev]) {
+    float* p = nullptr;
+    const size_t bytes = (size_t)LN_REP * 2 * LN_REP_LD * sizeof(float);
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    buf[dev] = p;
+  }
+  return buf[dev];
 }
 
 int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
@@ -208,11 +244,12 @@ int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ld
   if (M <= 0) return 0;
   const bool wg = dgamma != nullptr;
   dim3 grid(cdiv(M, 4 * LNB_ITERS(wg)));
+  float* rep = (wg && D <= LN_REP_LD && grid.x >= 4 * LN_REP) ? ln_rep_buffer() : nullptr;
 #define LN_BWD_LAUNCH(TG, WGv, RLv) \
   do { if (D <= 768) RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, 3>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
-              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv); \
+              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv, rep); \
        else RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, LN_MAXV>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
-              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv); } while (0)
+              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv, rep); } while (0)
   if (dt_dy == RMCL_F32) {
     if (relu) { if (wg) LN_BWD_LAUNCH(float, true, true); else LN_BWD_LAUNCH(float, false, true); }
     else { if (wg) LN_BWD_LAUNCH(float, true, false); else LN_BWD_LAUNCH(float, false, false); }
@@ -222,6 +259,10 @@ int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ld
   }
 #undef LN_BWD_LAUNCH
   RMCL_CHECK_LAUNCH();
+  if (rep) {
+    RMCL_LAUNCH(ln_rep_finish_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, rep, dgamma, dbeta, D);
+    RMCL_CHECK_LAUNCH();
+  }
   return 0;
 }
 
