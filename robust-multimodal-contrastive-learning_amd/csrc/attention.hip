@@ -107,13 +107,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   stage_rows<false>(Kimg, base + D, ld, N, NKP, wave, lane);
   stage_rows<true>(Vimg, base + 2 * D, ld, N, NKP, wave, lane);
   fill_maskbias(mb, mask + (long)b * N, N, NKP, t);
-  __syncthreads();
 
   const int nqt = (N + 15) / 16;
+  bf16x8 qn[2];                                              // Q fragments of the wave's NEXT tile (global-load latency off the loop's critical path)
+  qn[0] = frag_row_global(base, ld, wave * 16, N, 0, lane);
+  qn[1] = frag_row_global(base, ld, wave * 16, N, 1, lane);
+  __syncthreads();
   for (int qt = wave; qt < nqt; qt += 4) {
-    bf16x8 qf[2];
-    qf[0] = frag_row_global(base, ld, qt * 16, N, 0, lane);
-    qf[1] = frag_row_global(base, ld, qt * 16, N, 1, lane);
+    bf16x8 qf[2] = {qn[0], qn[1]};
+    if (qt + 4 < nqt) {
+      qn[0] = frag_row_global(base, ld, (qt + 4) * 16, N, 0, lane);
+      qn[1] = frag_row_global(base, ld, (qt + 4) * 16, N, 1, lane);
+    }
     f32x4 S[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -138,6 +143,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     l = group_sum(l);
     const int q_lane = qt * 16 + (lane & 15);
     if (g == 0 && q_lane < N) lse[((long)blockIdx.x) * NKP + q_lane] = m + __logf(l);
+    // O^T = V^T P^T: swapped operands leave the lane with 4 adjacent head dims of query lane%16 -> 8-byte stores, and the
+    // row's 1/l is already in the lane
     f32x4 O[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) O[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -145,17 +152,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     for (int u = 0; u < NKT / 2; ++u) {
       const bf16x8 pa = pack8(S[2 * u], S[2 * u + 1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, frag_tr32_lds(Vimg, 32 * u, dt, lane), O[dt], 0, 0, 0);
+      for (int dt = 0; dt < 4; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr32_lds(Vimg, 32 * u, dt, lane), pa, O[dt], 0, 0, 0);
     }
     const float linv = 1.0f / l;
+    if (q_lane < N) {
+      bf16_t* o = out + ((long)b * N + q_lane) * D + h * 64 + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float li = __shfl(linv, 4 * g + r, 64);           // 1/l of query row 4g+r lives in lane 4g+r
-      const int q = qt * 16 + 4 * g + r;
-      if (q < N) {
-        bf16_t* o = out + ((long)b * N + q) * D + h * 64 + (lane & 15);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[16 * dt] = f2bf(O[dt][r] * li);
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(O[dt][0] * linv) | ((uint32_t)f2bf(O[dt][1] * linv) << 16);
+        pk.y = (uint32_t)f2bf(O[dt][2] * linv) | ((uint32_t)f2bf(O[dt][3] * linv) << 16);
+        *reinterpret_cast<uint2*>(o + 16 * dt) = pk;
       }
     }
   }
@@ -181,18 +188,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   stage_rows<false>(Vrow, base + 2 * D, ld, N, NKP, wave, lane);
   stage_rows<true>(Ktr, base + D, ld, N, NKP, wave, lane);
   fill_maskbias(mb, mask + (long)b * N, N, NKP, t);
-  __syncthreads();
 
   const int nqt = (N + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
-    bf16x8 qf[2], df[2];
+  bf16x8 qn[2], dn[2];                                       // Q / dO fragments and lse of the wave's NEXT tile
+  float Ln;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      qf[s] = frag_row_global(base, ld, qt * 16, N, s, lane);
-      df[s] = frag_row_global(dob, D, qt * 16, N, s, lane);
-    }
+  for (int s = 0; s < 2; ++s) {
+    qn[s] = frag_row_global(base, ld, wave * 16, N, s, lane);
+    dn[s] = frag_row_global(dob, D, wave * 16, N, s, lane);
+  }
+  Ln = (wave * 16 + (lane & 15)) < N ? lse[((long)blockIdx.x) * NKP + wave * 16 + (lane & 15)] : INFINITY;
+  __syncthreads();
+  for (int qt = wave; qt < nqt; qt += 4) {
+    bf16x8 qf[2] = {qn[0], qn[1]}, df[2] = {dn[0], dn[1]};
+    const float L = Ln;
     const int q_lane = qt * 16 + (lane & 15);
-    const float L = q_lane < N ? lse[((long)blockIdx.x) * NKP + q_lane] : INFINITY;
+    if (qt + 4 < nqt) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        qn[s] = frag_row_global(base, ld, (qt + 4) * 16, N, s, lane);
+        dn[s] = frag_row_global(dob, D, (qt + 4) * 16, N, s, lane);
+      }
+      Ln = (q_lane + 64) < N ? lse[((long)blockIdx.x) * NKP + q_lane + 64] : INFINITY;
+    }
     f32x4 S[NKT], dP[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -221,22 +239,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) S[kt][r] = S[kt][r] * (dP[kt][r] - dl) * SCALE;   // dS
-    f32x4 dQ[4];
+    f32x4 dQ[4];                                             // dQ^T = K^T dS^T (swapped operands: 4 adjacent head dims per lane)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NKT / 2; ++u) {
       const bf16x8 sa = pack8(S[2 * u], S[2 * u + 1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dQ[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sa, frag_tr32_lds(Ktr, 32 * u, dt, lane), dQ[dt], 0, 0, 0);
+      for (int dt = 0; dt < 4; ++dt) dQ[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr32_lds(Ktr, 32 * u, dt, lane), sa, dQ[dt], 0, 0, 0);
     }
+    if (q_lane < N) {
+      bf16_t* o = dqkv + ((long)b * N + q_lane) * ld + h * 64 + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = qt * 16 + 4 * g + r;
-      if (q < N) {
-        bf16_t* o = dqkv + ((long)b * N + q) * ld + h * 64 + (lane & 15);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[16 * dt] = f2bf(dQ[dt][r]);
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(dQ[dt][0]) | ((uint32_t)f2bf(dQ[dt][1]) << 16);
+        pk.y = (uint32_t)f2bf(dQ[dt][2]) | ((uint32_t)f2bf(dQ[dt][3]) << 16);
+        *reinterpret_cast<uint2*>(o + 16 * dt) = pk;
       }
     }
   }
@@ -286,12 +305,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   __syncthreads();
 
   const int nqt = (N + 15) / 16;
-  for (int qt = 0; qt < nqt; ++qt) {
-    bf16x8 qf[2], df[2];
+  bf16x8 qn[2], dn[2];                                       // row-layout Q / dO fragments of the NEXT query tile
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      qf[s] = frag_row_global(base, ld, qt * 16, N, s, lane);
-      df[s] = frag_row_global(dob, D, qt * 16, N, s, lane);
+  for (int s = 0; s < 2; ++s) {
+    qn[s] = frag_row_global(base, ld, 0, N, s, lane);
+    dn[s] = frag_row_global(dob, D, 0, N, s, lane);
+  }
+  for (int qt = 0; qt < nqt; ++qt) {
+    bf16x8 qf[2] = {qn[0], qn[1]}, df[2] = {dn[0], dn[1]};
+    if (qt + 1 < nqt) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        qn[s] = frag_row_global(base, ld, (qt + 1) * 16, N, s, lane);
+        dn[s] = frag_row_global(dob, D, (qt + 1) * 16, N, s, lane);
+      }
     }
     const float4 L4 = *reinterpret_cast<const float4*>(Ls + qt * 16 + 4 * g);
     const float4 D4 = *reinterpret_cast<const float4*>(Ds + qt * 16 + 4 * g);
@@ -318,25 +345,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       }
       const s16x4 pa = pack4(P), sa = pack4(dS);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dV[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, dot[dt], dV[i][dt], 0, 0, 0);   // += P^T dO
-        dK[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(sa, qtr[dt], dK[i][dt], 0, 0, 0);   // += dS^T Q
+      for (int dt = 0; dt < 4; ++dt) {                       // swapped operands: dV^T[d = 4g+r][key = lane%16]
+        dV[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dot[dt], pa, dV[i][dt], 0, 0, 0);   // += dO^T P
+        dK[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtr[dt], sa, dK[i][dt], 0, 0, 0);   // += Q^T dS
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < TPW; ++i) {
-    const int kt = wave + 4 * i;
+    const int key = (wave + 4 * i) * 16 + (lane & 15);
+    if (key < N) {
+      bf16_t* o = dqkv + ((long)b * N + key) * ld + h * 64 + 4 * g;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kt * 16 + 4 * g + r;
-      if (key < N) {
-        bf16_t* o = dqkv + ((long)b * N + key) * ld + h * 64 + (lane & 15);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          o[D + 16 * dt] = f2bf(dK[i][dt][r]);
-          o[2 * D + 16 * dt] = f2bf(dV[i][dt][r]);
-        }
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk, pv;
+        pk.x = (uint32_t)f2bf(dK[i][dt][0]) | ((uint32_t)f2bf(dK[i][dt][1]) << 16);
+        pk.y = (uint32_t)f2bf(dK[i][dt][2]) | ((uint32_t)f2bf(dK[i][dt][3]) << 16);
+        pv.x = (uint32_t)f2bf(dV[i][dt][0]) | ((uint32_t)f2bf(dV[i][dt][1]) << 16);
+        pv.y = (uint32_t)f2bf(dV[i][dt][2]) | ((uint32_t)f2bf(dV[i][dt][3]) << 16);
+        *reinterpret_cast<uint2*>(o + D + 16 * dt) = pk;
+        *reinterpret_cast<uint2*>(o + 2 * D + 16 * dt) = pv;
       }
     }
   }
