@@ -22,11 +22,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 #define SCALE 0.125f
+#define ATT_QW 8            // waves per workgroup of the forward kernel: 12 query tiles -> 1-2 per wave
+#define ATT_DQW 4           // dQ kernel: its 96 score/dP accumulators + hoisted fragments need > 256 VGPRs, so one wave per SIMD
 
 // ---- staging: rows [0,N) of a [*, 64] bf16 slice (row pitch ld elements) -> LDS image of NKP rows x 128 B
-template <bool TR>
+template <bool TR, int NW = 4>
 __device__ __forceinline__ void stage_rows(char* img, const bf16_t* __restrict__ src, long ld, int N, int NKP, int wave, int lane) {
-  for (int inst = wave; inst < NKP / 8; inst += 4) {
+  for (int inst = wave; inst < NKP / 8; inst += NW) {
     const int row = inst * 8 + (lane >> 3), cp = lane & 7;
     int c;
     if (TR) c = (((cp >> 1) ^ ((row >> 1) & 3)) << 1) | (cp & 1);
@@ -87,13 +89,13 @@ __device__ __forceinline__ float group_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
-__device__ __forceinline__ void fill_maskbias(float* mb, const int* __restrict__ mask, int N, int NKP, int t) {
-  for (int j = t; j < NKP; j += 256) mb[j] = (j < N && mask[j] != 0) ? 0.f : -INFINITY;
+__device__ __forceinline__ void fill_maskbias(float* mb, const int* __restrict__ mask, int N, int NKP, int t, int nthreads = 256) {
+  for (int j = t; j < NKP; j += nthreads) mb[j] = (j < N && mask[j] != 0) ? 0.f : -INFINITY;
 }
 
 // ================================================================================== forward
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
+__global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
                                                        bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int NKP = NKT * 16;
@@ -104,20 +106,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * 64;
   const long ld = 3 * D;
   const bf16_t* base = qkv + (long)b * N * ld + h * 64;
-  stage_rows<false>(Kimg, base + D, ld, N, NKP, wave, lane);
-  stage_rows<true>(Vimg, base + 2 * D, ld, N, NKP, wave, lane);
-  fill_maskbias(mb, mask + (long)b * N, N, NKP, t);
+  stage_rows<false, ATT_QW>(Kimg, base + D, ld, N, NKP, wave, lane);
+  stage_rows<true, ATT_QW>(Vimg, base + 2 * D, ld, N, NKP, wave, lane);
+  fill_maskbias(mb, mask + (long)b * N, N, NKP, t, ATT_QW * 64);
 
   const int nqt = (N + 15) / 16;
   bf16x8 qn[2];                                              // Q fragments of the wave's NEXT tile (global-load latency off the loop's critical path)
   qn[0] = frag_row_global(base, ld, wave * 16, N, 0, lane);
   qn[1] = frag_row_global(base, ld, wave * 16, N, 1, lane);
   __syncthreads();
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += ATT_QW) {
     bf16x8 qf[2] = {qn[0], qn[1]};
-    if (qt + 4 < nqt) {
-      qn[0] = frag_row_global(base, ld, (qt + 4) * 16, N, 0, lane);
-      qn[1] = frag_row_global(base, ld, (qt + 4) * 16, N, 1, lane);
+    if (qt + ATT_QW < nqt) {
+      qn[0] = frag_row_global(base, ld, (qt + ATT_QW) * 16, N, 0, lane);
+      qn[1] = frag_row_global(base, ld, (qt + ATT_QW) * 16, N, 1, lane);
     }
     f32x4 S[NKT];
 #pragma unroll
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
 // ================================================================================== backward: dQ, delta
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
+__global__ __launch_bounds__(ATT_DQW * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -184,10 +186,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const long ld = 3 * D;
   const bf16_t* base = qkv + (long)b * N * ld + h * 64;
   const bf16_t* dob = dout + (long)b * N * D + h * 64;
-  stage_rows<false>(Krow, base + D, ld, N, NKP, wave, lane);
-  stage_rows<false>(Vrow, base + 2 * D, ld, N, NKP, wave, lane);
-  stage_rows<true>(Ktr, base + D, ld, N, NKP, wave, lane);
-  fill_maskbias(mb, mask + (long)b * N, N, NKP, t);
+  stage_rows<false, ATT_DQW>(Krow, base + D, ld, N, NKP, wave, lane);
+  stage_rows<false, ATT_DQW>(Vrow, base + 2 * D, ld, N, NKP, wave, lane);
+  stage_rows<true, ATT_DQW>(Ktr, base + D, ld, N, NKP, wave, lane);
+  fill_maskbias(mb, mask + (long)b * N, N, NKP, t, ATT_DQW * 64);
 
   const int nqt = (N + 15) / 16;
   bf16x8 qn[2], dn[2];                                       // Q / dO fragments and lse of the wave's NEXT tile
@@ -199,17 +201,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   }
   Ln = (wave * 16 + (lane & 15)) < N ? lse[((long)blockIdx.x) * NKP + wave * 16 + (lane & 15)] : INFINITY;
   __syncthreads();
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += ATT_DQW) {
     bf16x8 qf[2] = {qn[0], qn[1]}, df[2] = {dn[0], dn[1]};
     const float L = Ln;
     const int q_lane = qt * 16 + (lane & 15);
-    if (qt + 4 < nqt) {
+    if (qt + ATT_DQW < nqt) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        qn[s] = frag_row_global(base, ld, (qt + 4) * 16, N, s, lane);
-        dn[s] = frag_row_global(dob, D, (qt + 4) * 16, N, s, lane);
+        qn[s] = frag_row_global(base, ld, (qt + ATT_DQW) * 16, N, s, lane);
+        dn[s] = frag_row_global(dob, D, (qt + ATT_DQW) * 16, N, s, lane);
       }
-      Ln = (q_lane + 64) < N ? lse[((long)blockIdx.x) * NKP + q_lane + 64] : INFINITY;
+      Ln = (q_lane + 16 * ATT_DQW) < N ? lse[((long)blockIdx.x) * NKP + q_lane + 16 * ATT_DQW] : INFINITY;
     }
     f32x4 S[NKT], dP[NKT];
 #pragma unroll
@@ -378,7 +380,7 @@ long rmcl_attn_stat_elems(int B, int H, int N) { return (long)B * H * nkt_for(N)
 template <int NKT> static int launch_fwd(const bf16_t* qkv, const int* mask, bf16_t* out, float* lse, int B, int N, int H, hipStream_t s) {
   const size_t lds = (size_t)2 * NKT * 16 * 128 + NKT * 16 * 4;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  RMCL_LAUNCH(attn_fwd_kernel<NKT>, dim3(B * H), dim3(256), lds, s, qkv, mask, out, lse, N, H);
+  RMCL_LAUNCH(attn_fwd_kernel<NKT>, dim3(B * H), dim3(ATT_QW * 64), lds, s, qkv, mask, out, lse, N, H);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -387,7 +389,7 @@ template <int NKT> static int launch_bwd(const bf16_t* qkv, const int* mask, con
   const size_t lds1 = (size_t)3 * NKT * 16 * 128 + NKT * 16 * 4, lds2 = (size_t)2 * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-  RMCL_LAUNCH(attn_bwd_dq_kernel<NKT>, dim3(B * H), dim3(256), lds1, s, qkv, mask, dout, lse, delta, dqkv, N, H);
+  RMCL_LAUNCH(attn_bwd_dq_kernel<NKT>, dim3(B * H), dim3(ATT_DQW * 64), lds1, s, qkv, mask, dout, lse, delta, dqkv, N, H);
   RMCL_CHECK_LAUNCH();
   RMCL_LAUNCH(attn_bwd_dkv_kernel<NKT>, dim3(B * H), dim3(256), lds2, s, qkv, mask, dout, lse, delta, dqkv, N, H);
   RMCL_CHECK_LAUNCH();
