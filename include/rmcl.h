@@ -71,6 +71,11 @@ int rmcl_tune_set(int key, int value);
 
 /* Optional second HIP stream: the weight-gradient GEMMs of rmcl_encoder_backward (mode FULL, bf16) then run
  * concurrently with the data-gradient chain, fork/joined with events on `stream`.  NULL disables it.     */
+/* Data-parallel overlap: make `stream` wait until the gradients of encoder layer `layer` written by the most recently
+ * enqueued weight-gradient backward (rmcl_encoder_backward, full mode) are complete - the bucket of that layer can then be
+ * all-reduced while the backward of the layers below is still running (replaces DistributedDataParallel's bucket hooks,
+ * run.py:96 / pytorch_lightning ddp).  Layers finish in the order layers-1 .. 0.                                        */
+int rmcl_grad_ready_wait(int layer, void* stream);
 int rmcl_set_side_stream(void* stream);
 
 /* Test hook: x[i] *= dropout_mask(site seed of (drop_seed, layer, site), i), i < n (x pre-filled with ones gives the mask).

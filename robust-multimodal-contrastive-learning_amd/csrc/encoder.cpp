@@ -219,6 +219,17 @@ int ensure_events() {
 
 extern "C" int rmcl_set_side_stream(void* stream) { g_side = (hipStream_t)stream; return 0; }
 
+// ---- gradient-ready events of the last weight-gradient backward (overlapped data-parallel all-reduce) ----
+static int g_grad_layers = 0;      // 0: no full backward has run
+static bool g_grad_side = false;   // the weight gradients of that backward ran on the side stream
+extern "C" int rmcl_grad_ready_wait(int layer, void* stream) {
+  RMCL_REQUIRE(g_grad_layers > 0, "grad_ready_wait: no weight-gradient backward has been enqueued");
+  RMCL_REQUIRE(layer >= 0 && layer < g_grad_layers && layer < 32, "grad_ready_wait: bad layer");
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, g_ev[(3 * 32 + layer) & 127], 0));                 // dX chain + LayerNorm grads
+  if (g_grad_side) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, g_ev[(2 * 32 + layer) & 127], 0));  // weight-gradient GEMMs
+  return 0;
+}
+
 int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* probs, float* scores, int B, int N, int H, int dt,
                             int exact, hipStream_t s) {
   // bf16 fast path: fused kernel; `probs` then holds only the per-row log-sum-exp (fp32 [B,H,NKP])
@@ -436,7 +447,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   const float dinv = 1.0f / (1.0f - drop_p);
   const bool lpm = dt != RMCL_F32 || dth != 0;      // a (masked) copy of dx in the GEMM operand type is needed
   const bool use_side = full && lpm && g_side != nullptr;
-  if (use_side) RMCL_TRY(ensure_events());
+  if (use_side || full) RMCL_TRY(ensure_events());
   void* T[2] = {lpm ? w.dxT : nullptr, lpm ? (use_side ? w.dxT2 : w.dxT) : nullptr};
   void* DU[2] = {w.du, use_side ? w.du2 : w.du};
   void* DQ[2] = {w.dqkv, use_side ? w.dqkv2 : w.dqkv};
@@ -508,7 +519,12 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
                             full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, T[cur ^ 1], dt,
                             rmcl_site_seed(drop_seed, l - 1, DROP_SITE_FC2), l > 0 ? dth : 0u, dinv, s));
     cur ^= 1;
+    if (full) {                                                                            // layer l's gradients are complete after
+                                                                                           // this event (+ EV(2, l) on the side stream)
+      HIP_TRY(hipEventRecord(EV(3, l), s));
+    }
   }
+  if (full) { g_grad_layers = Lr; g_grad_side = use_side; }
   if (use_side) HIP_TRY(hipStreamWaitEvent(s, EV(2, 0), 0));                               // join: all side work done
 
   // ---- embeddings ----

@@ -146,6 +146,7 @@ class Engine:
         self.pass_counter = 0
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.dw_stream = torch.cuda.Stream(device=self.device)
+        self.comm_stream = torch.cuda.Stream(device=self.device)     # gradient all-reduces (N > 1), gated on backward events
         if os.environ.get("RMCL_NO_DW_STREAM", "0") != "1":          # weight-gradient GEMMs concurrent with the dX chain
             lib.rmcl_set_side_stream(C.c_void_p(self.dw_stream.cuda_stream))
 

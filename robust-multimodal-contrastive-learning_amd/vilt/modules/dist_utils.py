@@ -71,3 +71,55 @@ def allreduce_mean_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, as
         if async_op:
             works.append(w)
     return works
+
+
+def grad_buckets(layer0: int, layer_stride: int, layers: int, total: int):
+    """Buckets of the flat gradient arena in the order their gradients become final during the backward:
+    (gate_layer, start, end).  gate_layer = l: ready once encoder layer l's backward has finished; -1: ready only
+    when the whole backward has (embeddings).  Layer L-1's bucket also carries everything behind the layers
+    (final norm, pooler, heads), which the backward writes first."""
+    out = []
+    end_layers = layer0 + layers * layer_stride
+    for l in range(layers - 1, -1, -1):
+        s = layer0 + l * layer_stride
+        e = s + layer_stride if l < layers - 1 else max(total, end_layers)
+        out.append((l, s, e))
+    if layer0 > 0:
+        out.append((-1, 0, layer0))
+    return out
+
+
+class GradSync:
+    """Overlapped data-parallel gradient averaging (replaces DDP's bucketed all-reduce hooks, run.py:96): one all-reduce
+    per encoder layer (28 MB fp32 - xGMI rings want few, large messages), issued on a communication stream that waits
+    on that layer's gradient-ready events (rmcl_grad_ready_wait), so RCCL runs while the layers below are still in
+    their backward.  ``wait()`` makes the current stream wait for all of them (call before the optimizer step)."""
+
+    def __init__(self, flat: torch.Tensor, buckets, comm_stream, gate):
+        self.works = []
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        ws = world_size()
+        avg = dist.get_backend() == "nccl"
+        main = torch.cuda.current_stream() if flat.is_cuda else None
+        for layer, s, e in buckets:
+            chunk = flat[s:e]
+            if flat.is_cuda:
+                if layer >= 0:
+                    gate(layer, comm_stream)
+                else:
+                    comm_stream.wait_stream(main)
+                with torch.cuda.stream(comm_stream):
+                    if avg:
+                        self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+                    else:
+                        chunk.div_(ws)
+                        self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                chunk.div_(ws)
+                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []

@@ -53,6 +53,11 @@ def compute_geometric(pl_module, batch, loss_name, k_modality=None):
     return batch
 
 
+def _only_moco(pl_module):
+    ln = pl_module.hparams.config["loss_names"]
+    return ln.get("moco", 0) > 0 and sum(1 for v in ln.values() if v > 0) == 1
+
+
 def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_original, ret, phase):
     """One attacked view (objectives.py:287-317 / :324-354 / :362-392): encoder forward on `op` with the text in
     `pv`, InfoNCE against the queue, metrics, and a loss tensor whose backward runs the HIP backward."""
@@ -79,7 +84,8 @@ def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_origin
         dq = dq_saved * grad_out.to(dq_saved.dtype)
         eng.heads_backward(pv, dq, None, with_grads=True)
         eng.encoder_backward(pv, L.MODE_FULL, op, pv.dcls, cls_only=True, dpatches=None)
-        pl_module.after_backward()
+        # one attacked view = one backward per step: its gradient all-reduces can start layer by layer right away
+        pl_module.after_backward(overlap=(pl_module.image_view != pl_module.text_view) and _only_moco(pl_module))
 
     return _DeferredBackward.apply(pl_module.grad_anchor, value, backward)
 

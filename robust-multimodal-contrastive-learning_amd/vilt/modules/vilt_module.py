@@ -5,12 +5,15 @@ minimal ``log`` / ``hparams`` shim), the caller may be any loop that does
 ``loss = m.training_step(batch, i); loss.backward(); opt.step()``."""
 from __future__ import annotations
 
+import ctypes as C
+import os
 import types
 
 import torch
 import torch.nn as nn
 
 from ... import _lib as L
+from ..._lib import lib, check
 from ...runtime import Engine, EMA_GROUPS
 from ...attack.pgd_attack_vilt import PGDAttack_moco
 from ...attack.greedy_attack_vilt import GreedyAttack_moco
@@ -125,10 +128,35 @@ class ViLTransformerSS(nn.Module):
         self._queue_ptr_host = int(v)
         self.proj_queue_ptr.fill_(int(v))
 
-    def after_backward(self):
-        """DDP replacement: average the flat gradient arena over ranks (run.py:96)."""
-        if self.sync_grads and dist_utils.world_size() > 1:
-            dist_utils.allreduce_mean_(self.engine.g32)
+    def after_backward(self, overlap: bool = False):
+        """DDP replacement: average the flat gradient arena over ranks (run.py:96).  Called by the deferred-backward
+        closures right after the HIP backward has been ENQUEUED.  overlap=True (the MoCo step: one backward per
+        step): per-layer all-reduces gated on the backward's gradient-ready events; otherwise one blocking pass."""
+        import torch.distributed as dist
+        if not (self.sync_grads and dist.is_available() and dist.is_initialized()):
+            return
+        e = self.engine
+        if overlap and e.g32.is_cuda and os.environ.get("RMCL_NO_GRAD_OVERLAP", "0") != "1":
+            lay = e.layout
+            buckets = dist_utils.grad_buckets(int(lay.layer0), int(lay.layer_stride), int(self.hparams.config["num_layers"]),
+                                              int(e.g32.numel()))
+
+            def gate(layer, stream):
+                check(lib.rmcl_grad_ready_wait(int(layer), C.c_void_p(stream.cuda_stream)), "grad_ready_wait")
+
+            self.wait_grad_sync()
+            self._grad_sync = dist_utils.GradSync(e.g32, buckets, e.comm_stream, gate)
+        else:
+            self.wait_grad_sync()
+            if dist_utils.world_size() > 1:
+                dist_utils.allreduce_mean_(e.g32)
+
+    def wait_grad_sync(self):
+        """Make the current stream wait for the overlapped gradient all-reduces (the optimizer calls this)."""
+        gs = getattr(self, "_grad_sync", None)
+        if gs is not None:
+            gs.wait()
+            self._grad_sync = None
 
     def zero_grad(self, set_to_none: bool = False):
         self.engine.zero_grads()

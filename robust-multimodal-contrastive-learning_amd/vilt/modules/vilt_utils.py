@@ -28,6 +28,7 @@ class FusedAdamW:
     def __init__(self, pl_module, lr, wd, lr_mult, betas=(0.9, 0.98), eps=1e-8):
         eng = pl_module.engine
         self.eng = eng
+        self.module = pl_module
         self.betas, self.eps = betas, eps
         self.m = torch.zeros_like(eng.q32)
         self.v = torch.zeros_like(eng.q32)
@@ -54,6 +55,7 @@ class FusedAdamW:
     def step(self):
         self.t += 1
         e = self.eng
+        self.module.wait_grad_sync()                       # overlapped data-parallel all-reduces (N > 1)
         check(lib.rmcl_adamw_f32(P(e.q32), P(e.g32), P(self.m), P(self.v), P(e.q_lp), P(self.seg_end), P(self.seg_mult),
                                  P(self.seg_wd), int(self.seg_end.numel()), F(self.param_groups[0]["lr"]), F(self.betas[0]),
                                  F(self.betas[1]), F(self.eps), self.t, F(self.grad_scale), I64(e.q32.numel()), stream_ptr()),

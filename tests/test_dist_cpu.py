@@ -42,6 +42,13 @@ def _worker(rank, world, initfile, out_dir):
         dist_utils.allreduce_mean_(grads, bucket_elems=256)
         expect = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
         assert torch.allclose(grads, expect)
+        # bucketed (per-layer) gradient sync, the order the overlapped GPU path issues it in
+        layer0, stride, layers, total = 37, 50, 4, 300
+        buckets = dist_utils.grad_buckets(layer0, stride, layers, total)
+        g2 = torch.arange(total, dtype=torch.float32) * (rank + 1)
+        sync = dist_utils.GradSync(g2, buckets, None, None)
+        sync.wait()
+        assert torch.allclose(g2, torch.arange(total, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
         torch.save({"queue": queue, "keys": keys_all}, os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
@@ -60,6 +67,17 @@ def test_queue_advance_rejects_wraparound():
     with pytest.raises(RuntimeError):
         dist_utils.queue_advance(60, 8, 64, per_step_bs=8)
     assert dist_utils.queue_advance(56, 8, 64, per_step_bs=8) == (True, 0)
+
+
+def test_grad_buckets_tile_the_arena_in_backward_order():
+    from rmcl_amd.vilt.modules import dist_utils
+    layer0, stride, layers, total = 1000, 700, 12, 1000 + 12 * 700 + 321
+    b = dist_utils.grad_buckets(layer0, stride, layers, total)
+    assert [x[0] for x in b] == list(range(11, -1, -1)) + [-1]                 # last layer first, embeddings last
+    assert b[0] == (11, layer0 + 11 * stride, total)                           # + final norm / pooler / heads behind the layers
+    covered = sorted((s, e) for _, s, e in b)
+    assert covered[0][0] == 0 and covered[-1][1] == total
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
 
 
 def test_single_process_is_a_no_op():

@@ -3,6 +3,8 @@
   (2) the CPU oracle on fresh seeded inputs.
 Tolerances: fp32 path -> north_star's 1e-3 on loss/logits (tighter where fp32 allows);
 bf16 path -> documented drift bounds (bf16 has 8 significant bits; logits ~ +-40)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -254,6 +256,54 @@ def test_weight_gradient_kernels_agree_bs64():
             a, b = grads[0][base + off: base + off + n], grads[1][base + off: base + off + n]
             rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
             assert rel < 3e-2, (l, off, rel)
+
+
+def test_overlapped_gradient_sync_is_exact_on_one_rank():
+    """The N > 1 gradient path (per-layer all-reduces on the communication stream, gated on the backward's
+    gradient-ready events) run over a 1-rank RCCL group: averaging over one rank is the identity, so the gradients must
+    equal the unsynchronised run (weight matrices bit for bit) - a missing event / stream dependency shows up as a torn
+    bucket."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        ocfg = O.default_config(num_layers=3, num_negative=1024, per_gpu_batchsize=64, adv_steps_img=1)
+        m, p = build_module(ocfg, 5, "bf16")
+        (opt,), _ = m.configure_optimizers()
+        batch = dev_batch(O.synthetic_batch(ocfg, 64, 9))
+        q0 = m.engine.q32.clone()
+        outs = []
+        for sync in (False, True):
+            m.sync_grads = sync
+            m.engine.q32.copy_(q0)
+            m.engine.lp_stale = True
+            opt.m.zero_(); opt.v.zero_(); opt.t = 0
+            m.zero_grad()
+            m.queue_ptr = 0
+            m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+            m.shadow_momentum_encoder()
+            loss = m.training_step(batch, 0)
+            loss.backward()
+            assert (getattr(m, "_grad_sync", None) is not None) == sync
+            opt.step()
+            torch.cuda.synchronize()
+            outs.append((m.engine.g32.clone(), m.engine.q32.clone()))
+        lay = m.engine.layout
+        for l in range(3):                                     # weight-matrix gradients: ordered slab reduce -> bitwise
+            base = lay.layer0 + l * lay.layer_stride
+            for off, n in ((lay.qkv_w, 3 * 768 * 768), (lay.proj_w, 768 * 768), (lay.fc1_w, 3072 * 768), (lay.fc2_w, 3072 * 768)):
+                assert torch.equal(outs[0][0][base + off: base + off + n], outs[1][0][base + off: base + off + n]), (l, off)
+        # bias / LayerNorm gradients use float atomics (summation order varies run to run)
+        assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4 * float(outs[1][0].abs().max())
+        assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2.1 * float(opt.param_groups[0]["lr"]) * 10
+    finally:
+        m.sync_grads = True
+        if created:
+            dist.destroy_process_group()
 
 
 def test_text_attack_and_three_view_step_match_oracle():
