@@ -147,6 +147,8 @@ def main():
     from rmcl_amd.vilt.config import task_moco
     from rmcl_amd.vilt.modules import ViLTransformerSS
 
+    if world > 1:
+        L.check(L.lib.rmcl_tune_set(1, 8), "tune_set")     # leave 8 CUs to RCCL's channels (include/rmcl.h)
     B, K = args.batch, args.adv_steps
     cfg = task_moco(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=args.drop_rate, image_view=True,
                     text_view=False, max_steps=100000)

@@ -103,8 +103,10 @@ int rmcl_dropout_mask_apply(float* x, int64_t n, uint32_t drop_seed, int layer, 
   return rmcl_dropout_apply(x, n, rmcl_site_seed(drop_seed, layer, site), (uint32_t)((double)drop_p * 4294967296.0), 1.0f / (1.0f - drop_p),
                             (hipStream_t)stream);
 }
+extern int g_st_reserve_cus;
 int rmcl_tune_set(int key, int value) {
   if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }
+  if (key == 1) { g_st_reserve_cus = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }   // CUs left free by the activation GEMMs
   rmcl_set_error("tune_set: unknown key");
   return -1;
 }

@@ -340,6 +340,7 @@ double rmcl_gemm_st_fill(const GemmArgs& g) {
   return (double)tiles / (double)(cdiv(tiles, 256L) * 256L);
 }
 
+int g_st_reserve_cus = 8;            // CUs left to other kernels (rmcl_tune_set key 1; RCCL channels, side-stream kernels): free at M = 64*185
 int g_st_xflags = 0;                 // experiment switch (rmcl_tune_set key 0, values 61.. -> xflags = value - 60)
 
 static int st_num_cus() {
@@ -361,7 +362,8 @@ static int launch_st3(const GemmArgs& g, hipStream_t s) {
   // a tile costs the same whether 185 or 192 of its rows are live, so the fewest row tiles win; they share M evenly
   const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = A_KC ? cdiv(g.M, tm) : ST_T;
   const int items = tm * tn * (g.splitk > 1 ? g.splitk : 1);
-  const int grid = min(items, st_num_cus());
+  // M = 64 * 185 gives 62 row tiles: 248 x {1, 3, 4} tiles for N = 768 / 2304 / 3072, so a 248-workgroup grid loses nothing
+  const int grid = min(items, max(8, st_num_cus() - (A_KC ? g_st_reserve_cus : 0)));
   RMCL_LAUNCH((gemm_st_kernel<A_KC, B_KC, AUX, TO>), dim3(grid), dim3(512), ST_LDS, s, g, tm, tn, rows, g_st_xflags);
   RMCL_CHECK_LAUNCH();
   return 0;
