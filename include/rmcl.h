@@ -67,8 +67,9 @@ int rmcl_version(void);
  * recorded around each launch on the launch stream; used by bench.py for the roofline object.
  * rmcl_prof_end synchronises the recorded events and returns total ms, launches and algorithmic FLOPs. */
 /* Tuning knobs (developer use).  key 0: bf16 GEMM tile/pipeline configuration (-1 = automatic).
- * key 1: number of CUs the persistent activation GEMMs leave to other kernels (0 = none; multi-GPU runs pass 8 so that
- * RCCL's channel workgroups do not displace GEMM workgroups - at M = 64*185 a 248-workgroup grid costs nothing).          */
+ * key 1: number of CUs the persistent activation GEMMs leave to other kernels (default 8, so that RCCL's
+ * channel workgroups and small side-stream kernels do not displace GEMM workgroups - at M = 64*185 the 62 x {4,12,16} tiles
+ * are whole multiples of a 248-workgroup grid, so this costs nothing).                                                     */
 int rmcl_tune_set(int key, int value);
 
 /* Optional second HIP stream: the weight-gradient GEMMs of rmcl_encoder_backward (mode FULL, bf16) then run
