@@ -78,19 +78,25 @@ int rmcl_text_embed_fwd(const long* ids, const float* word, const float* pos, co
 __global__ __launch_bounds__(256) void text_embed_scatter_kernel(const long* __restrict__ ids, const float* __restrict__ de,
                                                                  float* __restrict__ dword, float* __restrict__ dpos,
                                                                  float* __restrict__ dbtype0, int B, int L, int D, long pad_id) {
-  const int r = blockIdx.x, t = r % L;
-  const long id = ids[r];
-  for (int c = threadIdx.x; c < D; c += 256) {
-    const float v = de[(long)r * D + c];
-    if (id != pad_id) atomicAdd(dword + id * D + c, v);
-    atomicAdd(dpos + (long)t * D + c, v);
-    atomicAdd(dbtype0 + c, v);
+  if ((int)blockIdx.x < B * L) {                             // word table: one token row per block (ids rarely collide)
+    const int r = blockIdx.x;
+    const long id = ids[r];
+    if (id == pad_id) return;
+    for (int c = threadIdx.x; c < D; c += 256) atomicAdd(dword + id * D + c, de[(long)r * D + c]);
+  } else {                                                   // position t: ordered sum over the batch, then L adders per type-0 column
+    const int t = blockIdx.x - B * L;                        // (was: every one of the B*L rows adding into the same D addresses)
+    for (int c = threadIdx.x; c < D; c += 256) {
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) acc += de[((long)b * L + t) * D + c];
+      atomicAdd(dpos + (long)t * D + c, acc);
+      atomicAdd(dbtype0 + c, acc);
+    }
   }
 }
 
 int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, float* dpos, float* dbtype0, int B, int L, int D,
                             long pad_id, hipStream_t s) {
-  RMCL_LAUNCH(text_embed_scatter_kernel, dim3(B * L), dim3(256), 0, s, ids, de, dword, dpos, dbtype0, B, L, D, pad_id);
+  RMCL_LAUNCH(text_embed_scatter_kernel, dim3(B * L + L), dim3(256), 0, s, ids, de, dword, dpos, dbtype0, B, L, D, pad_id);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -343,20 +349,28 @@ int rmcl_pgd_update(const void* g, int dt, float* delta, unsigned* amax_bits, in
 // mean over (b, y, x) of the channel-wise L2 norm of delta (objectives.py:184), delta in patch layout
 // [B*P, C*pp]: out += sum_{row, i<pp} sqrt(sum_c delta[row][c*pp + i]^2)   (caller divides by B*P*pp)
 __global__ __launch_bounds__(256) void delta_chan_norm_kernel(const float* __restrict__ d, float* __restrict__ out, long rows, int C, int pp) {
+  __shared__ float red[4];
   float acc = 0.f;
-  const long total = rows * pp;
+  const int pv = pp / 4;                                     // pp % 4 == 0 (launcher): float4 per lane
+  const long total = rows * pv;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const long r = i / pp;
-    const int k = (int)(i % pp);
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) { const float v = d[r * ((long)C * pp) + (long)c * pp + k]; s += v * v; }
-    acc += sqrtf(s);
+    const long r = i / pv;
+    const int k = (int)(i % pv) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < C; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(d + r * ((long)C * pp) + (long)c * pp + k);
+      s.x += v.x * v.x; s.y += v.y * v.y; s.z += v.z * v.z; s.w += v.w * v.w;
+    }
+    acc += sqrtf(s.x) + sqrtf(s.y) + sqrtf(s.z) + sqrtf(s.w);
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));   // one atomic per block
 }
 int rmcl_delta_chan_norm(const float* d, float* out, long rows, int C, int pp, hipStream_t s) {
-  RMCL_LAUNCH(delta_chan_norm_kernel, dim3(std::min<long>(cdiv(rows * pp, 256), 2048)), dim3(256), 0, s, d, out, rows, C, pp);
+  RMCL_REQUIRE(pp % 4 == 0, "delta_chan_norm: pixels per patch % 4");
+  RMCL_LAUNCH(delta_chan_norm_kernel, dim3(std::min<long>(cdiv(rows * (pp / 4), 256), 2048)), dim3(256), 0, s, d, out, rows, C, pp);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

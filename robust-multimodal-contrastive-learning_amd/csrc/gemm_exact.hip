@@ -242,8 +242,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   const float* B = reinterpret_cast<const float*>(g.B);
   const int nc = min(n, g.N - 1);
   B += B_KC ? (long)nc * g.ldb + 4 * gq : (long)(4 * gq) * g.ldb + nc;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+  // four independent accumulator chains (the 16x16x4 MFMA is 8 passes deep: one chain would serialise on its own latency)
+  // and 8 k-steps of loads in flight; the chains are summed in k order at the end.  NOTE: this changes the summation
+  // order relative to a single chain only in the last bits (heads: fp32, tolerance 1e-5).
+  f32x4 ac[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 8
   for (int k0 = 0; k0 < g.K; k0 += 16) {
     const float4 a = *reinterpret_cast<const float4*>(A + k0);
     float b[4];
@@ -254,11 +257,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = B[(long)(k0 + j) * g.ldb];
     }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3], acc, 0, 0, 0);
+    ac[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], ac[0], 0, 0, 0);
+    ac[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[1], ac[1], 0, 0, 0);
+    ac[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2], ac[2], 0, 0, 0);
+    ac[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3], ac[3], 0, 0, 0);
   }
+  f32x4 acc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r]);
   float* C = reinterpret_cast<float*>(g.C);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(PD) void infonce_combine_kernel(const float* __rest
   }
   // pass 2: Z and dq (each thread owns column c of dq)
   float Z = 0.f, acc = 0.f;
+#pragma unroll 16                                           // independent loads: keep 16 slices in flight (was latency-bound: 512 serial round trips)
   for (int s = 0; s < nslice; ++s) {
     const float* o = part + ((long)s * Bpad + i) * NPART;
     const float f = __expf(o[0] - M);
