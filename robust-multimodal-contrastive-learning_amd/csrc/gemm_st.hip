@@ -179,7 +179,9 @@ __device__ __forceinline__ void st_tile_setup(STTile& T, const GemmArgs& g, int 
 
 // epilogue (order: alpha, bias, gelu'(aux), save pre-activation, gelu, residual, accumulate; as gemm_fast.hip).  All
 // loads of the tile are issued first (rows past the tile end read a clamped row), only the stores are predicated.
-template <int AUX, typename TO>
+// DROP: dropout epilogues (counter-based masks, rmcl_common.h) compiled in - a separate instantiation so that the
+// parity / headline configuration (drop_rate 0) carries none of their live state.
+template <int AUX, typename TO, bool DROP>
 __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const GemmArgs& g, const STTile& T, int wm, int wn, int lane) {
   const int epi = g.epi;
   TO* C = reinterpret_cast<TO*>(g.C) + T.zoff;
@@ -208,6 +210,11 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
     for (int j = 0; j < 3; ++j) {
       float v[4] = {g.alpha * acc[i][j][0] + bias[j].x, g.alpha * acc[i][j][1] + bias[j].y, g.alpha * acc[i][j][2] + bias[j].z,
                     g.alpha * acc[i][j][3] + bias[j].w};
+      if (DROP && (epi & EPI_DROP_BWD)) {                    // mask of the forward's hidden dropout, indexed like the stash
+        const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, di + r, g.drop_thresh, g.drop_inv_keep);
+      }
       if (AUX == ST_AUX_DGELU) {
         const uint2 u = pre[i][j];
         v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
@@ -218,6 +225,10 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
       if (epi & EPI_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+      }
+      if (DROP && (epi & EPI_DROPOUT)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, (uint32_t)ci + r, g.drop_thresh, g.drop_inv_keep);
       }
       if (AUX == ST_AUX_RES) { v[0] += res[i][j].x; v[1] += res[i][j].y; v[2] += res[i][j].z; v[3] += res[i][j].w; }
       if constexpr (sizeof(TO) == 4) {
@@ -231,7 +242,7 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
   }
 }
 
-template <bool A_KC, bool B_KC, int AUX, typename TO>
+template <bool A_KC, bool B_KC, int AUX, typename TO, bool DROP>
 __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile, int xflags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
       sc = sc == 2 ? 0 : sc + 1;
       st_tile<2, A_KC, B_KC>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
     }
-    st_epilogue<AUX, TO>(acc, g, cur, wm, wn, lane);
+    st_epilogue<AUX, TO, DROP>(acc, g, cur, wm, wn, lane);
     if (nid < 0) break;
     cur = nxt;
   }
@@ -329,7 +340,7 @@ bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
     if (b_kc || g.M % ST_T != 0 || (g.epi & ~EPI_ACCUM)) return false;
     return true;
   }
-  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_ACCUM)) return false;
+  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_ACCUM | EPI_DROPOUT | EPI_DROP_BWD)) return false;
   if ((g.epi & EPI_RESIDUAL) && (g.epi & EPI_DGELU)) return false;
   return true;
 }
@@ -352,11 +363,11 @@ static int st_num_cus() {
   return n;
 }
 
-template <bool A_KC, bool B_KC, int AUX, typename TO>
+template <bool A_KC, bool B_KC, int AUX, typename TO, bool DROP = false>
 static int launch_st3(const GemmArgs& g, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<A_KC, B_KC, AUX, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<A_KC, B_KC, AUX, TO, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
     attr = true;
   }
   // a tile costs the same whether 185 or 192 of its rows are live, so the fewest row tiles win; they share M evenly
@@ -364,13 +375,15 @@ static int launch_st3(const GemmArgs& g, hipStream_t s) {
   const int items = tm * tn * (g.splitk > 1 ? g.splitk : 1);
   // M = 64 * 185 gives 62 row tiles: 248 x {1, 3, 4} tiles for N = 768 / 2304 / 3072, so a 248-workgroup grid loses nothing
   const int grid = min(items, max(8, st_num_cus() - (A_KC ? g_st_reserve_cus : 0)));
-  RMCL_LAUNCH((gemm_st_kernel<A_KC, B_KC, AUX, TO>), dim3(grid), dim3(512), ST_LDS, s, g, tm, tn, rows, g_st_xflags);
+  RMCL_LAUNCH((gemm_st_kernel<A_KC, B_KC, AUX, TO, DROP>), dim3(grid), dim3(512), ST_LDS, s, g, tm, tn, rows, g_st_xflags);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
 
 template <bool B_KC, int AUX>
 static int launch_st2(const GemmArgs& g, int dt_out, hipStream_t s) {
+  if (g.epi & (EPI_DROPOUT | EPI_DROP_BWD))
+    return dt_out == RMCL_F32 ? launch_st3<true, B_KC, AUX, float, true>(g, s) : launch_st3<true, B_KC, AUX, bf16_t, true>(g, s);
   return dt_out == RMCL_F32 ? launch_st3<true, B_KC, AUX, float>(g, s) : launch_st3<true, B_KC, AUX, bf16_t>(g, s);
 }
 

@@ -225,6 +225,44 @@ def test_side_stream_weight_gradients_are_race_free():
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-4 * float(grads[1].abs().max())    # bias grads use float atomics
 
 
+def test_dropout_step_kernels_agree_bs64():
+    """Training-realistic configuration (drop_rate 0.1, reference default config.py:57) at B = 64: the dropout epilogues of
+    the 192x192 kernels against those of the 128x128 kernels.  The masks are a pure function of (pass seed, layer, site,
+    element), so with the pass counter rewound both runs draw identical masks and must agree like the no-dropout runs."""
+    from rmcl_amd._lib import lib
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=64, adv_steps_img=1)
+    cfg = task_moco(num_layers=2, num_negative=1024, adv_steps_img=1, per_gpu_batchsize=64, drop_rate=0.1, image_view=True,
+                    text_view=False, num_gpus=1, num_nodes=1)
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype="bf16")
+    m.load_state_dict({n: t.to(DEV) for n, t in O.init_params(ocfg, 5).items()}, strict=False)
+    m.train()
+    batch = dev_batch(O.synthetic_batch(ocfg, 64, 9))
+    grads, losses = [], []
+    try:
+        for cfgk in (-1, 2):
+            lib.rmcl_tune_set(0, cfgk)
+            m.engine.pass_counter = 0
+            m.zero_grad()
+            m.queue_ptr = 0
+            m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+            m.shadow_momentum_encoder()
+            loss = m.training_step(batch, 0)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads.append(m.engine.g32.clone())
+            losses.append(float(loss))
+    finally:
+        lib.rmcl_tune_set(0, -1)
+    assert abs(losses[0] - losses[1]) < 2e-2 * abs(losses[1])
+    lay = m.engine.layout
+    for l in range(2):
+        base = lay.layer0 + l * lay.layer_stride
+        for off, n in ((lay.qkv_w, 3 * 768 * 768), (lay.proj_w, 768 * 768), (lay.fc1_w, 3072 * 768), (lay.fc2_w, 3072 * 768)):
+            a, b = grads[0][base + off: base + off + n], grads[1][base + off: base + off + n]
+            rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert rel < 3e-2, (l, off, rel)
+
+
 def test_weight_gradient_kernels_agree_bs64():
     """B = 64 (tokens = 11840): the 192x192 ping-pong kernels (activation GEMMs + [K][M]x[K][N] split-K weight gradients)
     against the 128x128 kernels (tune cfg 2) on the same step - same bf16 operands, fp32 accumulation, so only the
