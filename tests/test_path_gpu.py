@@ -196,6 +196,39 @@ def test_itm_wpa_matches_reference_golden(tag):
         np.testing.assert_allclose(mine[3:], dg[3:], atol=5e-3 * dg[2] + 1e-7, err_msg=str(name))
 
 
+def test_itm_wpa_full_size_bs64_kernels_agree():
+    """BASELINE configs[1] size (clean ITM + word-patch alignment, bs=64, bf16): the step on the 192x192 kernels against the
+    128x128 kernels (tune cfg 2), same labels and inputs; plus size-independent properties of the objective."""
+    from rmcl_amd._lib import lib
+    B = 64
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=B)
+    cfg = task_moco(num_layers=2, num_negative=1024, per_gpu_batchsize=B, drop_rate=0.0, num_gpus=1, num_nodes=1)
+    cfg["loss_names"] = dict(cfg["loss_names"], moco=0, itm=1)
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype="bf16")
+    p = O.init_params(ocfg, 3)
+    m.load_state_dict({n: t.to(DEV) for n, t in p.items() if not n.startswith("k_") and not n.startswith("moco_head")}, strict=False)
+    m.train()
+    g = torch.Generator().manual_seed(11)
+    m.itm_labels_override = (torch.rand(B, generator=g) < 0.5).long()
+    batch = dev_batch(O.synthetic_batch(ocfg, B, 13, ragged_text=True))
+    out = []
+    try:
+        for cfgk in (-1, 2):
+            lib.rmcl_tune_set(0, cfgk)
+            m.zero_grad()
+            loss = m.training_step(batch, 0)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((float(loss), m.logged["itm/train/loss"].item(), m.logged["itm/train/wpa_loss"].item(), m.engine.g32.clone()))
+    finally:
+        lib.rmcl_tune_set(0, -1)
+    (l0, i0, w0, g0), (l1, i1, w1, g1) = out
+    assert np.isfinite(l0) and 0.3 < i0 < 1.5                                   # 2-class CE of an untrained head ~ ln 2
+    assert abs(l0 - (i0 + w0)) < 1e-4                                           # total = itm + wpa (vilt_module.py:475)
+    assert abs(i0 - i1) < 2e-2 and abs(w0 - w1) < 2e-2 * max(1.0, abs(w1))
+    assert float((g0 - g1).norm() / g1.norm()) < 3e-2
+
+
 def test_side_stream_weight_gradients_are_race_free():
     """The weight-gradient GEMMs run on a second stream behind events; the split-K slab reduce is ordered,
     so weight-matrix gradients must be BITWISE equal with and without the side stream."""
