@@ -222,7 +222,7 @@ def test_im2patch_roundtrip():
 
 
 # ------------------------------------------------------------------ bf16 MFMA GEMM (fast path)
-@pytest.mark.parametrize("cfg", [-1, 1, 30, 60])
+@pytest.mark.parametrize("cfg", [-1, 1, 30, 50, 60])
 @pytest.mark.parametrize("shape", [(11840, 768, 768), (300, 128, 64), (1000, 3072, 768), (256, 768, 3072), (555, 192, 128), (9216, 2304, 192)])
 def test_gemm_fast_bf16_layouts(shape, cfg):
     """exact=0 routes to the glds/tr-read MFMA kernel; reference = fp64 matmul of the same bf16 inputs,
