@@ -22,6 +22,9 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 #define SCALE 0.125f
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define SCALE_L2 (SCALE * LOG2E)   // scores are kept in the log2 domain: v_exp_f32 is exp2, so exp(s - m) costs one subtract + one v_exp
 #define ATT_QW 8            // waves per workgroup of the forward kernel: 12 query tiles -> 1-2 per wave
 #define ATT_DQW 4           // dQ kernel: its 96 score/dP accumulators + hoisted fragments need > 256 VGPRs, so one wave per SIMD
 
@@ -131,9 +134,9 @@ __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __r
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const float4 bias = *reinterpret_cast<const float4*>(mb + kt * 16 + 4 * g);
-      S[kt][0] = S[kt][0] * SCALE + bias.x; S[kt][1] = S[kt][1] * SCALE + bias.y;
-      S[kt][2] = S[kt][2] * SCALE + bias.z; S[kt][3] = S[kt][3] * SCALE + bias.w;
+      const float4 bias = *reinterpret_cast<const float4*>(mb + kt * 16 + 4 * g);   // 0 or -inf: the same in either log base
+      S[kt][0] = fmaf(S[kt][0], SCALE_L2, bias.x); S[kt][1] = fmaf(S[kt][1], SCALE_L2, bias.y);
+      S[kt][2] = fmaf(S[kt][2], SCALE_L2, bias.z); S[kt][3] = fmaf(S[kt][3], SCALE_L2, bias.w);
       m = fmaxf(m, fmaxf(fmaxf(S[kt][0], S[kt][1]), fmaxf(S[kt][2], S[kt][3])));
     }
     m = group_max(m);
@@ -141,10 +144,10 @@ __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __r
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { S[kt][r] = __expf(S[kt][r] - m); l += S[kt][r]; }
+      for (int r = 0; r < 4; ++r) { S[kt][r] = __builtin_amdgcn_exp2f(S[kt][r] - m); l += S[kt][r]; }
     l = group_sum(l);
     const int q_lane = qt * 16 + (lane & 15);
-    if (g == 0 && q_lane < N) lse[((long)blockIdx.x) * NKP + q_lane] = m + __logf(l);
+    if (g == 0 && q_lane < N) lse[((long)blockIdx.x) * NKP + q_lane] = m * LN2 + __logf(l);   // natural-log lse, as the backward expects
     // O^T = V^T P^T: swapped operands leave the lane with 4 adjacent head dims of query lane%16 -> 8-byte stores, and the
     // row's 1/l is already in the lane
     f32x4 O[4];
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(ATT_DQW * 64) void attn_bwd_dq_kernel(const bf16_t*
   __syncthreads();
   for (int qt = wave; qt < nqt; qt += ATT_DQW) {
     bf16x8 qf[2] = {qn[0], qn[1]}, df[2] = {dn[0], dn[1]};
-    const float L = Ln;
+    const float L = Ln * LOG2E;                                 // (+inf for pad rows stays +inf)
     const int q_lane = qt * 16 + (lane & 15);
     if (qt + ATT_DQW < nqt) {
 #pragma unroll
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(ATT_DQW * 64) void attn_bwd_dq_kernel(const bf16_t*
       const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        S[kt][r] = __expf(S[kt][r] * SCALE + bb[r] - L);       // P
+        S[kt][r] = __builtin_amdgcn_exp2f(fmaf(S[kt][r], SCALE_L2, bb[r] - L));   // P
         dl += S[kt][r] * dP[kt][r];
       }
     }
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
   stage_rows<true, NW>(Qtr, base, ld, N, NKP, wave, lane);
   stage_rows<true, NW>(Dtr, dob, D, N, NKP, wave, lane);
   for (int j = t; j < NKP; j += NW * 64) {
-    Ls[j] = j < N ? lse[((long)blockIdx.x) * NKP + j] : INFINITY;
+    Ls[j] = j < N ? lse[((long)blockIdx.x) * NKP + j] * LOG2E : INFINITY;   // log2 domain
     Ds[j] = j < N ? delta[((long)blockIdx.x) * NKP + j] : 0.f;
   }
   // this wave's key tiles: kt = wave + NW*i ; K / V fragments and key mask stay in registers
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
       f32x4 P, dS;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        P[r] = __expf(S[r] * SCALE + mbk[i] - Lr[r]);
+        P[r] = __builtin_amdgcn_exp2f(fmaf(S[r], SCALE_L2, mbk[i] - Lr[r]));
         dS[r] = P[r] * (dP[r] - Dr[r]) * SCALE;
       }
       const s16x4 pa = pack4(P), sa = pack4(dS);
