@@ -6,7 +6,7 @@ OUT=../lib
 mkdir -p "$OUT" obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast"
 pids=()
-for f in gemm_exact.hip gemm_fast.hip gemm_big.hip gemm_pp.hip gemm_st.hip norm_softmax.hip embed_misc.hip infonce.hip ipot.hip itm.hip attention.hip encoder.cpp api.cpp; do
+for f in gemm_exact.hip gemm_fast.hip gemm_big.hip gemm_pp.hip gemm_st.hip gemm_sw.hip norm_softmax.hip embed_misc.hip infonce.hip ipot.hip itm.hip attention.hip encoder.cpp api.cpp; do
   [ -f "$f" ] || continue
   o=obj/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o")" ] || [ ../../include/rmcl.h -nt "$o" ]; then

@@ -315,6 +315,9 @@ static int launch_fast(const GemmArgs& g, int dt_out, hipStream_t s) {
 }
 
 int rmcl_launch_gemm_pp(const GemmArgs& g, int dt_out, hipStream_t s);
+int rmcl_launch_gemm_sw(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s);
+bool rmcl_gemm_sw_supported(const GemmArgs& g, int a_kc, int b_kc);
+double rmcl_gemm_sw_fill(const GemmArgs& g, int cus);
 int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s);
 double rmcl_gemm_st_fill(const GemmArgs& g);
 bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc);
@@ -324,6 +327,9 @@ int rmcl_launch_gemm_big(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipS
 
 int rmcl_launch_gemm_fast(const GemmArgs& g0, int dt_out, int a_kc, int b_kc, hipStream_t s) {
   GemmArgs g = g0;
+  // 192x384 tiles where they make exact rounds (N = 3072 at M = 64*185: 496 tiles = 2 x 248)
+  if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc))
+    return rmcl_launch_gemm_sw(g, dt_out, b_kc, s);
   // 192x192 ping-pong tiles for the activation GEMMs (M = B*185 rows) whenever they fill the CU rounds
   if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc))
     return rmcl_launch_gemm_st(g, dt_out, a_kc, b_kc, s);

@@ -1,0 +1,328 @@
+// bf16 MFMA GEMM with 192x384x64 block tiles ("wide" sibling of gemm_st.hip) for the N = 3072 activation GEMMs of the
+// step (fc1 forward, fc2 dX): the A tile is shared by twice as many columns, so the LDS-DMA moves 7.6 instead of 10.2 bytes
+// per KFLOP (the 192x192 loop is bound by that path) and half as many tile prologues / epilogues run per FLOP.
+// M = 64*185 -> 62 x 8 = 496 tiles = exactly 2 rounds of a 248-workgroup grid.
+//
+//   * one 8-wave workgroup per CU, per-wave output 96x96 (36 fragments = 144 accumulator registers); waves 0-3 / 4-7 are
+//     the two ping-pong groups (rows 0..95 / 96..191), wave column wn owns columns {h*192 + wn*48 + 0..47 : h = 0,1}.
+//   * LDS: 2 buffers x {A 192x64, B0 192x64, B1 192x64} bf16 (24 KiB each, images and swizzles of gemm_st.hip) = 144 KiB.
+//   * a k-tile is 4 phases of 18 MFMA (3 row fragments x 3 column fragments x 2 k-steps):
+//        P1: rows-lo x B0   (reads A-lo 6, B0 6)   stages A(t+1)
+//        P2: rows-lo x B1   (reads B1 6)           stages B0(t+1)
+//        P3: rows-hi x B1   (reads A-hi 6)         stages B1(t+1)
+//        P4: rows-hi x B0   (reads B0 6)           -
+//     every unit is staged >= 2 phases after the last read of the buffer it overwrites and waited for (counted vmcnt(3):
+//     only the youngest unit may be in flight) one phase before its first read.
+#include "rmcl_common.h"
+#include "kernels.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+#define SW_UNIT 24576                        // 192 rows x 64 bf16
+#define SW_BUF (3 * SW_UNIT)                 // A, B0, B1
+#define SW_LDS (2 * SW_BUF)                  // 144 KiB
+
+template <int N>
+__device__ __forceinline__ void sw_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void sw_stage(const bf16_t* base, const uint32_t (&off)[3], long koff, char* lds_unit, int wave) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    __builtin_amdgcn_global_load_lds((glb_void*)(base + koff + off[q]), (lds_void*)(lds_unit + (wave * 3 + q) * 1024), 16, 0, 0);
+}
+
+__device__ __forceinline__ int sw_gk(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }
+
+template <bool KC>
+__device__ __forceinline__ bf16x8 sw_ld(const char* unit, int off, int s) {
+  if (KC) {
+    return *reinterpret_cast<const bf16x8*>(unit + off);          // (off already holds the k-step swizzle)
+  } else {
+    union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(unit + off + s * (32 * 384) + h * (4 * 384)));
+    return u.v;
+  }
+}
+
+#define SW_PHASE_BEGIN()                                  \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_setprio(1)
+#define SW_PHASE_END()                                    \
+  __builtin_amdgcn_s_setprio(0);                          \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  __builtin_amdgcn_sched_barrier(0)
+
+enum { SW_AUX_NONE = 0, SW_AUX_RES = 1, SW_AUX_DGELU = 2 };
+
+struct SWCtx {
+  const bf16_t* A;
+  const bf16_t* B;
+  uint32_t oa[3], ob0[3], ob1[3];
+  int aoff[2], boff[2], boffj[3];
+  long kstep_b;
+  int wave;
+};
+
+// one k-tile; LAST: no staging (the last k-tile of the output tile)
+template <bool B_KC, bool LAST>
+__device__ __forceinline__ void sw_ktile(f32x4 (&acc)[6][6], const SWCtx& c, const char* cur, char* oth, int t1) {
+  bf16x8 a[3][2], b[3][2];
+  // ---- P1: rows-lo x B0
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b[j][s] = B_KC ? sw_ld<true>(cur + SW_UNIT, j * 2048 + c.boff[s], s) : sw_ld<false>(cur + SW_UNIT, c.boffj[j], s);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a[i][s] = sw_ld<true>(cur, i * 2048 + c.aoff[s], s);
+  if (!LAST) { sw_stage(c.A, c.oa, (long)t1 * 64, oth, c.wave); sw_wait_vm<3>(); } else { sw_wait_vm<0>(); }
+  SW_PHASE_BEGIN();
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][s], a[i][s], acc[i][j], 0, 0, 0);
+  SW_PHASE_END();
+  // ---- P2: rows-lo x B1
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b[j][s] = B_KC ? sw_ld<true>(cur + 2 * SW_UNIT, j * 2048 + c.boff[s], s) : sw_ld<false>(cur + 2 * SW_UNIT, c.boffj[j], s);
+  if (!LAST) sw_stage(c.B, c.ob0, (long)t1 * c.kstep_b, oth + SW_UNIT, c.wave);
+  SW_PHASE_BEGIN();
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][3 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][s], a[i][s], acc[i][3 + j], 0, 0, 0);
+  SW_PHASE_END();
+  // ---- P3: rows-hi x B1
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a[i][s] = sw_ld<true>(cur, (3 + i) * 2048 + c.aoff[s], s);
+  if (!LAST) sw_stage(c.B, c.ob1, (long)t1 * c.kstep_b, oth + 2 * SW_UNIT, c.wave);
+  SW_PHASE_BEGIN();
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[3 + i][3 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][s], a[i][s], acc[3 + i][3 + j], 0, 0, 0);
+  SW_PHASE_END();
+  // ---- P4: rows-hi x B0
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b[j][s] = B_KC ? sw_ld<true>(cur + SW_UNIT, j * 2048 + c.boff[s], s) : sw_ld<false>(cur + SW_UNIT, c.boffj[j], s);
+  if (!LAST) sw_wait_vm<3>();                                 // A(t+1), B0(t+1) have landed; B1(t+1) may be in flight
+  SW_PHASE_BEGIN();
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[3 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][s], a[i][s], acc[3 + i][j], 0, 0, 0);
+  SW_PHASE_END();
+}
+
+template <typename TO>
+__device__ __forceinline__ void sw_store4(TO* p, const float (&v)[4]) {
+  if constexpr (sizeof(TO) == 2) {
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = pk;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <bool B_KC, int AUX, typename TO>
+__global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // bands of 4 column tiles, row tiles inside a band, the band's column tiles innermost (as gemm_st.hip)
+  int tr, tc;
+  if (tiles_n % 4 == 0) {
+    const int band = bid / (tiles_m * 4), rem = bid - band * (tiles_m * 4);
+    tr = rem >> 2;
+    tc = band * 4 + (rem & 3);
+  } else {
+    tr = bid / tiles_n;
+    tc = bid - tr * tiles_n;
+  }
+  const int m0 = tr * rows_per_tile, n0 = tc * 384;
+  const int m_end = min(g.M, m0 + rows_per_tile);
+  const int nk = g.K / 64;
+
+  SWCtx c;
+  c.A = reinterpret_cast<const bf16_t*>(g.A);
+  c.B = reinterpret_cast<const bf16_t*>(g.B);
+  c.wave = wave;
+  c.kstep_b = B_KC ? 64 : 64 * g.ldb;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int row = (wave * 3 + q) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    const int lin = (wave * 3 + q) * 64 + lane;              // 16-byte chunk index in the [64][24] image of a [K][cols] operand
+    const int k = lin / 24, c16 = (lin - k * 24) ^ (sw_gk(k) << 1);
+    c.oa[q] = (uint32_t)min(m0 + row, g.M - 1) * (uint32_t)g.lda + chunk * 8;
+    if (B_KC) {
+      c.ob0[q] = (uint32_t)(n0 + row) * (uint32_t)g.ldb + chunk * 8;
+      c.ob1[q] = (uint32_t)(n0 + 192 + row) * (uint32_t)g.ldb + chunk * 8;
+    } else {
+      c.ob0[q] = (uint32_t)k * (uint32_t)g.ldb + n0 + c16 * 8;
+      c.ob1[q] = c.ob0[q] + 192;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int sw = ((4 * s + (lane >> 4)) ^ (lane & 7)) * 16;
+    c.aoff[s] = (wm * 96 + (lane & 15)) * 128 + sw;
+    c.boff[s] = (wn * 48 + (lane & 15)) * 128 + sw;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int k = 8 * (lane >> 4) + q;
+    const int c8 = (wn * 48 + j * 16) / 4 + p;
+    c.boffj[j] = k * 384 + (((c8 >> 1) ^ (sw_gk(k) << 1)) * 16) + (c8 & 1) * 8;
+  }
+
+  f32x4 acc[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  char* buf0 = smem;
+  char* buf1 = smem + SW_BUF;
+  sw_stage(c.A, c.oa, 0, buf0, wave);
+  sw_stage(c.B, c.ob0, 0, buf0 + SW_UNIT, wave);
+  sw_stage(c.B, c.ob1, 0, buf0 + 2 * SW_UNIT, wave);
+  sw_wait_vm<0>();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wm == 1) __builtin_amdgcn_s_barrier();                 // skew: group 1 runs one barrier behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  int it = 0;
+  for (; it + 1 < nk; ++it) {
+    char* cur = (it & 1) ? buf1 : buf0;
+    char* oth = (it & 1) ? buf0 : buf1;
+    sw_ktile<B_KC, false>(acc, c, cur, oth, it + 1);
+  }
+  sw_ktile<B_KC, true>(acc, c, (it & 1) ? buf1 : buf0, nullptr, 0);
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+
+  // epilogue (order as gemm_st.hip: alpha, bias, gelu'(aux), stash, gelu, residual), one 96x48 half at a time
+  const int epi = g.epi;
+  TO* C = reinterpret_cast<TO*>(g.C);
+  TO* C2 = reinterpret_cast<TO*>(g.C2);
+  const int mb = m0 + wm * 96 + (lane & 15);
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+    const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
+    float4 bias[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 res[AUX == SW_AUX_RES ? 6 : 1][3];
+    uint2 pre[AUX == SW_AUX_DGELU ? 6 : 1][3];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const long mr = min(mb + i * 16, g.M - 1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (AUX == SW_AUX_RES) res[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+        if (AUX == SW_AUX_DGELU) pre[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int m = mb + i * 16;
+      const bool live = m < m_end;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const f32x4 av = acc[i][hb * 3 + j];
+        float v[4] = {g.alpha * av[0] + bias[j].x, g.alpha * av[1] + bias[j].y, g.alpha * av[2] + bias[j].z, g.alpha * av[3] + bias[j].w};
+        if (AUX == SW_AUX_DGELU) {
+          const uint2 u = pre[i][j];
+          v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
+          v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
+        }
+        const long ci = (long)m * g.ldc + nb + j * 16;
+        if ((epi & EPI_SAVE_PREACT) && live) sw_store4<TO>(C2 + ci, v);
+        if (epi & EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+        }
+        if (AUX == SW_AUX_RES) { v[0] += res[i][j].x; v[1] += res[i][j].y; v[2] += res[i][j].z; v[3] += res[i][j].w; }
+        if (live) sw_store4<TO>(C + ci, v);
+      }
+    }
+  }
+}
+
+bool rmcl_gemm_sw_supported(const GemmArgs& g, int a_kc, int b_kc) {
+  if (!a_kc || g.nb1 > 1 || g.nb2 > 1 || g.splitk > 1) return false;
+  if (g.N % 384 != 0 || g.K % 64 != 0 || g.K < 128) return false;
+  if ((long)g.M * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
+  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU)) return false;   // (residual epilogue: 72 more live registers spill; N = 768 anyway)
+  return true;
+}
+
+// fraction of the `cus`-workgroup rounds that carry a tile
+double rmcl_gemm_sw_fill(const GemmArgs& g, int cus) {
+  const long tiles = (long)cdiv(g.M, 192) * (g.N / 384);
+  return (double)tiles / (double)(cdiv(tiles, (long)cus) * cus);
+}
+
+template <bool B_KC, int AUX, typename TO>
+static int launch_sw3(const GemmArgs& g, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sw_kernel<B_KC, AUX, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
+    attr = true;
+  }
+  const int tm = cdiv(g.M, 192), tn = g.N / 384, rows = cdiv(g.M, tm);
+  RMCL_LAUNCH((gemm_sw_kernel<B_KC, AUX, TO>), dim3(tm * tn), dim3(512), SW_LDS, s, g, tm, tn, rows);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+template <bool B_KC, int AUX>
+static int launch_sw2(const GemmArgs& g, int dt_out, hipStream_t s) {
+  return dt_out == RMCL_F32 ? launch_sw3<B_KC, AUX, float>(g, s) : launch_sw3<B_KC, AUX, bf16_t>(g, s);
+}
+
+template <bool B_KC>
+static int launch_sw(const GemmArgs& g, int dt_out, hipStream_t s) {
+  if (g.epi & EPI_DGELU) return launch_sw2<B_KC, SW_AUX_DGELU>(g, dt_out, s);
+  return launch_sw2<B_KC, SW_AUX_NONE>(g, dt_out, s);
+}
+
+int rmcl_launch_gemm_sw(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s) {
+  return b_kc ? launch_sw<true>(g, dt_out, s) : launch_sw<false>(g, dt_out, s);
+}

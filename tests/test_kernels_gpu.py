@@ -222,8 +222,8 @@ def test_im2patch_roundtrip():
 
 
 # ------------------------------------------------------------------ bf16 MFMA GEMM (fast path)
-@pytest.mark.parametrize("cfg", [-1, 1, 30, 50, 60])
-@pytest.mark.parametrize("shape", [(11840, 768, 768), (300, 128, 64), (1000, 3072, 768), (256, 768, 3072), (555, 192, 128), (9216, 2304, 192)])
+@pytest.mark.parametrize("cfg", [-1, 1, 30, 50, 60, 70])
+@pytest.mark.parametrize("shape", [(11840, 768, 768), (300, 128, 64), (1000, 3072, 768), (256, 768, 3072), (555, 192, 128), (9216, 2304, 192), (400, 768, 256), (11840, 3072, 768)])
 def test_gemm_fast_bf16_layouts(shape, cfg):
     """exact=0 routes to the glds/tr-read MFMA kernel; reference = fp64 matmul of the same bf16 inputs,
     tolerance = fp32 accumulation-order noise only (products of bf16 are exact in fp32)."""
@@ -285,6 +285,29 @@ def test_gemm_sample_tile_epilogues_match_exact_kernel(b_kc):
         lib.rmcl_tune_set(0, 60)
         out = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, L.F32, exact=0, epi=64, C_init=base)           # accumulate
         assert rel_err(out, X.double() @ W.double().t() + base.double()) < 2e-5
+    finally:
+        lib.rmcl_tune_set(0, -1)
+
+
+@pytest.mark.parametrize("b_kc", [1, 0])
+def test_gemm_wide_tile_epilogues_match_exact_kernel(b_kc):
+    """The 192x384 kernel (tune cfg 70) against the exact-f32 kernel: bias, bias+GELU+stash, GELU' epilogues."""
+    M, N, K = 377, 768, 320
+    X, W, b = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2, scale=0.1).to(torch.bfloat16), rnd(N, seed=3)
+    Wm = W if b_kc else W.t().contiguous()
+    U = rnd(M, N, seed=6).to(torch.bfloat16)
+    cases = [(0, dict()), (1, dict(bias=b)), (1 | 2 | 4, dict(bias=b, want_c2=True)), (16, dict(aux=U, ld_aux=N))]
+    try:
+        for epi, kw in cases:
+            for dto in (L.F32, L.BF16):
+                lib.rmcl_tune_set(0, -1)
+                a = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, dto, epi=epi, exact=1, **kw)
+                lib.rmcl_tune_set(0, 70)
+                f = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, dto, epi=epi, exact=0, **kw)
+                a, f = (a, f) if isinstance(a, tuple) else ((a,), (f,))
+                tol = 2e-4 if epi & (2 | 16) else 2e-5
+                for x, y in zip(a, f):
+                    assert rel_err(y, x) < (tol if dto == L.F32 else 1e-2), (epi, dto)
     finally:
         lib.rmcl_tune_set(0, -1)
 
