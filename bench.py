@@ -18,7 +18,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/un
                  (per-launch event brackets inside the step add ~20 us of marker/dispatch latency each, so
                  they over-state the duration rocprofv3 reports); algorithmic FLOPs / average duration vs
                  the dense bf16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PFLOP/s);
-  step_mfma_frac - whole-step algorithmic FLOPs ((5+2K)F per pair, SURVEY 8d) / step time / peak;
+  step_mfma_frac - whole-step algorithmic FLOPs ((4+2K)F per pair with dropout off - the clean query forward IS PGD step
+                 0's forward and runs once - else SURVEY 8d's (5+2K)F) / step time / peak;
   cpu_baseline - the CPU oracle (port of the reference algorithm, oracle/rmcl_oracle.py) timed on this
                  host's cores on a bounded sample of the same workload (rank 0, N=1 only).
 """

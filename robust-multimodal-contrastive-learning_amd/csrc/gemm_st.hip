@@ -2,8 +2,11 @@
 //
 // Why this tile: the activations of one RMCL step have M = B * 185 rows (185 tokens per sample) and N = 768,
 // 2304 or 3072 = 4, 12, 16 x 192 columns.  With `rows_per_tile` = 185 (each row tile = one sample, 7 of the 192
-// tile rows idle) B = 64 gives 64 x {4, 12, 16} = 256, 768, 1024 tiles = exactly 1, 3, 4 rounds over the 256 CUs,
-// where 128x128 / 256x256 tiles leave 13-45 % of the chip idle in the last round.
+// tile rows idle; the launcher uses the fewest row tiles, 62 of 191 rows) B = 64 gives 62 x {4, 12, 16} = 248 x {1, 3, 4}
+// tiles = exact rounds of a 248-workgroup grid, where 128x128 / 256x256 tiles leave 13-45 % of the chip idle in the
+// last round.  Forms: A [M,K] x B [N,K] (forward), A [M,K] x B [K,N] (dX; B through ds_read_b64_tr_b16),
+// A [K,M] x B [K,N] over split-K work items (weight gradients -> fp32 slabs); epilogues incl. dropout as separate
+// instantiations.
 //
 // Schedule ("ping-pong", cf. gemm_pp.hip): waves 0-3 (group 0, wave rows 0..95) and waves 4-7 (group 1, rows
 // 96..191) run half a phase apart - group 1 executes one extra s_barrier first - so that one group's 18-MFMA
@@ -11,7 +14,8 @@
 //     P1: read fragments of k-step 0;                          barrier, 18 MFMA, barrier
 //     P2: read fragments of k-step 1; stage tile t+2 (6 LDS-DMA per wave) into stage (t+2)%3, whose last read was
 //         (t-1,P2) two phases earlier; s_waitcnt vmcnt(6) -> tile t+1 has landed, first read one phase later.
-// Barriers are raw s_barrier, so the DMA of tile t+2 stays in flight across them.
+// Barriers are raw s_barrier, so the DMA of tile t+2 stays in flight across them.  The transposed-read forms use ONE
+// phase per k-tile instead (PH = 1, see st_tile).
 //
 // Persistence: a workgroup walks its output tiles (round r: tile r * grid + xcd-aware slot) as ONE stream of k-tiles -
 // the last two k-tiles of an output tile already stage the first two k-tiles of the next one, so the epilogue

@@ -312,6 +312,15 @@ def test_gemm_wide_tile_epilogues_match_exact_kernel(b_kc):
         lib.rmcl_tune_set(0, -1)
 
 
+def test_grad_ready_wait_rejects_bad_layers():
+    """rmcl_grad_ready_wait: error codes, never a crash (layers beyond the last backward's depth / negative)."""
+    import ctypes as C
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.rmcl_grad_ready_wait(-1, st) != 0
+    assert lib.rmcl_grad_ready_wait(64, st) != 0
+    assert b"grad_ready_wait" in lib.rmcl_last_error()
+
+
 def test_gemm_skinny_heads_shapes():
     """M <= 256 fp32 problems (pooler / MoCo head) run on the skinny 64x16-tile kernel."""
     for M, N, K in ((64, 768, 768), (64, 128, 768), (2, 768, 768), (70, 40, 256)):
