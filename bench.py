@@ -197,7 +197,7 @@ def main():
         step_flops = ((4 if args.drop_rate == 0 else 5) + 2 * K) * F_PER_PAIR * B
         kern_tf = kern_fl / (kern_ms * 1e-3) / 1e12 if kern_n else 0.0
         out = {
-            "metric": "image-text pairs/sec, ViLT-B/32 RMCL step (PGD K=3)", "value": round(value, 2), "unit": "pairs/s",
+            "metric": f"image-text pairs/sec, ViLT-B/32 RMCL step (PGD K={K})", "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"RMCL step, PGD K={K} image attack + MoCo InfoNCE (queue 65536) + full backward + AdamW, "
