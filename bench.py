@@ -139,8 +139,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RMCL_BENCH_FORCE_DIST", "0") == "1"   # (1-rank rehearsal of the N > 1 code path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     import rmcl_pkg  # noqa: F401
@@ -172,7 +174,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -183,7 +185,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms, kern_n, kern_fl = mlp_gemm_replay(L, B * 185, args.dtype, device) if rank == 0 else (0.0, 0, 0.0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -213,7 +215,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(K)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
