@@ -277,6 +277,116 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
   }
 }
 
+// Epilogue through LDS: the MFMA accumulator layout gives each wave-instruction sixteen 32-byte (bf16) / 64-byte (fp32)
+// row segments, which the memory system writes at 3.2 TB/s chip-wide against 5.9 TB/s for whole rows
+// (tools/store_pattern_bench.hip).  Each wave group (the four waves that share 96 tile rows) therefore writes its
+// converted fragments into a [rows][192] image in LDS (16-byte chunk c of row r at chunk c ^ (r & 7): conflict-free for 8
+// rows) and stores it back row by row, 16 bytes per lane.  `scratch`: this GROUP's region (24 KiB) inside the LDS stage of
+// the tile's last k-tile, which nothing reads any more and the next tile's DMA overwrites only two phases later.
+// Barriers: s_barrier is workgroup-wide, the two groups stand at different epilogue steps when it releases (they run one
+// barrier apart), and both execute the same number (2 + 2 * chunks), so the skew survives the epilogue.
+template <int AUX, typename TO, bool DROP>
+__device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const GemmArgs& g, const STTile& T, int wm, int wn, int lane, int wave,
+                                                char* scratch) {
+  constexpr int ESZ = sizeof(TO), RI = ESZ == 2 ? 3 : 2, NCH = 6 / RI, ROWS = RI * 16, ROWB = 192 * ESZ, PIECES = ROWB / 16;
+  const int epi = g.epi;
+  TO* C = reinterpret_cast<TO*>(g.C) + T.zoff;
+  TO* C2 = reinterpret_cast<TO*>(g.C2);
+  asm volatile("" : "+v"(lane));
+  const int nb = T.n0 + wn * 48 + 4 * (lane >> 4);
+  const int mb = T.m0 + wm * 96 + (lane & 15);
+  float4 bias[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __builtin_amdgcn_s_barrier();                              // the other group's last reads of this stage have retired
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    float4 res[AUX == ST_AUX_RES ? RI : 1][3];
+    uint2 pre[AUX == ST_AUX_DGELU ? RI : 1][3];
+#pragma unroll
+    for (int il = 0; il < RI; ++il) {
+      const long mr = min(mb + (ch * RI + il) * 16, g.M - 1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (AUX == ST_AUX_RES) res[il][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+        if (AUX == ST_AUX_DGELU) pre[il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+      }
+    }
+#pragma unroll
+    for (int il = 0; il < RI; ++il) {
+      const int i = ch * RI + il;
+      const int m = mb + i * 16;
+      const bool live = m < T.m_end;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float v[4] = {g.alpha * acc[i][j][0] + bias[j].x, g.alpha * acc[i][j][1] + bias[j].y, g.alpha * acc[i][j][2] + bias[j].z,
+                      g.alpha * acc[i][j][3] + bias[j].w};
+        if (DROP && (epi & EPI_DROP_BWD)) {
+          const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, di + r, g.drop_thresh, g.drop_inv_keep);
+        }
+        if (AUX == ST_AUX_DGELU) {
+          const uint2 u = pre[il][j];
+          v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
+          v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
+        }
+        const long ci = (long)m * g.ldc + nb + j * 16;
+        if ((epi & EPI_SAVE_PREACT) && live) st_store4<TO>(C2 + ci, v);
+        if (epi & EPI_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+        }
+        if (DROP && (epi & EPI_DROPOUT)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, (uint32_t)ci + r, g.drop_thresh, g.drop_inv_keep);
+        }
+        if (AUX == ST_AUX_RES) { v[0] += res[il][j].x; v[1] += res[il][j].y; v[2] += res[il][j].z; v[3] += res[il][j].w; }
+        // image: row il*16 + lane%16, element column wn*48 + j*16 + 4*(lane/16); 16-byte chunk index XOR (row & 7)
+        const int row = il * 16 + (lane & 15);
+        if constexpr (ESZ == 2) {
+          const int e8 = wn * 12 + j * 4 + (lane >> 4);      // 8-byte unit (4 bf16) in the row
+          const int c16 = (e8 >> 1) ^ (row & 7);
+          uint2 pk;
+          pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(scratch + row * ROWB + c16 * 16 + (e8 & 1) * 8) = pk;
+        } else {
+          const int c16 = (wn * 12 + j * 4 + (lane >> 4)) ^ (row & 7);
+          *reinterpret_cast<float4*>(scratch + row * ROWB + c16 * 16) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();                            // the group's image of this chunk is complete
+    int tg = (wave & 3) * 64 + lane;                         // lane id inside the group
+    asm volatile("" : "+v"(tg));                             // (keeps the read-back addresses from being hoisted out of the tile loop as live registers)
+#pragma unroll
+    for (int q0 = 0; q0 < ROWS * PIECES; q0 += 256) {
+      const int q = q0 + tg;
+      if (q < ROWS * PIECES) {
+        const int row = q / PIECES, cp = q - row * PIECES;   // physical chunk cp holds logical chunk cp ^ (row & 7)
+        const int m = T.m0 + wm * 96 + ch * ROWS + row;
+        if (m < T.m_end) {
+          const float4 w = *reinterpret_cast<const float4*>(scratch + row * ROWB + cp * 16);
+          TO* dst = C + (long)m * g.ldc + T.n0 + (cp ^ (row & 7)) * (16 / ESZ);
+          if constexpr (ESZ == 4) {
+            float4 o = w;
+            if (epi & EPI_ACCUM) {
+              const float4 old = *reinterpret_cast<const float4*>(dst);
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *reinterpret_cast<float4*>(dst) = o;
+          } else {
+            *reinterpret_cast<float4*>(dst) = w;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();                            // image consumed: the next chunk may overwrite it
+  }
+  __builtin_amdgcn_s_barrier();                              // the OTHER group (one barrier behind) has consumed its last image too:
+}                                                            // the next tile's LDS-DMA may now target this stage
+
 template <bool A_KC, bool B_KC, int AUX, typename TO, bool DROP, int PH>
 __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile, int xflags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -359,7 +469,9 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
       sc = sc == 2 ? 0 : sc + 1;
       st_tile<2, A_KC, B_KC, PH>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
     }
-    st_epilogue<AUX, TO, DROP>(acc, g, cur, wm, wn, lane);
+    // the stage the tile's last k-tile was read from (sc has already moved on when the stream continues): 24 KiB per group
+    const int s_free = nid >= 0 ? (sc == 0 ? 2 : sc - 1) : sc;
+    st_epilogue_lds<AUX, TO, DROP>(acc, g, cur, wm, wn, lane, wave, smem + s_free * ST_STAGE + wm * (ST_STAGE / 2));
     if (nid < 0) break;
     cur = nxt;
   }

@@ -237,49 +237,119 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
   sw_ktile<B_KC, true>(acc, c, (it & 1) ? buf1 : buf0, nullptr, 0);
   if (wm == 0) __builtin_amdgcn_s_barrier();
 
-  // epilogue (order as gemm_st.hip: alpha, bias, gelu'(aux), stash, gelu, residual), one 96x48 half at a time
+  // epilogue (order as gemm_st.hip: alpha, bias, gelu'(aux), stash, gelu, residual)
   const int epi = g.epi;
   TO* C = reinterpret_cast<TO*>(g.C);
   TO* C2 = reinterpret_cast<TO*>(g.C2);
   const int mb = m0 + wm * 96 + (lane & 15);
+  if constexpr (sizeof(TO) == 2) {
+    // bf16 outputs go through LDS (all 144 KiB are free now) and leave as whole 768-byte rows, 16 bytes per lane: the
+    // fragment layout's 32-byte row segments are written at about half that rate (tools/store_pattern_bench.hip).  Per wave
+    // group: 48 rows x 768 B images of the output and, when stashed, of the pre-activation; 16-byte chunk c of row r at
+    // c ^ (r & 7).  (Both groups are barrier-aligned here; every wave executes the same 4 barriers.)
+    constexpr int ROWB = 768, PIECES = 48, ROWS = 48, IMG = ROWS * ROWB;   // 36 KiB per image
+    char* img = smem + wm * (2 * IMG);
+    const bool stash = (epi & EPI_SAVE_PREACT) != 0;
 #pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {
-    const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
-    float4 bias[3];
+    for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 res[AUX == SW_AUX_RES ? 6 : 1][3];
-    uint2 pre[AUX == SW_AUX_DGELU ? 6 : 1][3];
+      for (int hb = 0; hb < 2; ++hb) {
+        const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
+        float4 bias[3];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const long mr = min(mb + i * 16, g.M - 1);
+        for (int j = 0; j < 3; ++j) bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 pre[AUX == SW_AUX_DGELU ? 3 : 1][3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (AUX == SW_AUX_RES) res[i][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + mr * g.ld_aux + nb + j * 16);
-        if (AUX == SW_AUX_DGELU) pre[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+        for (int il = 0; il < 3; ++il) {
+          const long mr = min(mb + (ch * 3 + il) * 16, g.M - 1);
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            if (AUX == SW_AUX_DGELU) pre[il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+        }
+#pragma unroll
+        for (int il = 0; il < 3; ++il) {
+          const int i = ch * 3 + il;
+          const int row = il * 16 + (lane & 15);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const f32x4 av = acc[i][hb * 3 + j];
+            float v[4] = {g.alpha * av[0] + bias[j].x, g.alpha * av[1] + bias[j].y, g.alpha * av[2] + bias[j].z, g.alpha * av[3] + bias[j].w};
+            if (AUX == SW_AUX_DGELU) {
+              const uint2 u = pre[il][j];
+              v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
+              v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
+            }
+            const int e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);        // 8-byte unit (4 bf16) in the 384-column row
+            const int off = row * ROWB + (((e8 >> 1) ^ (row & 7)) * 16) + (e8 & 1) * 8;
+            if (stash) {
+              uint2 pk;
+              pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+              pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+              *reinterpret_cast<uint2*>(img + IMG + off) = pk;
+            }
+            if (epi & EPI_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+            }
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(img + off) = pk;
+          }
+        }
       }
+      __builtin_amdgcn_s_barrier();                          // the group's images of this chunk are complete
+      int tg = (wave & 3) * 64 + lane;
+      asm volatile("" : "+v"(tg));
+#pragma unroll
+      for (int q0 = 0; q0 < ROWS * PIECES; q0 += 256) {
+        const int q = q0 + tg;
+        const int row = q / PIECES, cp = q - row * PIECES;
+        const int m = m0 + wm * 96 + ch * ROWS + row;
+        if (m < m_end) {
+          const long dst = (long)m * g.ldc + n0 + (cp ^ (row & 7)) * 8;
+          *reinterpret_cast<float4*>(C + dst) = *reinterpret_cast<const float4*>(img + row * ROWB + cp * 16);
+          if (stash) *reinterpret_cast<float4*>(C2 + dst) = *reinterpret_cast<const float4*>(img + IMG + row * ROWB + cp * 16);
+        }
+      }
+      __builtin_amdgcn_s_barrier();                          // images consumed
     }
+  } else {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int m = mb + i * 16;
-      const bool live = m < m_end;
+    for (int hb = 0; hb < 2; ++hb) {
+      const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
+      float4 bias[3];
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const f32x4 av = acc[i][hb * 3 + j];
-        float v[4] = {g.alpha * av[0] + bias[j].x, g.alpha * av[1] + bias[j].y, g.alpha * av[2] + bias[j].z, g.alpha * av[3] + bias[j].w};
-        if (AUX == SW_AUX_DGELU) {
-          const uint2 u = pre[i][j];
-          v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
-          v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
+      for (int j = 0; j < 3; ++j) bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      uint2 pre[AUX == SW_AUX_DGELU ? 6 : 1][3];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const long mr = min(mb + i * 16, g.M - 1);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (AUX == SW_AUX_DGELU) pre[i][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int m = mb + i * 16;
+        const bool live = m < m_end;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const f32x4 av = acc[i][hb * 3 + j];
+          float v[4] = {g.alpha * av[0] + bias[j].x, g.alpha * av[1] + bias[j].y, g.alpha * av[2] + bias[j].z, g.alpha * av[3] + bias[j].w};
+          if (AUX == SW_AUX_DGELU) {
+            const uint2 u = pre[i][j];
+            v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
+            v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
+          }
+          const long ci = (long)m * g.ldc + nb + j * 16;
+          if ((epi & EPI_SAVE_PREACT) && live) sw_store4<TO>(C2 + ci, v);
+          if (epi & EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+          }
+          if (live) sw_store4<TO>(C + ci, v);
         }
-        const long ci = (long)m * g.ldc + nb + j * 16;
-        if ((epi & EPI_SAVE_PREACT) && live) sw_store4<TO>(C2 + ci, v);
-        if (epi & EPI_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
-        }
-        if (AUX == SW_AUX_RES) { v[0] += res[i][j].x; v[1] += res[i][j].y; v[2] += res[i][j].z; v[3] += res[i][j].w; }
-        if (live) sw_store4<TO>(C + ci, v);
       }
     }
   }
