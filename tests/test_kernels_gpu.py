@@ -312,6 +312,63 @@ def test_gemm_wide_tile_epilogues_match_exact_kernel(b_kc):
         lib.rmcl_tune_set(0, -1)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_gemm_pingpong_kernels_random_shapes(seed):
+    """192x192 (cfg 60) and 192x384 (cfg 70) kernels on random shapes: ragged last row tiles (any M >= 1), the shortest
+    k-loops (K = 128: two k-tiles), multi-round persistence (more tiles than CUs), both B layouts, and the [K][M] x [K][N]
+    form; reference = fp64 matmul of the same bf16 operands."""
+    import random
+    rng = random.Random(1000 + seed)
+    M = rng.choice([1, 7, 185, 191, 192, 193, 370, 555, 1000, 2368, rng.randint(1, 3000)])
+    N = 192 * rng.choice([1, 2, 4, 6, 8, 12])
+    K = 64 * rng.choice([2, 3, 4, 5, 12, 13, 24])
+    if seed % 4 == 3:
+        M = 192 * rng.choice([40, 62, 70])                       # more than one tile per CU: the persistent k-tile stream
+        N = 192 * rng.choice([8, 12])
+        K = 64 * rng.choice([2, 3, 4])
+    X = rnd(M, K, seed=seed).to(torch.bfloat16)
+    W = rnd(N, K, seed=seed + 50, scale=0.05).to(torch.bfloat16)
+    b = rnd(N, seed=seed + 99)
+    ref = X.double() @ W.double().t() + b.double()
+    Wn = W.t().contiguous()
+    try:
+        for cfg in (60, 70):
+            lib.rmcl_tune_set(0, cfg)
+            out = gemm(X, W, M, N, K, 1, 1, L.BF16, L.F32, bias=b, epi=1, exact=0)
+            assert rel_err(out, ref) < 2e-5, ("NT", cfg, M, N, K)
+            out = gemm(X, Wn, M, N, K, 1, 0, L.BF16, L.BF16, bias=b, epi=1, exact=0)
+            assert rel_err(out, ref) < 1e-2, ("NN", cfg, M, N, K)
+        if M % 192 == 0:                                             # [K][M] x [K][N] (weight-gradient form), accumulate
+            lib.rmcl_tune_set(0, 60)
+            Xt = X.t().contiguous()
+            base = rnd(M, N, seed=seed + 7)
+            out = gemm(Xt, Wn, M, N, K, 0, 0, L.BF16, L.F32, exact=0, epi=64, C_init=base)
+            assert rel_err(out, X.double() @ W.double().t() + base.double()) < 2e-5, ("TN", M, N, K)
+    finally:
+        lib.rmcl_tune_set(0, -1)
+
+
+@pytest.mark.parametrize("cfg,N", [(60, 2304), (70, 3072)])
+def test_gemm_pingpong_kernels_are_run_to_run_deterministic(cfg, N):
+    """The LDS-DMA / ds_read ordering of the ping-pong kernels rests on counted vmcnt + barriers: a mis-placed wait shows up
+    as rare torn tiles, so the same multi-round launch is repeated and every result must be bitwise identical."""
+    M, K = 11840, 768
+    X = rnd(M, K, seed=3).to(torch.bfloat16)
+    W = rnd(N, K, seed=4, scale=0.05).to(torch.bfloat16)
+    Wn = W.t().contiguous()
+    try:
+        lib.rmcl_tune_set(0, cfg)
+        for b_kc, Wm in ((1, W), (0, Wn)):
+            first = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, L.BF16, exact=0)
+            for _ in range(15):
+                again = gemm(X, Wm, M, N, K, 1, b_kc, L.BF16, L.BF16, exact=0)
+                assert torch.equal(first, again)
+        ref = X.double() @ W.double().t()
+        assert rel_err(first, ref) < 1e-2
+    finally:
+        lib.rmcl_tune_set(0, -1)
+
+
 def test_grad_ready_wait_rejects_bad_layers():
     """rmcl_grad_ready_wait: error codes, never a crash (layers beyond the last backward's depth / negative)."""
     import ctypes as C
