@@ -145,20 +145,24 @@ __global__ __launch_bounds__(256) void infonce_partial_kernel(const float* __res
   }
 }
 
-// One workgroup (128 threads = PD) per query row: merge slice partials, add the positive pair.
+// One workgroup per query row: merge slice partials, add the positive pair.  512 threads = 4 groups of PD: group 0 does the
+// scalar bookkeeping, all four split the slices of the Z / dq merge (the serial 512-slice loop was latency-bound).
 // rows_out[i, 0..9] = loss_i, pred_i (argmax of the logits incl. the positive at index 0),
 //   l_pos, pos_dist, pos_cos, pos_dot, neg_dist_mean, neg_cos_mean, neg_dot_mean, logsumexp
-__global__ __launch_bounds__(PD) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
+#define CMB_G 4
+__global__ __launch_bounds__(CMB_G * PD) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ part, const float* __restrict__ dq_part,
                                                              int nslice, int B, int Bpad, long Kq, float invT, float gscale,
                                                              float* __restrict__ dq, float* __restrict__ rows_out,
                                                              float* __restrict__ loss_sum) {
   __shared__ float red[4][2];
   __shared__ float sh[8];
-  const int i = blockIdx.x, c = threadIdx.x, lane = c & 63, wave = c >> 6;
+  __shared__ float accs[CMB_G][PD];
+  __shared__ float zs[CMB_G];
+  const int i = blockIdx.x, c = threadIdx.x & (PD - 1), grp = threadIdx.x / PD, lane = c & 63, wave = c >> 6;
   const float qc = q[(long)i * PD + c], kc = k[(long)i * PD + c];
   float s_qk = wave_sum(qc * kc), s_qq = wave_sum(qc * qc), s_kk = wave_sum(kc * kc), s_d = wave_sum((qc - kc) * (qc - kc));
-  if (lane == 0) { red[0][wave] = s_qk; red[1][wave] = s_qq; red[2][wave] = s_kk; red[3][wave] = s_d; }
+  if (grp == 0 && lane == 0) { red[0][wave] = s_qk; red[1][wave] = s_qq; red[2][wave] = s_kk; red[3][wave] = s_d; }
   __syncthreads();
   const float dotp = red[0][0] + red[0][1], qq = red[1][0] + red[1][1], kk = red[2][0] + red[2][1], dd = red[3][0] + red[3][1];
   const float lpos = dotp * invT;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(PD) void infonce_combine_kernel(const float* __rest
   float M = lpos, best = -INFINITY;
   int bidx = 0;
   float sd = 0.f, sc = 0.f, so = 0.f;
-  for (int s = c; s < nslice; s += PD) {
+  for (int s = grp == 0 ? c : nslice; s < nslice; s += PD) {
     const float* o = part + ((long)s * Bpad + i) * NPART;
     M = fmaxf(M, o[0]);
     const int oi = __float_as_int(o[3]);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(PD) void infonce_combine_kernel(const float* __rest
     if (ob > wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
   }
   __shared__ float r2[2][8];
-  if (lane == 0) { r2[wave][0] = M; r2[wave][1] = sd; r2[wave][2] = sc; r2[wave][3] = so; r2[wave][4] = wb; r2[wave][5] = __int_as_float(wi); }
+  if (grp == 0 && lane == 0) { r2[wave][0] = M; r2[wave][1] = sd; r2[wave][2] = sc; r2[wave][3] = so; r2[wave][4] = wb; r2[wave][5] = __int_as_float(wi); }
   __syncthreads();
   M = fmaxf(r2[0][0], r2[1][0]);
   sd = r2[0][1] + r2[1][1]; sc = r2[0][2] + r2[1][2]; so = r2[0][3] + r2[1][3];
@@ -195,13 +199,19 @@ __global__ __launch_bounds__(PD) void infonce_combine_kernel(const float* __rest
   }
   // pass 2: Z and dq (each thread owns column c of dq)
   float Z = 0.f, acc = 0.f;
-#pragma unroll 16                                           // independent loads: keep 16 slices in flight (was latency-bound: 512 serial round trips)
-  for (int s = 0; s < nslice; ++s) {
+#pragma unroll 8
+  for (int s = grp; s < nslice; s += CMB_G) {
     const float* o = part + ((long)s * Bpad + i) * NPART;
     const float f = __expf(o[0] - M);
     Z += o[1] * f;
     acc += f * dq_part[((long)s * Bpad + i) * PD + c];
   }
+  accs[grp][c] = acc;
+  if (c == 0) zs[grp] = Z;
+  __syncthreads();
+  if (grp != 0) return;
+  Z = (zs[0] + zs[1]) + (zs[2] + zs[3]);
+  acc = (accs[0][c] + accs[1][c]) + (accs[2][c] + accs[3][c]);
   const float epos = __expf(lpos - M);
   Z += epos;
   const float lse = logf(Z) + M;
@@ -243,7 +253,7 @@ int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int 
   }
   RMCL_LAUNCH(infonce_partial_kernel, dim3(ns, Bpad / RT), dim3(256), lds, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
   RMCL_CHECK_LAUNCH();
-  RMCL_LAUNCH(infonce_combine_kernel, dim3(B), dim3(PD), 0, s, q, k, part, dq_part, ns, B, Bpad, Kq, 1.0f / T, gscale, dq,
+  RMCL_LAUNCH(infonce_combine_kernel, dim3(B), dim3(CMB_G * PD), 0, s, q, k, part, dq_part, ns, B, Bpad, Kq, 1.0f / T, gscale, dq,
                      rows_out, loss_sum);
   RMCL_CHECK_LAUNCH();
   return 0;
