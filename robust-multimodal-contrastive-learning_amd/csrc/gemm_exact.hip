@@ -246,8 +246,33 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
   // and 8 k-steps of loads in flight; the chains are summed in k order at the end.  NOTE: this changes the summation
   // order relative to a single chain only in the last bits (heads: fp32, tolerance 1e-5).
   f32x4 ac[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 8
-  for (int k0 = 0; k0 < g.K; k0 += 16) {
+  // 64 k per iteration with every load of the iteration issued before the first MFMA (the compiler otherwise waits
+  // vmcnt(0) after each scalar B load: four serial L2 round trips per 16 k); 16-k tail for K % 64
+  int k0 = 0;
+  for (; k0 + 64 <= g.K; k0 += 64) {
+    float4 av[4];
+    float bv[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[u] = *reinterpret_cast<const float4*>(A + k0 + 16 * u);
+      if (B_KC) {
+        const float4 t = *reinterpret_cast<const float4*>(B + k0 + 16 * u);
+        bv[u][0] = t.x; bv[u][1] = t.y; bv[u][2] = t.z; bv[u][3] = t.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[u][j] = B[(long)(k0 + 16 * u + j) * g.ldb];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // all 20 loads are in flight before the first MFMA waits
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ac[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].x, bv[u][0], ac[0], 0, 0, 0);
+      ac[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].y, bv[u][1], ac[1], 0, 0, 0);
+      ac[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].z, bv[u][2], ac[2], 0, 0, 0);
+      ac[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].w, bv[u][3], ac[3], 0, 0, 0);
+    }
+  }
+  for (; k0 < g.K; k0 += 16) {
     const float4 a = *reinterpret_cast<const float4*>(A + k0);
     float b[4];
     if (B_KC) {
