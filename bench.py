@@ -143,6 +143,9 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        # RCCL's channel workgroups share the CUs with one-workgroup-per-CU GEMMs that leave 8 CUs free (rmcl_tune_set key 1);
+        # 8 channels move the 447 MB of gradients well inside the ~12 ms backward window they overlap with
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     import rmcl_pkg  # noqa: F401

@@ -73,6 +73,15 @@ def allreduce_mean_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, as
     return works
 
 
+def allreduce_sum_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024):
+    """Blocking bucketed SUM over the flat gradient arena (the 1/world_size is applied to the loss gradient beforehand)."""
+    if world_size() == 1:
+        return
+    n = flat.numel()
+    for s in range(0, n, bucket_elems):
+        dist.all_reduce(flat[s:min(n, s + bucket_elems)], op=dist.ReduceOp.SUM)
+
+
 def grad_buckets(layer0: int, layer_stride: int, layers: int, total: int):
     """Buckets of the flat gradient arena in the order their gradients become final during the backward:
     (gate_layer, start, end).  gate_layer = l: ready once encoder layer l's backward has finished; -1: ready only
@@ -90,17 +99,17 @@ def grad_buckets(layer0: int, layer_stride: int, layers: int, total: int):
 
 
 class GradSync:
-    """Overlapped data-parallel gradient averaging (replaces DDP's bucketed all-reduce hooks, run.py:96): one all-reduce
+    """Overlapped data-parallel gradient reduction (replaces DDP's bucketed all-reduce hooks, run.py:96; SUM - the
+    1/world_size is applied to the loss gradient before the backward, `prescaled=True`): one all-reduce
     per encoder layer (28 MB fp32 - xGMI rings want few, large messages), issued on a communication stream that waits
     on that layer's gradient-ready events (rmcl_grad_ready_wait), so RCCL runs while the layers below are still in
     their backward.  ``wait()`` makes the current stream wait for all of them (call before the optimizer step)."""
 
-    def __init__(self, flat: torch.Tensor, buckets, comm_stream, gate):
+    def __init__(self, flat: torch.Tensor, buckets, comm_stream, gate, prescaled: bool = False):
         self.works = []
         if not (dist.is_available() and dist.is_initialized()):
             return
         ws = world_size()
-        avg = dist.get_backend() == "nccl"
         main = torch.cuda.current_stream() if flat.is_cuda else None
         for layer, s, e in buckets:
             chunk = flat[s:e]
@@ -110,13 +119,12 @@ class GradSync:
                 else:
                     comm_stream.wait_stream(main)
                 with torch.cuda.stream(comm_stream):
-                    if avg:
-                        self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
-                    else:
+                    if not prescaled:
                         chunk.div_(ws)
-                        self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+                    self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
             else:
-                chunk.div_(ws)
+                if not prescaled:
+                    chunk.div_(ws)
                 self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
 
     def wait(self):

@@ -18,14 +18,17 @@ class _DeferredBackward(torch.autograd.Function):
     backward, which accumulates into the gradient arena that every ``param.grad`` is a view of."""
 
     @staticmethod
-    def forward(ctx, anchor, value, closure):
+    def forward(ctx, anchor, value, closure, prescale=1.0):
         ctx.closure = closure
+        ctx.prescale = float(prescale)
         return value.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        ctx.closure(grad_out)
-        return None, None, None
+        # data-parallel mean: the backward is linear in grad_out, so the 1/world_size of DDP's gradient averaging is applied
+        # here (exact for power-of-two world sizes) and the collectives are plain SUMs - no pre-multiplied reduction op
+        ctx.closure(grad_out * ctx.prescale if ctx.prescale != 1.0 else grad_out)
+        return None, None, None, None
 
 
 def _scalar(t):
@@ -87,7 +90,7 @@ def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_origin
         # one attacked view = one backward per step: its gradient all-reduces can start layer by layer right away
         pl_module.after_backward(overlap=(pl_module.image_view != pl_module.text_view) and _only_moco(pl_module))
 
-    return _DeferredBackward.apply(pl_module.grad_anchor, value, backward)
+    return _DeferredBackward.apply(pl_module.grad_anchor, value, backward, pl_module.grad_prescale())
 
 
 def compute_itm_wpa(pl_module, batch):
@@ -171,7 +174,7 @@ def compute_itm_wpa(pl_module, batch):
             eng.encoder_backward(pb, L.MODE_FULL, op, dxn, cls_only=False, dpatches=None)
             pl_module.after_backward()
 
-        value = _DeferredBackward.apply(pl_module.grad_anchor, value, backward)
+        value = _DeferredBackward.apply(pl_module.grad_anchor, value, backward, pl_module.grad_prescale())
     ret = {"itm_loss": value[0], "itm_wpa_loss": value[1], "itm_logits": logits, "itm_labels": itm_labels}
     phase = "train" if pl_module.training else "val"
     pl_module.log(f"itm/{phase}/loss", ret["itm_loss"].detach())

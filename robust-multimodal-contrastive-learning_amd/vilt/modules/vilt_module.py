@@ -145,11 +145,19 @@ class ViLTransformerSS(nn.Module):
                 check(lib.rmcl_grad_ready_wait(int(layer), C.c_void_p(stream.cuda_stream)), "grad_ready_wait")
 
             self.wait_grad_sync()
-            self._grad_sync = dist_utils.GradSync(e.g32, buckets, e.comm_stream, gate)
+            self._grad_sync = dist_utils.GradSync(e.g32, buckets, e.comm_stream, gate, prescaled=True)
         else:
             self.wait_grad_sync()
             if dist_utils.world_size() > 1:
-                dist_utils.allreduce_mean_(e.g32)
+                dist_utils.allreduce_sum_(e.g32)
+
+    def grad_prescale(self) -> float:
+        """1 / world_size when this module averages gradients over ranks (applied to the loss gradient, see
+        objectives._DeferredBackward), else 1."""
+        import torch.distributed as dist
+        if self.sync_grads and dist.is_available() and dist.is_initialized():
+            return 1.0 / dist.get_world_size()
+        return 1.0
 
     def wait_grad_sync(self):
         """Make the current stream wait for the overlapped gradient all-reduces (the optimizer calls this)."""
