@@ -145,11 +145,11 @@ __global__ __launch_bounds__(256) void infonce_partial_kernel(const float* __res
   }
 }
 
-// One workgroup per query row: merge slice partials, add the positive pair.  512 threads = 4 groups of PD: group 0 does the
-// scalar bookkeeping, all four split the slices of the Z / dq merge (the serial 512-slice loop was latency-bound).
+// One workgroup per query row: merge slice partials, add the positive pair.  1024 threads = 8 groups of PD: group 0 does the
+// scalar bookkeeping, all eight split the slices of the Z / dq merge (the serial 512-slice loop was latency-bound).
 // rows_out[i, 0..9] = loss_i, pred_i (argmax of the logits incl. the positive at index 0),
 //   l_pos, pos_dist, pos_cos, pos_dot, neg_dist_mean, neg_cos_mean, neg_dot_mean, logsumexp
-#define CMB_G 4
+#define CMB_G 8
 __global__ __launch_bounds__(CMB_G * PD) void infonce_combine_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ part, const float* __restrict__ dq_part,
                                                              int nslice, int B, int Bpad, long Kq, float invT, float gscale,
@@ -210,8 +210,9 @@ __global__ __launch_bounds__(CMB_G * PD) void infonce_combine_kernel(const float
   if (c == 0) zs[grp] = Z;
   __syncthreads();
   if (grp != 0) return;
-  Z = (zs[0] + zs[1]) + (zs[2] + zs[3]);
-  acc = (accs[0][c] + accs[1][c]) + (accs[2][c] + accs[3][c]);
+  Z = 0.f; acc = 0.f;
+#pragma unroll
+  for (int gi = 0; gi < CMB_G; ++gi) { Z += zs[gi]; acc += accs[gi][c]; }
   const float epos = __expf(lpos - M);
   Z += epos;
   const float lse = logf(Z) + M;
