@@ -26,7 +26,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define LN2 0.6931471805599453f
 #define SCALE_L2 (SCALE * LOG2E)   // scores are kept in the log2 domain: v_exp_f32 is exp2, so exp(s - m) costs one subtract + one v_exp
 #define ATT_QW 8            // waves per workgroup of the forward kernel: 12 query tiles -> 1-2 per wave
-#define ATT_DQW 4           // dQ kernel: its 96 score/dP accumulators + hoisted fragments need > 256 VGPRs, so one wave per SIMD
+#define ATT_DQW 8           // dQ kernel: its 96 score/dP accumulators + hoisted fragments need > 256 VGPRs, so one wave per SIMD
 
 // ---- staging: rows [0,N) of a [*, 64] bf16 slice (row pitch ld elements) -> LDS image of NKP rows x 128 B
 template <bool TR, int NW = 4>
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __r
       S[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 2; ++s) S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row_lds(Kimg, kt * 16, s, lane), qf[s], S[kt], 0, 0, 0);
+      if (kt & 1) __builtin_amdgcn_sched_barrier(0);         // at most two key tiles of fragment reads live: fewer VGPRs, more resident waves
     }
     float m = -INFINITY;
 #pragma unroll
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __r
       const bf16x8 pa = pack8(S[2 * u], S[2 * u + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr32_lds(Vimg, 32 * u, dt, lane), pa, O[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     const float linv = 1.0f / l;
     if (q_lane < N) {
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(ATT_DQW * 64) void attn_bwd_dq_kernel(const bf16_t*
         S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row_lds(Krow, kt * 16, s, lane), qf[s], S[kt], 0, 0, 0);
         dP[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_row_lds(Vrow, kt * 16, s, lane), df[s], dP[kt], 0, 0, 0);
       }
+      if (kt & 1) __builtin_amdgcn_sched_barrier(0);         // keeps the fragment reads of at most two key tiles live (8 waves: 256 VGPRs)
     }
     float dl = 0.f;
 #pragma unroll
