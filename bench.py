@@ -219,6 +219,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(K)
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()                                     # rank 0 is still replaying / printing: leave together
         dist.destroy_process_group()
 
 
