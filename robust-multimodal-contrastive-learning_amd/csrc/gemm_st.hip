@@ -113,15 +113,15 @@ __device__ __forceinline__ void st_tile(f32x4 (&acc)[6][3], const STCtx& c, cons
       for (int j = 0; j < 3; ++j) b[j] = B_KC ? st_ld_b<true>(cur + ST_OP_BYTES, j * 2048 + c.boff[s], s) : st_ld_b<false>(cur + ST_OP_BYTES, c.boffj[j], s);
 #pragma unroll
       for (int i = 0; i < 6; ++i) a[i] = A_KC ? st_ld_b<true>(cur, i * 2048 + c.aoff[s], s) : st_ld_b<false>(cur, c.aoffi[i], s);
-      if (s == 1) {
-        if (MODE == 0) {
-          st_stage_op(c.A, c.oa, (long)t2 * c.kstep_a, nxt2, c.wave);
-          st_stage_op(c.B, c.ob, (long)t2 * c.kstep_b, nxt2 + ST_OP_BYTES, c.wave);
-          st_wait_vm<6>();
-        } else if (MODE == 1) {
-          st_wait_vm<0>();
-        }
+      if (MODE == 0) {
+        // half of tile t+2 per phase (A with k-step 0, B with k-step 1): the A half is issued ONE phase after the stage's last
+        // reads, which is why those reads are retired before the barrier below
+        if (s == 0) st_stage_op(c.A, c.oa, (long)t2 * c.kstep_a, nxt2, c.wave);
+        else { st_stage_op(c.B, c.ob, (long)t2 * c.kstep_b, nxt2 + ST_OP_BYTES, c.wave); st_wait_vm<6>(); }
+      } else if (MODE == 1 && s == 1) {
+        st_wait_vm<0>();
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ST_PHASE_BEGIN();
 #pragma unroll
       for (int i = 0; i < 6; ++i)
