@@ -11,9 +11,10 @@
 // Schedule ("ping-pong", cf. gemm_pp.hip): waves 0-3 (group 0, wave rows 0..95) and waves 4-7 (group 1, rows
 // 96..191) run half a phase apart - group 1 executes one extra s_barrier first - so that one group's 18-MFMA
 // cluster overlaps the other's 9 ds_read_b128 + LDS-DMA issue.  A k-tile is two phases (k-steps of 32):
-//     P1: read fragments of k-step 0;                          barrier, 18 MFMA, barrier
-//     P2: read fragments of k-step 1; stage tile t+2 (6 LDS-DMA per wave) into stage (t+2)%3, whose last read was
-//         (t-1,P2) two phases earlier; s_waitcnt vmcnt(6) -> tile t+1 has landed, first read one phase later.
+//     P1: read fragments of k-step 0; stage the A half of tile t+2 (3 LDS-DMA per wave) into stage (t+2)%3, whose last
+//         reads, (t-1,P2), were retired (lgkmcnt(0)) before that phase's first barrier;  barrier, 18 MFMA, barrier
+//     P2: read fragments of k-step 1; stage the B half of tile t+2; s_waitcnt vmcnt(6) -> tile t+1 has landed, first read
+//         one phase later.
 // Barriers are raw s_barrier, so the DMA of tile t+2 stays in flight across them.  The transposed-read forms use ONE
 // phase per k-tile instead (PH = 1, see st_tile).
 //
