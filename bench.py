@@ -22,11 +22,20 @@ Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/un
                  0's forward and runs once - else SURVEY 8d's (5+2K)F) / step time / peak;
   cpu_baseline - the CPU oracle (port of the reference algorithm, oracle/rmcl_oracle.py) timed on this
                  host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+
+--config rmcl_pgd (default) is BASELINE configs[2] (the metric's configuration; configs[3] at N=8);
+--config itm_clean is BASELINE configs[1] ("clean ITM + contrastive": ITM + word-patch alignment + CE on the clean
+InfoNCE logits, 7F per pair, SURVEY 8d Config 2).
+
+--gpus N > 1 without a torchrun environment: bench.py launches the N ranks itself (torch.distributed.run as a child
+process, before anything touches the GPU) and exits with the child's code.  A WORLD_SIZE that disagrees with --gpus is an
+error.  The JSON carries the process group's actual size (`world_size`).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -84,8 +93,9 @@ def mlp_gemm_replay(L, M, dtype, device, reps=40):
     return e0.elapsed_time(e1), 2 * reps, reps * 2 * (2.0 * M * D * H)
 
 
-def cpu_baseline(K_adv):
-    """Oracle (kind "port") on the host cores: one RMCL step (image view, PGD K) + backward."""
+def cpu_baseline(K_adv, config="rmcl_pgd"):
+    """Oracle (kind "port") on the host cores: one RMCL step (image view, PGD K) + backward; for --config itm_clean
+    the ITM + word-patch-alignment + clean-InfoNCE step + backward."""
     from oracle import rmcl_oracle as O
     threads = os.cpu_count() or 1
     try:
@@ -101,7 +111,9 @@ def cpu_baseline(K_adv):
     threads = min(threads, 32)
     torch.set_num_threads(threads)
     Bc, nsteps = 4, 7
-    ocfg = O.default_config(per_gpu_batchsize=Bc, adv_steps_img=K_adv)
+    clean = config == "itm_clean"
+    ocfg = O.default_config(per_gpu_batchsize=Bc, adv_steps_img=K_adv, image_view=not clean, clean_view=clean)
+    labels = (torch.arange(Bc) % 2).float()
     p = O.init_params(ocfg, 1)
     for n, t in p.items():
         if not n.startswith("k_"):
@@ -112,13 +124,37 @@ def cpu_baseline(K_adv):
     for i in range(nsteps + 1):                       # 1 warm-up + nsteps timed
         t0 = time.time()
         ret = O.compute_moco_contrastive(p, ocfg, batch, queue, ptr, training=True)
-        ret["moco_loss"].backward()
+        loss = ret["moco_loss"]
+        if clean:
+            ri = O.compute_itm_wpa(p, ocfg, batch, labels)
+            loss = loss + ri["itm_loss"] + ri["itm_wpa_loss"]
+        loss.backward()
         ptr = ret["ptr"]
         if i > 0:
             dt += time.time() - t0
     return {"value": Bc * nsteps / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{nsteps} steps of the same workload at bs={Bc} (12 layers, queue 65536, PGD K={K_adv}, fwd+bwd, no optimizer), "
-                      f"fp32 CPU oracle, {dt:.1f} s"}
+            "sample": f"{nsteps} steps of the same workload at bs={Bc} (12 layers, queue 65536, "
+                      + ("ITM+WPA + clean InfoNCE" if clean else f"PGD K={K_adv}") + f", fwd+bwd, no optimizer), fp32 CPU oracle, {dt:.1f} s"}
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torchrun: start the N ranks as a child torch.distributed.run (nothing has touched the GPU in
+    this process) and leave with its exit code."""
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def traffic_record(kernel_key):
+    """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/roofline_traffic.json,
+    written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload,
+    gfx950 correction applied: FETCH_SIZE x 2).  None when no record matches."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
+        return rec.get(kernel_key)
+    except Exception:
+        return None
 
 
 def main():
@@ -132,11 +168,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--drop-rate", type=float, default=0.0,
                     help="0 = the parity configuration (headline); 0.1 = the reference's training default (config.py:57)")
+    ap.add_argument("--config", default="rmcl_pgd", choices=["rmcl_pgd", "itm_clean"],
+                    help="rmcl_pgd = BASELINE configs[2]/[3] (the metric); itm_clean = BASELINE configs[1]")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 f"(or without a torchrun environment, then bench.py starts the ranks itself)")
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     use_dist = world > 1 or os.environ.get("RMCL_BENCH_FORCE_DIST", "0") == "1"   # (1-rank rehearsal of the N > 1 code path)
@@ -156,13 +199,20 @@ def main():
     if world > 1:
         L.check(L.lib.rmcl_tune_set(1, 8), "tune_set")     # leave 8 CUs to RCCL's channels (include/rmcl.h)
     B, K = args.batch, args.adv_steps
-    cfg = task_moco(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=args.drop_rate, image_view=True,
-                    text_view=False, max_steps=100000)
+    clean = args.config == "itm_clean"
+    cfg = task_moco(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=args.drop_rate, image_view=not clean,
+                    text_view=False, clean_view=clean, max_steps=100000)
+    if clean:
+        cfg["loss_names"]["itm"] = 1
     torch.manual_seed(0)
     model = ViLTransformerSS(cfg, device=device, compute_dtype=args.dtype)
     model.train()
     (opt,), (sched,) = model.configure_optimizers()
     batch = synthetic_batch(cfg, B, 1234 + rank, device)
+    if clean:
+        batch["false_image_0"] = [torch.roll(batch["image"][0], shifts=1, dims=0)]    # SURVEY 8d Config 2
+    if use_dist:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     def step(i):
         loss = model.training_step(batch, i)
@@ -200,23 +250,33 @@ def main():
         # algorithmic FLOPs per GPU per step: SURVEY 8(d) counts (5+2K)F; with dropout off the clean query forward
         # and PGD step 0's forward are the same computation and run once -> (4+2K)F are executed and credited
         step_flops = ((4 if args.drop_rate == 0 else 5) + 2 * K) * F_PER_PAIR * B
+        workload = (f"RMCL step, PGD K={K} image attack + MoCo InfoNCE (queue 65536) + full backward + AdamW, "
+                    f"ViLT-B/32, bs={B}/GPU, 384x384 img + 40 tok (BASELINE configs[2]; [3] when n_gpus=8)")
+        metric = f"image-text pairs/sec, ViLT-B/32 RMCL step (PGD K={K})"
+        if clean:                                        # key 1F + clean query fwd+bwd 3F + ITM fwd+bwd 3F (SURVEY 8d Config 2)
+            step_flops = 7 * F_PER_PAIR * B
+            workload = (f"clean ITM + contrastive step: ITM + word-patch alignment (IPOT) + CE on the clean InfoNCE logits (queue 65536) "
+                        f"+ full backward + AdamW, ViLT-B/32, bs={B}/GPU, 384x384 img + 40 tok (BASELINE configs[1])")
+            metric = "image-text pairs/sec, ViLT-B/32 clean ITM+contrastive step"
         kern_tf = kern_fl / (kern_ms * 1e-3) / 1e12 if kern_n else 0.0
+        traffic = traffic_record("mlp_fwd_pair") if args.dtype == "bf16" and B == 64 else None
         out = {
-            "metric": f"image-text pairs/sec, ViLT-B/32 RMCL step (PGD K={K})", "value": round(value, 2), "unit": "pairs/s",
+            "metric": metric, "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"RMCL step, PGD K={K} image attack + MoCo InfoNCE (queue 65536) + full backward + AdamW, "
-                                   f"ViLT-B/32, bs={B}/GPU, 384x384 img + 40 tok (BASELINE configs[2]; [3] when n_gpus=8)",
-                       "global_batch": world * B, "parallelism": f"dp{world}", "drop_rate": args.drop_rate,
+            "world_size": dist.get_world_size() if use_dist else 1,
+            "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}", "drop_rate": args.drop_rate,
                        "final_loss": round(final_loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(kern_tf, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                         "frac": round(kern_tf * 1e12 / PEAK_BF16, 4), "traffic": None,
+                         "frac": round(kern_tf * 1e12 / PEAK_BF16, 4),
+                         "traffic": traffic["bytes_per_launch"] if traffic else None,
+                         "traffic_note": (traffic or {}).get("note"),
                          "kernel": "encoder MLP forward GEMMs (fc1 768->3072 +bias+GELU, fc2 3072->768 +bias+residual), "
                                    f"M={B * 185}; {kern_n} replayed launches, avg {kern_ms / max(kern_n, 1):.4f} ms"},
             "step_mfma_frac": round(step_flops / (elapsed / args.steps) / PEAK_BF16, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(K)
+            out["cpu_baseline"] = cpu_baseline(K, args.config)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()                                     # rank 0 is still replaying / printing: leave together

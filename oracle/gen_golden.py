@@ -19,7 +19,7 @@ vilt_module.py:275-351) pointed at the q-modules, resp. k-modules + q-pooler (:4
 Weights: ``oracle.rmcl_oracle.init_params(cfg, seed)`` loaded into the reference modules via
 their state-dict names, so a fixture is reproducible from (cfg, seed) without the reference.
 
-Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz, ~1 min)
+Usage:  python oracle/gen_golden.py [moco itm moco2 cleanitm txtatk sched]   (writes tests/golden/*.npz, ~2 min)
 """
 from __future__ import annotations
 
@@ -76,6 +76,9 @@ def _install_standins():
     pl = mod("pytorch_lightning", LightningModule=nn.Module)
     pl.metrics = mod("pytorch_lightning.metrics", Metric=object)
     mod("TSNE_vizualisation", TSNE_projection=None)
+    # attack/greedy_attack_vilt.py:2,7-8 imports nltk at module top; its stop-word / wordnet loaders are never called
+    nl = mod("nltk")
+    nl.corpus = mod("nltk.corpus", stopwords=None, wordnet=None)
     for pkg in ("vilt", "vilt.modules"):
         m = types.ModuleType(pkg)
         m.__path__ = [os.path.join(REF, *pkg.split("."))]
@@ -88,6 +91,7 @@ import vilt.modules.vision_transformer as vit  # noqa: E402  (reference, unmodif
 import vilt.modules.heads as heads  # noqa: E402
 import vilt.modules.objectives as objectives  # noqa: E402
 from attack.pgd_attack_vilt import PGDAttack, PGDAttack_moco  # noqa: E402
+from attack.greedy_attack_vilt import GreedyAttack_moco  # noqa: E402
 from transformers.models.bert.modeling_bert import BertConfig, BertEmbeddings  # noqa: E402
 
 
@@ -164,6 +168,9 @@ class Holder(nn.Module):
         for n, prm in self.named_parameters():
             if n.startswith("k_"):
                 prm.requires_grad = False
+
+
+NUDGE = 0.002         # step size of the SGD nudge between the two steps of the moco2 fixtures
 
 
 def tensor_digest(t: torch.Tensor) -> np.ndarray:
@@ -285,11 +292,232 @@ def run_itm(tag, cfg, B, seed_w, seed_b, ragged):
     print(tag, "itm", out["itm_loss"], out["itm_wpa_loss"], "bytes", os.path.getsize(path))
 
 
+def _grad_digests(h):
+    gnames, gd = [], []
+    for n, prm in h.named_parameters():
+        if not n.startswith("k_") and prm.grad is not None:
+            gnames.append(n)
+            gd.append(tensor_digest(prm.grad))
+    return np.array(gnames), np.stack(gd)
+
+
+def _ema_digests(h):
+    names, kd = [], []
+    for n, prm in h.named_parameters():
+        if n.startswith("k_"):
+            names.append(n)
+            kd.append(tensor_digest(prm))
+    return np.array(names), np.stack(kd)
+
+
+def run_moco_two_step(tag, cfg, B, seed_w, seed_k, seed_b, ragged, ptr0, nudge):
+    """Two consecutive reference steps from a NON-degenerate state: k_* != q (own seed), queue pointer != 0,
+    momentum < 1, and an SGD-style nudge q <- q - nudge * grad between the steps, so that the EMA, the enqueue
+    offset, the key encoder's own weights and the 'k modules + query pooler' quirk (vilt_module.py:405) all
+    carry information in the fixture."""
+    torch.manual_seed(1234)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+    cfg = dict(cfg, per_gpu_batchsize=B)
+    p = O.init_params(cfg, seed_w, k_seed=seed_k)
+    h = Holder(cfg)
+    h.load_oracle_params(p)
+    h.proj_queue.copy_(O.init_queue(cfg, 0))
+    h.proj_queue_ptr[0] = ptr0
+    h.train()
+    out = {}
+    b0 = O.synthetic_batch(cfg, B, seed_b, ragged_text=ragged)
+    with torch.no_grad():
+        rk = h.infer_k(deepcopy(b0))                        # k modules + QUERY pooler, before any EMA
+        out["init_k_cls_feats"] = rk["cls_feats"].numpy()
+        out["init_k_raw_cls_feats"] = rk["raw_cls_feats"].numpy()
+        out["init_k_proj"] = nn.functional.normalize(h.k_moco_head(rk["cls_feats"]), dim=1).numpy()
+        rq = h.infer(deepcopy(b0))
+        out["init_q_cls_feats"] = rq["cls_feats"].numpy()
+    for s in range(2):
+        batch = O.synthetic_batch(cfg, B, seed_b + s, ragged_text=ragged)
+        h.zero_grad()
+        h.logged = {}
+        ret = objectives.compute_moco_contrastive(h, deepcopy(batch))
+        loss = sum(v for kk, v in ret.items() if "loss" in kk)
+        loss.backward()
+        out[f"s{s}_moco_loss"] = np.float64(loss.item())
+        out[f"s{s}_ptr_after"] = np.int64(int(h.proj_queue_ptr))
+        with torch.no_grad():                               # the key of this step: k weights are final after the EMA
+            rk = h.infer_k(deepcopy(batch))
+            out[f"s{s}_k"] = nn.functional.normalize(h.k_moco_head(rk["cls_feats"]), dim=1).numpy()
+        out["ema_names"], out[f"s{s}_ema_digest"] = _ema_digests(h)
+        out["grad_names"], out[f"s{s}_grad_digest"] = _grad_digests(h)
+        out[f"s{s}_k_qkv0_w"] = h.k_transformer.blocks[0].attn.qkv.weight[:8, :64].detach().numpy().copy()
+        out[f"s{s}_delta_log"] = np.float64(h.logged["moco_attack/train/delta"])
+        for kk, v in ret.items():
+            if kk != "moco_loss":
+                out[f"s{s}_ret_" + kk] = np.float64(float(v))
+        if s == 0:
+            with torch.no_grad():
+                for n, prm in h.named_parameters():
+                    if not n.startswith("k_") and prm.grad is not None:
+                        prm.data -= nudge * prm.grad
+    out["queue_block_after"] = h.proj_queue[:, ptr0 - B: min(ptr0 + 3 * B, cfg["num_negative"])].numpy().copy()
+    out["meta"] = np.array([B, seed_w, seed_b, int(ragged), cfg["num_layers"], cfg["num_negative"], cfg["adv_steps_img"]])
+    out["meta2"] = np.array([seed_k, ptr0, cfg["momentum"], nudge], dtype=np.float64)
+    path = os.path.join(ROOT, "tests", "golden", f"moco2_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(tag, "two-step losses", out["s0_moco_loss"], out["s1_moco_loss"], "bytes", os.path.getsize(path))
+
+
+def run_clean_itm(tag, cfg, B, seed_w, seed_k, seed_b, ragged):
+    """BASELINE configs[1] 'clean ITM + contrastive' from the reference's pieces: the clean logits exactly as
+    objectives.py:262-275 forms them (EMA, infer_k, infer, moco_head, normalize, einsum, /T) + CrossEntropyLoss
+    with label 0 like :333,351, plus the unmodified compute_itm_wpa; total = sum of the three losses."""
+    torch.manual_seed(777)
+    cfg = dict(cfg, per_gpu_batchsize=B)
+    p = O.init_params(cfg, seed_w, k_seed=seed_k)
+    h = Holder(cfg)
+    h.load_oracle_params(p)
+    h.proj_queue.copy_(O.init_queue(cfg, 0))
+    h.train()
+    batch = O.synthetic_batch(cfg, B, seed_b, ragged_text=ragged)
+    h.zero_grad()
+    ret_itm = objectives.compute_itm_wpa(h, deepcopy(batch))
+    with torch.no_grad():                                    # objectives.py:219-224,257-260
+        for q_l, k_l in ((h.text_embeddings, h.k_text_embeddings), (h.token_type_embeddings, h.k_token_type_embeddings),
+                         (h.transformer, h.k_transformer), (h.moco_head, h.k_moco_head)):
+            for pq, pk in zip(q_l.parameters(), k_l.parameters()):
+                pk.data = pk.data * h.momentum + pq.data * (1.0 - h.momentum)
+        rk = h.infer_k(deepcopy(batch), mask_text=False, mask_image=False)
+        k = nn.functional.normalize(h.k_moco_head(rk["cls_feats"]), dim=1)
+    inf = h.infer(deepcopy(batch), mask_text=False, mask_image=False)
+    q_original = nn.functional.normalize(h.moco_head(inf["cls_feats"]), dim=1)
+    neg_k = h.proj_queue.clone().detach()
+    l_pos = torch.einsum('nc,nc->n', [q_original, k]).unsqueeze(-1)
+    l_neg = torch.einsum('nc,ck->nk', [q_original, neg_k])
+    logits = torch.cat([l_pos, l_neg], dim=1)
+    logits = logits / h.temperature
+    labels = torch.zeros(logits.shape[0], dtype=torch.long)
+    clean_loss = nn.CrossEntropyLoss()(logits.float(), labels)
+    total = ret_itm["itm_loss"] + ret_itm["itm_wpa_loss"] + clean_loss
+    total.backward()
+    out = {"itm_loss": np.float64(ret_itm["itm_loss"].item()), "itm_wpa_loss": np.float64(ret_itm["itm_wpa_loss"].item()),
+           "clean_loss": np.float64(clean_loss.item()), "total_loss": np.float64(total.item()),
+           "itm_labels": ret_itm["itm_labels"].numpy(), "itm_logits": ret_itm["itm_logits"].detach().numpy(),
+           "k": k.numpy(), "q_original": q_original.detach().numpy(),
+           "logits_head": logits[:, :64].detach().numpy(), "prediction_original": logits.argmax(-1).numpy()}
+    out["grad_names"], out["grad_digest"] = _grad_digests(h)
+    out["meta"] = np.array([B, seed_w, seed_b, int(ragged), cfg["num_layers"], cfg["num_negative"], seed_k])
+    path = os.path.join(ROOT, "tests", "golden", f"cleanitm_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(tag, "clean+itm", out["clean_loss"], out["itm_loss"], out["itm_wpa_loss"], "bytes", os.path.getsize(path))
+
+
+def run_text_attack(tag, cfg, B, seed_w, seed_k, seed_b, ragged, n_cand):
+    """Tensor side of the greedy text attack from the reference's own GreedyAttack_moco.get_grad / split_forward
+    (attack/greedy_attack_vilt.py:406-492).  The object is made with __new__ (its __init__ loads a tokenizer by
+    name and nltk stop words - unavailable offline and never needed by these two methods); build_mini_vilt
+    (:391-397) deep-copies the holder's modules like the reference does."""
+    torch.manual_seed(99)
+    cfg = dict(cfg, per_gpu_batchsize=B)
+    p = O.init_params(cfg, seed_w, k_seed=seed_k)
+    h = Holder(cfg)
+    h.load_oracle_params(p)
+    h.proj_queue.copy_(O.init_queue(cfg, 0))
+    h.train()
+    batch = O.synthetic_batch(cfg, B, seed_b, ragged_text=ragged)
+    with torch.no_grad():
+        rk = h.infer_k(deepcopy(batch))
+        k = nn.functional.normalize(h.k_moco_head(rk["cls_feats"]), dim=1)
+    g = GreedyAttack_moco.__new__(GreedyAttack_moco)
+    g.max_image_len = cfg["max_image_len"]
+    g.criterion = nn.CrossEntropyLoss()                     # greedy_attack_vilt.py:501 (without .cuda)
+    g.build_mini_vilt(h)
+    ids, masks = batch["text_ids"], batch["text_masks"]
+    loss, grads, q = g.get_grad(ids.clone(), masks.clone(), batch["text"], deepcopy(batch), torch.device("cpu"), k)
+    out = {"k": k.numpy(), "loss": np.float64(loss.item()), "q": q.detach().numpy(),
+           "saliency_l1": np.abs(grads).sum(-1), "grads_sub": grads[:, :, ::16].copy(),
+           "grads_digest": tensor_digest(torch.from_numpy(grads))}
+    # candidates: the same synthetic replacement rule the build's default candidate_fn uses, at the top-saliency
+    # position of every sample (positions 1..sep-1)
+    fn = O.synthetic_candidates(cfg.get("seed", 0), n_cand, cfg["vocab_size"])
+    rows, all_num, pos = [], [], []
+    sal = torch.from_numpy(out["saliency_l1"])
+    for b in range(B):
+        sep = int((ids[b] == 102).nonzero()[0])
+        t = int(torch.argsort(sal[b, 1:sep], descending=True, stable=True)[0]) + 1
+        pos.append(t)
+        for c in fn(0, b, t, ids[b]):
+            r = ids[b].clone()
+            r[t] = c
+            rows.append(r)
+        all_num.append(n_cand)
+    cids = torch.stack(rows)
+    own = torch.arange(B).repeat_interleave(n_cand)
+    cb = {"text_ids": cids, "text_masks": masks[own], "text_labels": batch["text_labels"][own], "image": [batch["image"][0][own]],
+          "text": ["synthetic"] * len(rows)}
+    all_loss = g.split_forward(cb, all_num, q.detach().clone(), k)
+    out["cand_pos"] = np.array(pos)
+    out["cand_ids"] = cids.numpy()
+    out["cand_loss"] = np.array([[float(x) for x in cl] for cl, _ in all_loss])       # batch-mean CE with row i replaced
+    out["cand_best_idx"] = np.array([j for _, j in all_loss])
+    out["meta"] = np.array([B, seed_w, seed_b, int(ragged), cfg["num_layers"], cfg["num_negative"], seed_k, n_cand])
+    path = os.path.join(ROOT, "tests", "golden", f"txtatk_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(tag, "text attack loss", out["loss"], "best idx", out["cand_best_idx"], "bytes", os.path.getsize(path))
+
+
+def run_schedules():
+    """LR curves from transformers.optimization (the functions vilt_utils.py:404-432 calls; importable here).
+    HF AdamW itself (vilt_utils.py:395-398, transformers==4.2.1) no longer exists in the installed transformers:
+    the optimizer stays parity-unpinned (restated from the 4.2.1 source), only the schedules are pinned."""
+    from transformers.optimization import get_polynomial_decay_schedule_with_warmup, get_cosine_schedule_with_warmup
+    out = {}
+    for name, (base, warm, total, end_lr, power) in {"poly1": (1e-4, 10, 100, 0.0, 1.0), "poly2": (3e-4, 25, 250, 1e-6, 2.0),
+                                                      "poly_nowarm": (1e-4, 0, 40, 0.0, 1.0)}.items():
+        w = nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([w], lr=base)
+        sch = get_polynomial_decay_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total, lr_end=end_lr, power=power)
+        lrs = []
+        for _ in range(total + 20):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[name] = np.array(lrs)
+        out[name + "_args"] = np.array([base, warm, total, end_lr, power])
+    for name, (base, warm, total) in {"cos1": (1e-4, 10, 100), "cos2": (2e-4, 0, 64)}.items():
+        w = nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([w], lr=base)
+        sch = get_cosine_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total)
+        lrs = []
+        for _ in range(total + 20):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[name] = np.array(lrs)
+        out[name + "_args"] = np.array([base, warm, total])
+    path = os.path.join(ROOT, "tests", "golden", "schedules.npz")
+    np.savez_compressed(path, **out)
+    print("schedules", {k: v.shape for k, v in out.items() if not k.endswith("_args")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     small = O.default_config(num_layers=2, num_negative=1024)
     full = O.default_config()
-    run_moco("L2_B4_ragged", small, 4, 11, 21, True)
-    run_moco("L12_B2", full, 2, 12, 22, False)
-    run_itm("L2_B4_ragged", small, 4, 11, 21, True)
-    run_itm("L12_B2", full, 2, 12, 22, False)
+    only = set(sys.argv[1:])
+    want = lambda n: not only or n in only
+    if want("moco"):
+        run_moco("L2_B4_ragged", small, 4, 11, 21, True)
+        run_moco("L12_B2", full, 2, 12, 22, False)
+    if want("itm"):
+        run_itm("L2_B4_ragged", small, 4, 11, 21, True)
+        run_itm("L12_B2", full, 2, 12, 22, False)
+    if want("moco2"):
+        run_moco_two_step("L2_B4_ragged", dict(small, adv_steps_img=2, momentum=0.9), 4, 11, 31, 21, True, 12, NUDGE)
+        run_moco_two_step("L12_B2", dict(full, momentum=0.95), 2, 12, 32, 22, False, 65536 - 4, NUDGE)     # second enqueue wraps the pointer to 0
+    if want("cleanitm"):
+        run_clean_itm("L2_B4_ragged", dict(small, momentum=0.9), 4, 11, 31, 21, True)
+        run_clean_itm("L12_B2", dict(full, momentum=0.95), 2, 12, 32, 22, False)
+    if want("txtatk"):
+        run_text_attack("L2_B4_ragged", small, 4, 11, 31, 21, True, 5)
+    if want("sched"):
+        run_schedules()

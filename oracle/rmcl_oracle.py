@@ -90,7 +90,7 @@ def param_shapes(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
     return s
 
 
-def init_params(cfg: dict, seed: int, dtype=torch.float32) -> Params:
+def init_params(cfg: dict, seed: int, dtype=torch.float32, k_seed: Optional[int] = None, k_scale: float = 0.01) -> Params:
     """Seeded, machine-independent synthetic weights (CPU generator).
 
     NOT the reference's initialiser (objectives.py:1505-1516 zeroes every bias and sets
@@ -98,7 +98,9 @@ def init_params(cfg: dict, seed: int, dtype=torch.float32) -> Params:
     reference, but biases ~ N(0, 0.02) and LayerNorm weights ~ 1 + N(0, 0.05).  The golden
     generator loads exactly these tensors into the reference modules, so fixtures are
     reproducible from (cfg, seed) alone.  Momentum copies start equal to the query
-    weights (vilt_module.py:270-273)."""
+    weights (vilt_module.py:270-273) unless ``k_seed`` is given: then k_* = q + k_scale * N(0,1) from
+    its own generator - the NORMAL case in the reference, whose k_* modules are shadowed before the
+    strict=False checkpoint load (vilt_module.py:75-85 vs :135-138) and then trail q by the EMA."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     p: Params = {}
@@ -108,9 +110,16 @@ def init_params(cfg: dict, seed: int, dtype=torch.float32) -> Params:
             "norm.weight") or name.endswith("LayerNorm.weight") or name.endswith("projector.1.weight"):
             t = 1.0 + 2.5 * t
         p[name] = t.to(dtype)
+    gk = None
+    if k_seed is not None:
+        gk = torch.Generator(device="cpu")
+        gk.manual_seed(k_seed)
     for name in list(p.keys()):
         if name.split(".")[0] in EMA_GROUPS:
-            p["k_" + name] = p[name].clone()
+            kt = p[name].clone()
+            if gk is not None:
+                kt = kt + (k_scale * torch.randn(kt.shape, generator=gk, dtype=torch.float32)).to(dtype)
+            p["k_" + name] = kt
     return p
 
 
@@ -398,14 +407,22 @@ def greedy_text_attack(p: Params, cfg: dict, batch: dict, k: Tensor, queue: Tens
             out = infer(pd, cfg, cids, masks[own], img[own])
             qc = l2_normalize(moco_head(pd, "", out["cls_feats"]))
             cec = infonce_ce_rows(qc, k[own], queue, T)
+        # split_forward (:454-492) scores candidate j of sample b by the BATCH-MEAN loss with row b replaced, against the
+        # original batch-mean loss.  Reference quirk (found while pinning the fixture): `t_save = ori_z[i]` (:475) is a
+        # view, so the "restore" at :489 is a no-op and row i keeps its LAST candidate while samples i+1.. are scored:
+        # loss_bj = mean(ce0) + sum_{r<b} (ce_{r,last} - ce0_r)/B + (ce_bj - ce0_b)/B.
+        ori_loss = float(ce0.mean())
+        drift = 0.0
         for b in range(Bn):
             idx = (own == b).nonzero().flatten().tolist()
+            best, best_j = ori_loss, -1
+            for j, r in enumerate(idx):
+                lj = ori_loss + drift + (float(cec[r]) - float(ce0[b])) / Bn
+                if lj > best:
+                    best, best_j = lj, j
+            drift += (float(cec[idx[-1]]) - float(ce0[b])) / Bn
             if pos_of[idx[0]] is None:
                 continue
-            best, best_j = float(ce0[b]), -1
-            for j, r in enumerate(idx):
-                if float(cec[r]) > best:
-                    best, best_j = float(cec[r]), j
             if best_j > 0:
                 changes[b] += 1
                 ids[b] = cids[idx[best_j]]
@@ -416,10 +433,11 @@ def greedy_text_attack(p: Params, cfg: dict, batch: dict, k: Tensor, queue: Tens
 
 
 def ema_update(p: Params, m: float) -> None:
-    """_momentum_update_key_layer (objectives.py:219-224,257-260)."""
-    for name in list(p.keys()):
-        if name.startswith("k_"):
-            p[name] = p[name] * m + p[name[2:]] * (1.0 - m)
+    """_momentum_update_key_layer (objectives.py:219-224,257-260; on .data, i.e. outside autograd)."""
+    with torch.no_grad():
+        for name in list(p.keys()):
+            if name.startswith("k_"):
+                p[name] = p[name] * m + p[name[2:]] * (1.0 - m)
 
 
 def enqueue(queue: Tensor, ptr: int, keys_all: Tensor, per_step_bs: int) -> int:
@@ -437,7 +455,7 @@ def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, p
 
     Mutates ``p`` (EMA of k_*) and ``queue``.  Returns the loss (with autograd graph onto the
     query params that have requires_grad), logits, delta, metrics and the new queue pointer."""
-    if not (cfg["image_view"] or cfg["text_view"]):
+    if not (cfg["image_view"] or cfg["text_view"] or cfg.get("clean_view", False)):
         raise ZeroDivisionError("loss / loss_num with both views off (objectives.py:250-251,397)")
     ema_update(p, cfg["momentum"])
     ids, masks, img = batch["text_ids"], batch["text_masks"], batch["image"][0]
@@ -451,6 +469,10 @@ def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, p
     pred0 = logits0.argmax(-1)
     ret = {"k": k, "q_original": q0.detach(), "logits_original": logits0.detach()}
     loss, n = 0.0, 0
+    if cfg.get("clean_view", False):
+        # BASELINE configs[1] "clean ITM + contrastive" (SURVEY 8d Config 2): CE on the clean logits the reference
+        # forms at objectives.py:267-275 (the reference itself never turns them into a loss: quirk 3)
+        loss, n = loss + infonce_loss(logits0), n + 1
     t_ids = t_masks = None
     if cfg["text_view"]:                                                   # objectives.py:277-317
         fn = cfg.get("candidate_fn") or synthetic_candidates(cfg.get("seed", 0), cfg["n_candidates"], cfg["vocab_size"])

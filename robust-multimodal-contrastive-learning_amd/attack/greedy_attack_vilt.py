@@ -45,6 +45,50 @@ class GreedyAttack_moco(GreedyAttack):
     def __init__(self, config, candidate_fn: Optional[Callable] = None):
         super().__init__(config, "moco", candidate_fn)
 
+    # ---- tensor side, same method names as the reference ----------------------------------------------------------
+    def get_grad(self, pl_module, pb, op, de):
+        """get_grad (:406-452): forward, batch-mean InfoNCE, backward to the OUTPUT of word_embeddings (what the
+        reference's backward hook captures).  Returns (per-row CE [B], grads view [B,L,D] = `de`, q [B,128])."""
+        eng = pl_module.engine
+        Bn = pb.B
+        eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+        eng.heads_forward(pb, key=False)
+        eng.infonce(pb, 1.0 / Bn, want_dq=True)
+        ce0 = pb.rows[:, 0].clone()
+        eng.heads_backward(pb, pb.dq, None, with_grads=False)
+        eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=None, dtext=de)
+        return ce0, de.view(Bn, pb.d.L, -1), pb.q
+
+    def split_forward(self, pl_module, pc, n_real):
+        """split_forward (:454-492), device part: candidates through the encoder, per-row CE against the same keys."""
+        eng = pl_module.engine
+        eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT)
+        eng.heads_forward(pc, key=False)
+        eng.infonce(pc, 0.0, want_dq=False)
+        return pc.rows[:n_real, 0]
+
+    @staticmethod
+    def select(ce0, cec, owner, n_real, Bn):
+        """split_forward's scoring (:466-490) on per-row CE values.  The reference evaluates the BATCH-MEAN loss with row
+        i replaced by candidate j and compares it with the original batch mean.  Its `t_save = ori_z[i]` (:475) is a
+        view, so the restore at :489 is a no-op and row i keeps its LAST candidate while later samples are scored:
+            loss_ij = mean(ce0) + sum_{r<i} (ce_{r,last} - ce0_r)/B + (ce_ij - ce0_i)/B
+        Returns [(losses, best index or -1)] per sample (first maximum, strict >, like :485-486)."""
+        ori = float(sum(ce0) / Bn)
+        out, drift, start = [], 0.0, 0
+        for b in range(Bn):
+            idx = [i for i in range(start, n_real) if owner[i] == b]
+            start = idx[-1] + 1
+            best, best_j, losses = ori, -1, []
+            for j, r in enumerate(idx):
+                lj = ori + drift + (cec[r] - ce0[b]) / Bn
+                losses.append(lj)
+                if lj > best:
+                    best, best_j = lj, j
+            drift += (cec[idx[-1]] - ce0[b]) / Bn
+            out.append((losses, best_j))
+        return out
+
     def adv_attack_samples(self, pl_module, batch, k_modality):
         eng = pl_module.engine
         dev = eng.device
@@ -63,18 +107,11 @@ class GreedyAttack_moco(GreedyAttack):
         history = [set() for _ in range(Bn)]
         changes = [0] * Bn
         sep = [int((ids_host[b] == SEP_ID).nonzero()[0]) for b in range(Bn)]
-        per_sample = op.shape[0] // Bn
 
         for loop in range(self.max_loops):
-            # ---- get_grad: forward, InfoNCE, backward to the word-embedding output --------------------
             pb.text_ids = ids_host.to(dev)
-            eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
-            eng.heads_forward(pb, key=False)
-            eng.infonce(pb, 1.0 / Bn, want_dq=True)
-            ce0 = pb.rows[:, 0].clone()
-            eng.heads_backward(pb, pb.dq, None, with_grads=False)
-            eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=None, dtext=de)
-            sal = de.view(Bn, Lt, -1).abs().sum(-1).cpu()            # L1 norm of the gradient per position (:221-228)
+            ce0, grads, _ = self.get_grad(pl_module, pb, op, de)
+            sal = grads.abs().sum(-1).cpu()                          # L1 norm of the gradient per position (:221-228)
             # ---- pick one position per sample, build the candidate sentences (host logic) -------------
             rows, owner, pos_of = [], [], []
             for b in range(Bn):
@@ -97,30 +134,22 @@ class GreedyAttack_moco(GreedyAttack):
             while len(rows) < Bc:                                      # pad to the fixed candidate batch
                 rows.append(ids_host[0].clone()); owner.append(0)
             own = torch.tensor(owner, device=dev)
-            # ---- split_forward: candidates through the encoder, per-row CE against the same keys -------
             pc.text_ids = torch.stack(rows).to(dev)
             pc.text_mask = masks.index_select(0, own)
             torch.index_select(op.view(Bn, -1), 0, own, out=pc.patchesT.view(Bc, -1))
             pc.k.copy_(k.index_select(0, own))
-            eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT)
-            eng.heads_forward(pc, key=False)
-            eng.infonce(pc, 0.0, want_dq=False)
-            cec = pc.rows[:n_real, 0].cpu()
-            ce0h = ce0.cpu()
-            # ---- selection (:471-490, :562-578): best candidate must beat the current loss, index > 0 ---
+            cec = self.split_forward(pl_module, pc, n_real).cpu().tolist()
+            picks = self.select(ce0.cpu().tolist(), cec, owner, n_real, Bn)
+            # ---- selection (:562-578): a changed sample takes its best candidate when its index is > 0 ---
             start = 0
-            for b in range(Bn):
-                idx = [i for i in range(start, n_real) if owner[i] == b]
-                start = idx[-1] + 1
-                if pos_of[idx[0]] is None:
+            for b, (_, best_j) in enumerate(picks):
+                first = start
+                start += len(picks[b][0])
+                if pos_of[first] is None:
                     continue
-                best, best_j = float(ce0h[b]), -1
-                for j, r in enumerate(idx):
-                    if float(cec[r]) > best:
-                        best, best_j = float(cec[r]), j
                 if best_j > 0:
                     changes[b] += 1
-                    ids_host[b] = rows[idx[best_j]]
+                    ids_host[b] = rows[first + best_j]
 
         nchg = [(orig[b] != ids_host[b]).sum().item() for b in range(Bn)]
         nwords = [max(sep[b] - 1, 1) for b in range(Bn)]

@@ -39,6 +39,7 @@ class PGDAttack_moco(PGDAttack):
         pb.delta_prev.zero_()
         if k is not None and k.data_ptr() != pb.k.data_ptr():
             pb.k.copy_(k)
+        pb = eng.pgd_bufs(pb)                                 # fp32 twin when the engine runs PGD in fp32 (:141)
         for step in range(K):
             if step == K - 1 and K > 1:
                 pb.delta_prev.copy_(pb.delta)

@@ -5,15 +5,18 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT" obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast"
+SRCS="gemm_exact.hip gemm_fast.hip gemm_big.hip gemm_pp.hip gemm_st.hip gemm_sw.hip norm_softmax.hip embed_misc.hip infonce.hip ipot.hip itm.hip attention.hip encoder.cpp api.cpp"
 pids=()
-for f in gemm_exact.hip gemm_fast.hip gemm_big.hip gemm_pp.hip gemm_st.hip gemm_sw.hip norm_softmax.hip embed_misc.hip infonce.hip ipot.hip itm.hip attention.hip encoder.cpp api.cpp; do
-  [ -f "$f" ] || continue
+objs=()
+for f in $SRCS; do
+  [ -f "$f" ] || { echo "build.sh: missing source $f" >&2; exit 1; }
   o=obj/${f%.*}.o
+  objs+=("$o")
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name '*.h' -newer "$o")" ] || [ ../../include/rmcl.h -nt "$o" ]; then
     ( hipcc $FLAGS -x hip -c "$f" -o "$o" ) &
     pids+=($!)
   fi
 done
-for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC obj/*.o -o "$OUT/librmcl_hip.so"
+for p in "${pids[@]}"; do wait $p || { echo "build.sh: compile failed" >&2; exit 1; }; done
+hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT/librmcl_hip.so"
 echo "built $OUT/librmcl_hip.so"

@@ -81,9 +81,10 @@ EMA_GROUPS = ("text_embeddings", "token_type_embeddings", "transformer", "moco_h
 class PassBuffers:
     """Everything sized by the per-GPU batch B (allocated once, reused every step)."""
 
-    def __init__(self, eng: "Engine", B: int):
+    def __init__(self, eng: "Engine", B: int, dtype=None):
         dev = eng.device
-        d = eng.dims(B)
+        self.dtype = eng.dtype if dtype is None else dtype       # arithmetic of the passes run through these buffers
+        d = eng.dims(B, self.dtype)
         self.B = B
         self.d = d
         N = d.L + 1 + d.P
@@ -98,7 +99,7 @@ class PassBuffers:
         self.co_mask = torch.empty(B, N, dtype=torch.int32, device=dev)
         self.xn = f32(M, d.D)
         self.patches32 = f32(B * d.P, d.patch_k)
-        tdt = torch.float32 if eng.dtype == L.F32 else torch.bfloat16
+        tdt = torch.float32 if self.dtype == L.F32 else torch.bfloat16
         self.patchesT = torch.empty(B * d.P, d.patch_k, dtype=tdt, device=dev)
         self.patchesT_full = torch.empty(B * d.P, d.patch_k, dtype=tdt, device=dev)
         self.gpatch = torch.empty(B * d.P, d.patch_k, dtype=tdt, device=dev)
@@ -119,13 +120,17 @@ class PassBuffers:
 
 
 class Engine:
-    def __init__(self, cfg: dict, device, dtype: str = "bf16", exact: bool = False):
+    def __init__(self, cfg: dict, device, dtype: str = "bf16", exact: bool = False, pgd_dtype=None):
         if not torch.cuda.is_available():
             raise L.RmclError("rmcl_amd needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         self.cfg = cfg
         self.device = torch.device(device)
         self.dtype = {"f32": L.F32, "fp32": L.F32, "bf16": L.BF16}[dtype]
         self.exact = bool(exact) or self.dtype == L.F32
+        # precision of the PGD inner loop only: the reference forces fp32 there (attack/pgd_attack_vilt.py:141) while its
+        # main forwards run under autocast; "f32" reproduces that split on a bf16 engine (exact fp32 matrix cores: a
+        # measurement / parity mode, ~6x slower than bf16 PGD).  None: PGD runs in the engine's dtype.
+        self.pgd_dtype = {None: None, "f32": L.F32, "fp32": L.F32, "bf16": None}[pgd_dtype] if self.dtype == L.BF16 else None
         self.num_negative = int(cfg.get("num_negative", 65536))
         d0 = self.dims(1)
         self.layout = L.Layout()
@@ -151,15 +156,26 @@ class Engine:
             lib.rmcl_set_side_stream(C.c_void_p(self.dw_stream.cuda_stream))
 
     # ---- geometry ------------------------------------------------------------------------------
-    def dims(self, B: int) -> L.Dims:
-        return make_dims(self.cfg, B, self.dtype, getattr(self, "exact", False))
+    def dims(self, B: int, dtype=None) -> L.Dims:
+        dt = self.dtype if dtype is None else dtype
+        return make_dims(self.cfg, B, dt, getattr(self, "exact", False) or dt == L.F32)
 
-    def bufs(self, B: int, tag: str = "moco") -> PassBuffers:
+    def bufs(self, B: int, tag: str = "moco", dtype=None) -> PassBuffers:
         """Per-(batch size, objective) buffers: each objective keeps its own FULL stash so that several
         task losses of one training_step can be backpropagated after all forwards have run."""
         if (B, tag) not in self._bufs:
-            self._bufs[(B, tag)] = PassBuffers(self, B)
+            self._bufs[(B, tag)] = PassBuffers(self, B, dtype)
         return self._bufs[(B, tag)]
+
+    def pgd_bufs(self, pb: PassBuffers) -> PassBuffers:
+        """Buffers of the PGD inner loop: `pb` itself, or (pgd_dtype="f32" on a bf16 engine) an fp32 twin that shares the
+        batch, the keys and the perturbation buffers with `pb`."""
+        if self.pgd_dtype is None or self.pgd_dtype == pb.dtype:
+            return pb
+        pp = self.bufs(pb.B, "pgd_f32", self.pgd_dtype)
+        pp.text_ids, pp.text_mask, pp.patches32 = pb.text_ids, pb.text_mask, pb.patches32
+        pp.delta, pp.delta_prev, pp.k = pb.delta, pb.delta_prev, pb.k
+        return pp
 
     def view(self, arena: torch.Tensor, off: int, shape) -> torch.Tensor:
         n = 1
@@ -215,7 +231,7 @@ class Engine:
     def make_operand(self, pb: PassBuffers, d1=None, d2=None, out=None) -> torch.Tensor:
         """out = cast(patches32 + d1 + d2): the `img_init + img_delta` of pgd_attack_vilt.py:144."""
         out = pb.patchesT if out is None else out
-        check(lib.rmcl_add_cast_f32(P(pb.patches32), P(d1), P(d2), P(out), self.dtype,
+        check(lib.rmcl_add_cast_f32(P(pb.patches32), P(d1), P(d2), P(out), pb.dtype,
                                     I64(pb.patches32.numel()), stream_ptr()), "add_cast")
         return out
 
@@ -262,7 +278,7 @@ class Engine:
 
     def pgd_step(self, pb: PassBuffers, lr: float, eps: float):
         per = pb.d.P * pb.d.patch_k
-        check(lib.rmcl_pgd_step(P(pb.gpatch), self.dtype, P(pb.delta), P(pb.amax), pb.B, I64(per), F(lr), F(eps),
+        check(lib.rmcl_pgd_step(P(pb.gpatch), pb.dtype, P(pb.delta), P(pb.amax), pb.B, I64(per), F(lr), F(eps),
                                 stream_ptr()), "pgd_step")
 
     def enqueue(self, keys_all: torch.Tensor, ptr: int):

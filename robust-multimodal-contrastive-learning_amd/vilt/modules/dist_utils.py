@@ -73,9 +73,10 @@ def allreduce_mean_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, as
     return works
 
 
-def allreduce_sum_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024):
-    """Blocking bucketed SUM over the flat gradient arena (the 1/world_size is applied to the loss gradient beforehand)."""
-    if world_size() == 1:
+def allreduce_sum_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, force: bool = False):
+    """Blocking bucketed SUM over the flat gradient arena (the 1/world_size is applied to the loss gradient beforehand).
+    ``force``: issue the collectives even in a 1-rank group (single-GPU rehearsal of the communication path)."""
+    if world_size() == 1 and not force:
         return
     n = flat.numel()
     for s in range(0, n, bucket_elems):
@@ -131,3 +132,49 @@ class GradSync:
         for w in self.works:
             w.wait()
         self.works = []
+
+
+class StepGradSync:
+    """Reduces the gradient arena over ranks EXACTLY ONCE per backward pass of a training step, whatever the number of
+    deferred-backward closures that accumulate into it (itm + moco, the three RMCL views, gradient accumulation).
+
+    Why: the HIP backward kernels accumulate (``dW +=``) into one flat arena.  Reducing after every closure would sum
+    the already-reduced part over ranks again (g = W^2 R_a + W R_b ... instead of the mean).  So closures only report
+    that they ran; the SUM all-reduce is launched when the last closure of the step has been enqueued.  The 1/world_size
+    of DDP's mean (run.py:96) is applied to every closure's incoming loss gradient (``prescale``), including micro-steps
+    whose reduction is skipped (``enabled=False``: gradient accumulation, DDP ``no_sync`` semantics).
+
+    ``overlap``: a factory returning a ``GradSync`` (per-layer buckets gated on the backward's events); used only when the
+    step has a single closure, because the per-layer events belong to ONE backward."""
+
+    def __init__(self):
+        self.open = 0
+        self.created = 0
+        self.handle = None
+
+    def begin_step(self):
+        self.open = 0
+        self.created = 0
+
+    def register(self) -> float:
+        """A loss with a deferred backward was created; returns the gradient prescale for its closure."""
+        self.open += 1
+        self.created += 1
+        return 1.0 / world_size()
+
+    def closure_done(self, flat: torch.Tensor, enabled: bool = True, overlap=None):
+        self.open = max(0, self.open - 1)
+        if self.open > 0 or not enabled:
+            return
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        self.wait()
+        if overlap is not None and self.created == 1:
+            self.handle = overlap()
+        else:
+            allreduce_sum_(flat, force=True)
+
+    def wait(self):
+        if self.handle is not None:
+            self.handle.wait()
+            self.handle = None

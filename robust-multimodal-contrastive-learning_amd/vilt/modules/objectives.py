@@ -61,19 +61,22 @@ def _only_moco(pl_module):
     return ln.get("moco", 0) > 0 and sum(1 for v in ln.values() if v > 0) == 1
 
 
-def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_original, ret, phase):
-    """One attacked view (objectives.py:287-317 / :324-354 / :362-392): encoder forward on `op` with the text in
-    `pv`, InfoNCE against the queue, metrics, and a loss tensor whose backward runs the HIP backward."""
+def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_original, ret, phase, before_loss=None):
+    """One loss view (objectives.py:287-317 / :324-354 / :362-392; suffix "clean": the clean query of :267-275 as a
+    loss, BASELINE configs[1]): encoder forward on `op` with the text in `pv`, InfoNCE against the queue, metrics, and a
+    loss tensor whose backward runs the HIP backward."""
     eng = pl_module.engine
     B = pv.B
     need_grad = torch.is_grad_enabled() and pl_module.training
-    if pv.k.data_ptr() != k.data_ptr():
-        pv.k.copy_(k)
     eng.encoder_forward(pv, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op)
     eng.heads_forward(pv, key=False)
+    if before_loss is not None:
+        before_loss()                                  # e.g. join the key-encoder stream: k is needed from here on
+    if pv.k.data_ptr() != k.data_ptr():
+        pv.k.copy_(k)
     eng.infonce(pv, 1.0 / B, want_dq=need_grad)
     rows = pv.rows
-    if phase == "train":
+    if phase == "train" and success_name is not None:
         pl_module.log(f"moco_attack/{success_name}", (rows[:, 1] != prediction_original).float().mean())
     for j, name in ((3, "pos_dist"), (4, "pos_cosine"), (5, "pos_dot"), (6, "neg_dist"), (7, "neg_cosine"), (8, "neg_dot")):
         ret[f"{name}_attacked_{suffix}"] = rows[:, j].mean()
@@ -88,7 +91,9 @@ def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_origin
         eng.heads_backward(pv, dq, None, with_grads=True)
         eng.encoder_backward(pv, L.MODE_FULL, op, pv.dcls, cls_only=True, dpatches=None)
         # one attacked view = one backward per step: its gradient all-reduces can start layer by layer right away
-        pl_module.after_backward(overlap=(pl_module.image_view != pl_module.text_view) and _only_moco(pl_module))
+        # reduced over ranks once per step, after the step's last closure; a single closure (the image-view step) gets
+        # per-layer all-reduces that start while the layers below are still in their backward
+        pl_module.after_backward(overlap=True)
 
     return _DeferredBackward.apply(pl_module.grad_anchor, value, backward, pl_module.grad_prescale())
 
@@ -186,7 +191,8 @@ def compute_itm_wpa(pl_module, batch):
 def compute_moco_contrastive(pl_module, batch):
     """objectives.py:217-447 (image view).  Returns {"moco_loss", pos_/neg_{dist,cosine,dot}_attacked_img}."""
     eng = pl_module.engine
-    if not (pl_module.image_view or pl_module.text_view):
+    clean_view = bool(pl_module.hparams.config.get("clean_view", False))
+    if not (pl_module.image_view or pl_module.text_view or clean_view):
         raise ZeroDivisionError("division by zero: loss / loss_num with both views off (objectives.py:250-251,397)")
     if pl_module.augmentation:
         raise NotImplementedError("augmentation views are out of scope (SURVEY 2.1 #17)")
@@ -219,9 +225,22 @@ def compute_moco_contrastive(pl_module, batch):
     k = pb.k
     # PGD step 0 runs the query encoder on img + delta_0 = img: with dropout off that IS the clean query forward
     # (:267-275), so it is computed once (common sub-expression) and its logits give prediction_original.
-    fuse_clean = pl_module.image_view and not pl_module.text_view and not eng.dropout_on
+    fuse_clean = pl_module.image_view and not pl_module.text_view and not eng.dropout_on and not clean_view
     clean = {}
-    if not fuse_clean:
+    loss = 0
+    loss_num = 0
+    if clean_view:
+        # build extension (config key "clean_view", default off): CE on the clean logits of :267-275 as a loss term -
+        # BASELINE configs[1] "clean ITM + contrastive" (SURVEY 8d Config 2).  The reference forms these logits in
+        # every step but never turns them into a loss (quirk 3).
+        pc = eng.bind_text(pb, pb.text_ids, pb.text_mask, tag="moco_clean")
+        op_c = eng.make_operand(pb, out=pc.patchesT_full)
+        loss_c = _attacked_view(pl_module, pc, op_c, k, "clean", None, None, ret, phase, before_loss=join_key_stream)
+        clean = {"prediction": pc.rows[:, 1].clone(), "q": pc.q.clone()}
+        pl_module.log("moco_loss/clean_loss", loss_c.detach())
+        loss = loss + loss_c
+        loss_num += 1
+    elif not fuse_clean:
         eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)     # clean query
         eng.heads_forward(pb, key=False)
         join_key_stream()
@@ -229,8 +248,6 @@ def compute_moco_contrastive(pl_module, batch):
         clean = {"prediction": pb.rows[:, 1].clone(), "q": pb.q.clone()}
     prediction_original = clean.get("prediction")
 
-    loss = 0
-    loss_num = 0
     txt_ids = txt_masks = None
     if pl_module.text_view:                                                 # :277-317
         aug = compute_geometric(pl_module, copy(batch), "moco", k_modality=k)

@@ -6,6 +6,7 @@ minimal ``log`` / ``hparams`` shim), the caller may be any loop that does
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import types
 
@@ -18,6 +19,10 @@ from ...runtime import Engine, EMA_GROUPS
 from ...attack.pgd_attack_vilt import PGDAttack_moco
 from ...attack.greedy_attack_vilt import GreedyAttack_moco
 from . import objectives, vilt_utils, dist_utils
+
+
+def config_patch(module) -> int:
+    return int(module.hparams.config["patch_size"])
 
 
 class _Node(nn.Module):
@@ -35,11 +40,11 @@ def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
 
 
 class ViLTransformerSS(nn.Module):
-    def __init__(self, config, device="cuda:0", compute_dtype="bf16", exact=False):
+    def __init__(self, config, device="cuda:0", compute_dtype="bf16", exact=False, pgd_dtype=None):
         super().__init__()
         self.hparams = types.SimpleNamespace(config=config)
         self.config = config
-        self.engine = Engine(config, device, compute_dtype, exact)
+        self.engine = Engine(config, device, compute_dtype, exact, pgd_dtype)
         eng = self.engine
         self.current_tasks = []
         self.logged = {}
@@ -76,8 +81,28 @@ class ViLTransformerSS(nn.Module):
             if self.text_view and not self.augmentation:
                 self.greedy_attacker = GreedyAttack_moco(config)
         self.grad_anchor = torch.zeros((), device=eng.device, requires_grad=True)
-        self.sync_grads = True
+        self.sync_grads = True                     # False on the early micro-steps of gradient accumulation (DDP no_sync)
+        self.step_sync = dist_utils.StepGradSync()
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._after_load())
+        # downstream checkpoint (vilt_module.py:134-160, test_only twin :252-268): loaded AFTER the momentum copies were
+        # shadowed, strict=False, like the reference - so k_* keys absent from the file keep their pre-load values
+        if config.get("load_path", "") not in ("", None):
+            self._load_checkpoint(config["load_path"])
+
+    def _load_checkpoint(self, path):
+        # weights_only=True: executes nothing from the file (the reference uses a full unpickle, vilt_module.py:138)
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        state_dict = ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+        if self.hparams.config["loss_names"].get("itm", 0) > 0:          # ITM head from the 200k checkpoint (:152-159)
+            for cand in ("models_weight/vilt_200k_mlm_itm.ckpt", "../models_weight/vilt_200k_mlm_itm.ckpt"):
+                if os.path.isfile(cand):
+                    c2 = torch.load(cand, map_location="cpu", weights_only=True)["state_dict"]
+                    state_dict["itm_score.fc.weight"] = c2["itm_score.fc.weight"]
+                    state_dict["itm_score.fc.bias"] = c2["itm_score.fc.bias"]
+                    break
+        mine = self.state_dict()
+        usable = {k: v for k, v in state_dict.items() if k in mine and tuple(mine[k].shape) == tuple(v.shape)}
+        return self.load_state_dict(usable, strict=False)
 
     # ---- initialisation (objectives.init_weights :1505-1516, ViT _init_weights :512-519) ----
     @torch.no_grad()
@@ -89,6 +114,15 @@ class ViLTransformerSS(nn.Module):
             is_ln = any(t in name for t in ("LayerNorm", "norm1", "norm2", "transformer.norm", "projector.1"))
             if is_ln:
                 p.fill_(1.0 if leaf == "weight" else 0.0)
+            elif name.startswith("transformer.patch_embed.proj"):
+                # the reference leaves the patch projection at nn.Conv2d's default init (vision_transformer.py:397-403;
+                # VisionTransformer._init_weights :512-519 only touches nn.Linear / nn.LayerNorm)
+                fan_in = p.shape[1] * p.shape[2] * p.shape[3] if p.dim() == 4 else 3 * config_patch(self) ** 2
+                if leaf == "weight":
+                    nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                else:
+                    bound = 1.0 / math.sqrt(fan_in)
+                    p.uniform_(-bound, bound)
             elif leaf == "bias":
                 p.zero_()
             elif name.startswith("transformer."):
@@ -129,42 +163,34 @@ class ViLTransformerSS(nn.Module):
         self.proj_queue_ptr.fill_(int(v))
 
     def after_backward(self, overlap: bool = False):
-        """DDP replacement: average the flat gradient arena over ranks (run.py:96).  Called by the deferred-backward
-        closures right after the HIP backward has been ENQUEUED.  overlap=True (the MoCo step: one backward per
-        step): per-layer all-reduces gated on the backward's gradient-ready events; otherwise one blocking pass."""
-        import torch.distributed as dist
-        if not (self.sync_grads and dist.is_available() and dist.is_initialized()):
-            return
+        """DDP replacement (run.py:96).  Called by every deferred-backward closure right after its HIP backward has been
+        ENQUEUED.  The arena is reduced once per step, after the LAST closure (dist_utils.StepGradSync): with a single
+        closure (the MoCo image-view step) as per-layer all-reduces gated on the backward's gradient-ready events
+        (overlap=True), otherwise as one blocking pass over the arena."""
         e = self.engine
+        factory = None
         if overlap and e.g32.is_cuda and os.environ.get("RMCL_NO_GRAD_OVERLAP", "0") != "1":
             lay = e.layout
-            buckets = dist_utils.grad_buckets(int(lay.layer0), int(lay.layer_stride), int(self.hparams.config["num_layers"]),
-                                              int(e.g32.numel()))
 
             def gate(layer, stream):
                 check(lib.rmcl_grad_ready_wait(int(layer), C.c_void_p(stream.cuda_stream)), "grad_ready_wait")
 
-            self.wait_grad_sync()
-            self._grad_sync = dist_utils.GradSync(e.g32, buckets, e.comm_stream, gate, prescaled=True)
-        else:
-            self.wait_grad_sync()
-            if dist_utils.world_size() > 1:
-                dist_utils.allreduce_sum_(e.g32)
+            def factory():
+                buckets = dist_utils.grad_buckets(int(lay.layer0), int(lay.layer_stride), int(self.hparams.config["num_layers"]),
+                                                  int(e.g32.numel()))
+                return dist_utils.GradSync(e.g32, buckets, e.comm_stream, gate, prescaled=True)
+
+        self.step_sync.closure_done(e.g32, enabled=self.sync_grads, overlap=factory)
 
     def grad_prescale(self) -> float:
-        """1 / world_size when this module averages gradients over ranks (applied to the loss gradient, see
-        objectives._DeferredBackward), else 1."""
-        import torch.distributed as dist
-        if self.sync_grads and dist.is_available() and dist.is_initialized():
-            return 1.0 / dist.get_world_size()
-        return 1.0
+        """Registers one deferred backward with the step's gradient reducer and returns 1 / world_size: the mean over
+        ranks is applied to the loss gradient of EVERY closure (objectives._DeferredBackward), also on micro-steps
+        whose reduction is skipped (sync_grads=False: gradient accumulation)."""
+        return self.step_sync.register()
 
     def wait_grad_sync(self):
         """Make the current stream wait for the overlapped gradient all-reduces (the optimizer calls this)."""
-        gs = getattr(self, "_grad_sync", None)
-        if gs is not None:
-            gs.wait()
-            self._grad_sync = None
+        self.step_sync.wait()
 
     def zero_grad(self, set_to_none: bool = False):
         self.engine.zero_grads()
@@ -214,6 +240,7 @@ class ViLTransformerSS(nn.Module):
         return self._infer(batch, True, mask_text, mask_image, image_token_type_idx, image_embeds, image_masks)
 
     def forward(self, batch):
+        self.step_sync.begin_step()
         self.engine.dropout_on = self.training and self.engine.drop_p > 0
         ret = dict()
         if len(self.current_tasks) == 0:
@@ -234,10 +261,19 @@ class ViLTransformerSS(nn.Module):
         total_loss = sum([v for k, v in output.items() if "loss" in k])
         return total_loss
 
+    def training_epoch_end(self, outs=None):
+        vilt_utils.epoch_wrapup(self)
+
     def validation_step(self, batch, batch_idx):
         vilt_utils.set_task(self)
         with torch.no_grad():
             return self(batch)
+
+    def validation_epoch_end(self, outs=None):
+        vilt_utils.epoch_wrapup(self)
+
+    def test_epoch_end(self, outs=None):
+        vilt_utils.epoch_wrapup(self)
 
     def test_step(self, batch, batch_idx):
         return self.validation_step(batch, batch_idx)

@@ -11,6 +11,7 @@ import torch
 from ... import _lib as L
 from ..._lib import lib, check, P, I64, F
 from ...runtime import stream_ptr
+from . import schedules
 
 NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight", "norm.bias", "norm.weight", "norm1.bias", "norm1.weight",
             "norm2.bias", "norm2.weight"]
@@ -20,6 +21,18 @@ HEAD_NAMES = ["vqa_classifier", "nlvr2_classifier", "moco_head", "barlowtwinshea
 def set_task(pl_module):
     pl_module.current_tasks = [k for k, v in pl_module.hparams.config["loss_names"].items() if v >= 1]
     return
+
+
+def epoch_wrapup(pl_module):
+    """vilt_utils.epoch_wrapup (:227-323) for the tasks on this path: the reference computes and logs the epoch value of
+    every task metric and resets it.  Metrics here are the per-step values kept in ``pl_module.logged``; the wrap-up
+    returns them as ``the_metric`` inputs and clears them.  (As written, the reference's own wrap-up reads undefined
+    ``text_attack`` / ``image_attack`` attributes, :236 - not imitated.)"""
+    phase = "train" if pl_module.training else "val"
+    out = {k: (float(v) if torch.is_tensor(v) and v.numel() == 1 else v) for k, v in pl_module.logged.items()}
+    pl_module.logged = {}
+    pl_module.last_epoch_metrics = {"phase": phase, **out}
+    return pl_module.last_epoch_metrics
 
 
 class FusedAdamW:
@@ -72,12 +85,7 @@ class PolySchedule:
         self._apply()
 
     def lr_at(self, step):
-        if step < self.warmup:
-            return self.base * step / max(1, self.warmup)
-        if step > self.total:
-            return self.end_lr
-        rem = 1 - (step - self.warmup) / (self.total - self.warmup)
-        return (self.base - self.end_lr) * rem ** self.power + self.end_lr
+        return schedules.poly_lr(step, self.base, self.warmup, self.total, self.end_lr, self.power)
 
     def _apply(self):
         self.opt.param_groups[0]["lr"] = self.lr_at(self.n)
@@ -88,11 +96,10 @@ class PolySchedule:
 
 
 class CosineSchedule(PolySchedule):
+    """get_cosine_schedule_with_warmup (vilt_utils.py:417-421)."""
+
     def lr_at(self, step):
-        if step < self.warmup:
-            return self.base * step / max(1, self.warmup)
-        prog = (step - self.warmup) / max(1, self.total - self.warmup)
-        return self.base * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+        return schedules.cosine_lr(step, self.base, self.warmup, self.total)
 
 
 def set_schedule(pl_module):
@@ -101,6 +108,11 @@ def set_schedule(pl_module):
         raise NotImplementedError("only optim_type='adamw' (the reference default) is built")
     opt = FusedAdamW(pl_module, cfg["learning_rate"], cfg["weight_decay"], cfg["lr_mult"])
     max_steps = cfg["max_steps"]
+    if max_steps is None:
+        # the reference derives it from the Lightning trainer's dataloader (vilt_utils.py:404-411); there is no
+        # trainer here, so the caller states it
+        raise ValueError("set_schedule: config['max_steps'] is None - set it to the number of optimizer steps "
+                         "(the reference computes it from len(train_dataloader) * max_epoch // accumulate_grad_batches)")
     warmup = cfg["warmup_steps"]
     if isinstance(warmup, float):
         warmup = int(max_steps * warmup)

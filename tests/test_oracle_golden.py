@@ -101,3 +101,128 @@ def test_both_views_off_raises():
     cfg = O.default_config(num_layers=1, image_view=False, text_view=False)
     with pytest.raises(ZeroDivisionError):
         O.compute_moco_contrastive({}, cfg, {}, None, 0)
+
+
+# ---- round 2: non-degenerate fixtures (k != q, queue pointer != 0, two consecutive steps) ---------------------------
+
+def _two_step_cfg(g):
+    cfg, B, sw, sb, ragged = cfg_from_meta(O, g["meta"])
+    seed_k, ptr0, momentum, nudge = g["meta2"]
+    cfg["momentum"] = float(momentum)
+    return cfg, B, sw, sb, ragged, int(seed_k), int(ptr0), float(nudge)
+
+
+@pytest.mark.parametrize("tag", ["L2_B4_ragged", "L12_B2"])
+def test_two_step_k_ne_q_matches_reference(tag):
+    g = load(f"moco2_{tag}.npz")
+    cfg, B, sw, sb, ragged, seed_k, ptr0, nudge = _two_step_cfg(g)
+    p = O.init_params(cfg, sw, k_seed=seed_k)
+    queue = O.init_queue(cfg, 0)
+    b0 = O.synthetic_batch(cfg, B, sb, ragged_text=ragged)
+    with torch.no_grad():
+        rk = O.infer(p, cfg, b0["text_ids"], b0["text_masks"], b0["image"][0], key=True)     # k modules + QUERY pooler
+        np.testing.assert_allclose(rk["cls_feats"].numpy(), g["init_k_cls_feats"], atol=2e-5)
+        np.testing.assert_allclose(O.l2_normalize(O.moco_head(p, "k_", rk["cls_feats"])).numpy(), g["init_k_proj"], atol=2e-5)
+        assert np.abs(g["init_k_cls_feats"] - g["init_q_cls_feats"]).max() > 0.1               # the fixture is not degenerate
+    ptr = ptr0
+    for s in range(2):
+        for n, t in p.items():
+            if not n.startswith("k_"):
+                t.requires_grad_(True)
+                t.grad = None
+        batch = O.synthetic_batch(cfg, B, sb + s, ragged_text=ragged)
+        ret = O.compute_moco_contrastive(p, cfg, batch, queue, ptr, training=True)
+        assert abs(float(ret["moco_loss"]) - float(g[f"s{s}_moco_loss"])) < 1e-3, s
+        ret["moco_loss"].backward()
+        ptr = ret["ptr"]
+        assert ptr == int(g[f"s{s}_ptr_after"])
+        np.testing.assert_allclose(ret["k"].numpy(), g[f"s{s}_k"], atol=2e-5)
+        for name, dg in zip(g["ema_names"], g[f"s{s}_ema_digest"]):
+            np.testing.assert_allclose(digest(p[str(name)]), dg, rtol=1e-5, atol=2e-6, err_msg=str(name))
+        np.testing.assert_allclose(p["k_transformer.blocks.0.attn.qkv.weight"][:8, :64].numpy(), g[f"s{s}_k_qkv0_w"], atol=1e-6)
+        for name, dg in zip(g["grad_names"], g[f"s{s}_grad_digest"]):
+            t = p[str(name)].grad
+            mine = digest(t)
+            assert abs(mine[1] - dg[1]) <= 3e-3 * max(dg[1], 1e-6) + 1e-7, (s, name, mine[1], dg[1])
+        if s == 0:
+            with torch.no_grad():
+                for n, t in p.items():
+                    if not n.startswith("k_") and t.grad is not None:
+                        t -= nudge * t.grad
+    Kq = cfg["num_negative"]
+    np.testing.assert_allclose(queue[:, ptr0 - B: min(ptr0 + 3 * B, Kq)].numpy(), g["queue_block_after"], atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["L2_B4_ragged", "L12_B2"])
+def test_clean_itm_matches_reference_pieces(tag):
+    """BASELINE configs[1]: CE on the clean logits (objectives.py:267-275) + compute_itm_wpa."""
+    g = load(f"cleanitm_{tag}.npz")
+    B, sw, sb, ragged, L, Kq, seed_k = [int(x) for x in g["meta"]]
+    cfg = O.default_config(num_layers=L, num_negative=Kq, per_gpu_batchsize=B, image_view=False, text_view=False, clean_view=True,
+                           momentum=0.9 if L == 2 else 0.95)
+    p = O.init_params(cfg, sw, k_seed=seed_k)
+    for n, t in p.items():
+        if not n.startswith("k_"):
+            t.requires_grad_(True)
+    batch = O.synthetic_batch(cfg, B, sb, ragged_text=bool(ragged))
+    queue = O.init_queue(cfg, 0)
+    ri = O.compute_itm_wpa(p, cfg, batch, torch.from_numpy(g["itm_labels"]))
+    rm = O.compute_moco_contrastive(p, cfg, batch, queue, 0, training=False)
+    assert abs(float(rm["moco_loss"]) - float(g["clean_loss"])) < 1e-3
+    assert abs(float(ri["itm_loss"]) - float(g["itm_loss"])) < 1e-5
+    assert abs(float(ri["itm_wpa_loss"]) - float(g["itm_wpa_loss"])) < 1e-5
+    np.testing.assert_allclose(rm["k"].numpy(), g["k"], atol=2e-5)
+    np.testing.assert_allclose(rm["q_original"].numpy(), g["q_original"], atol=2e-5)
+    np.testing.assert_allclose(rm["logits_original"][:, :64].numpy(), g["logits_head"], atol=1e-3)
+    (rm["moco_loss"] + ri["itm_loss"] + ri["itm_wpa_loss"]).backward()
+    for name, dg in zip(g["grad_names"], g["grad_digest"]):
+        mine = digest(p[str(name)].grad)
+        assert abs(mine[1] - dg[1]) <= 3e-3 * max(dg[1], 1e-6) + 1e-7, (name, mine[1], dg[1])
+
+
+def test_text_attack_tensor_side_matches_reference():
+    """a14 pinned: saliency (get_grad, greedy_attack_vilt.py:406-452) and candidate losses (split_forward :454-492)."""
+    g = load("txtatk_L2_B4_ragged.npz")
+    B, sw, sb, ragged, L, Kq, seed_k, n_cand = [int(x) for x in g["meta"]]
+    cfg = O.default_config(num_layers=L, num_negative=Kq, per_gpu_batchsize=B)
+    p = O.init_params(cfg, sw, k_seed=seed_k)
+    batch = O.synthetic_batch(cfg, B, sb, ragged_text=bool(ragged))
+    queue = O.init_queue(cfg, 0)
+    k = torch.from_numpy(g["k"])
+    ids, masks, img = batch["text_ids"], batch["text_masks"], batch["image"][0]
+    grads, q = O.text_saliency(p, cfg, ids, masks, img, k, queue)
+    np.testing.assert_allclose(q.numpy(), g["q"], atol=2e-5)
+    np.testing.assert_allclose(grads[:, :, ::16].numpy(), g["grads_sub"], atol=2e-3 * np.abs(g["grads_sub"]).max())
+    np.testing.assert_allclose(grads.abs().sum(-1).numpy(), g["saliency_l1"], rtol=3e-3, atol=1e-6)
+    ce0 = O.infonce_ce_rows(q, k, queue, cfg["temperature"])
+    assert abs(float(ce0.mean()) - float(g["loss"])) < 1e-3
+    cids = torch.from_numpy(g["cand_ids"])
+    own = torch.arange(B).repeat_interleave(n_cand)
+    with torch.no_grad():
+        out = O.infer(p, cfg, cids, masks[own], img[own])
+        qc = O.l2_normalize(O.moco_head(p, "", out["cls_feats"]))
+        cec = O.infonce_ce_rows(qc, k[own], queue, cfg["temperature"]).view(B, n_cand)
+    # reference: batch-mean CE with row i replaced by candidate j, rows < i left at their LAST candidate (the `t_save`
+    # view quirk, greedy_attack_vilt.py:475,489)  ==  mean(ce0) + drift_i + (ce_ij - ce0_i) / B
+    drift = torch.cumsum((cec[:, -1] - ce0) / B, 0) - (cec[:, -1] - ce0) / B
+    mine = ce0.mean() + drift[:, None] + (cec - ce0[:, None]) / B
+    np.testing.assert_allclose(mine.numpy(), g["cand_loss"], atol=2e-4)
+    best = [int(j) if float(mine[b, j]) > float(ce0.mean()) else -1 for b, j in enumerate(mine.argmax(1))]
+    assert best == g["cand_best_idx"].tolist()
+
+
+def test_lr_schedules_match_transformers():
+    """f1: the schedules vilt_utils.py:404-432 builds, against transformers.optimization's own curves."""
+    import rmcl_pkg  # noqa: F401
+    from rmcl_amd.vilt.modules.schedules import poly_lr, cosine_lr
+    g = load("schedules.npz")
+    for name in ("poly1", "poly2", "poly_nowarm"):
+        base, warm, total, end_lr, power = g[name + "_args"]
+        mine = [poly_lr(i, base, int(warm), int(total), end_lr, power) for i in range(len(g[name]))]
+        np.testing.assert_allclose(mine, g[name], rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose([O.poly_lr(i, base, int(warm), int(total), end_lr, power) for i in range(len(g[name]))], g[name],
+                                   rtol=1e-12, atol=1e-18)
+    for name in ("cos1", "cos2"):
+        base, warm, total = g[name + "_args"]
+        mine = [cosine_lr(i, base, int(warm), int(total)) for i in range(len(g[name]))]
+        np.testing.assert_allclose(mine, g[name], rtol=1e-12, atol=1e-18)

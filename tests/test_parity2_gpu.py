@@ -1,0 +1,359 @@
+"""-m gpu, round 2: parity cases that CAN fail where round 1's could not.
+
+  * two consecutive reference steps from a non-degenerate state (k_* != q, queue pointer != 0, momentum < 1, weight
+    nudge between the steps): EMA, enqueue offset / wrap, the key encoder's own weights and the 'k modules + QUERY
+    pooler' quirk (vilt_module.py:405) all carry information - fp32 at north_star's 1e-3, bf16 with stated bounds;
+  * a sabotage test: binding the QUERY arena in the key pass must turn that comparison red;
+  * the benchmarked bf16 path at 12 layers against the reference golden (loss, cls_feats, delta saturation pattern,
+    gradient digests), and the same with the PGD legs in fp32 like the reference (pgd_attack_vilt.py:141);
+  * BASELINE configs[1] (clean ITM + contrastive) against the reference's pieces, and at 12 layers / bs=64 in bf16;
+  * the greedy text attack's tensor side against the reference's own get_grad / split_forward;
+  * the Adam part of the fused AdamW against torch.optim.AdamW.
+Measured errors are appended to gpurun_out/parity2_measured.json so DESIGN.md can quote them."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import rmcl_pkg  # noqa: F401,E402
+from oracle import rmcl_oracle as O  # noqa: E402
+from rmcl_amd import _lib as L  # noqa: E402
+from rmcl_amd.vilt.config import task_moco  # noqa: E402
+from rmcl_amd.vilt.modules import ViLTransformerSS  # noqa: E402
+from rmcl_amd.attack.pgd_attack_vilt import PGDAttack_moco  # noqa: E402
+from rmcl_amd.attack.greedy_attack_vilt import GreedyAttack_moco  # noqa: E402
+from tests.golden_util import cfg_from_meta, digest, load  # noqa: E402
+from tests.test_path_gpu import dev_batch  # noqa: E402
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def record(name, **vals):
+    path = os.path.join(ROOT, "gpurun_out", "parity2_measured.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        try:
+            data = json.load(open(path))
+        except Exception:
+            data = {}
+    data[name] = {k: (float(v) if not isinstance(v, (list, str)) else v) for k, v in vals.items()}
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
+def make_module(ocfg, seed_w, dtype="f32", k_seed=None, itm=0, pgd_dtype=None, **over):
+    cfg = task_moco(num_layers=ocfg["num_layers"], num_negative=ocfg["num_negative"], adv_steps_img=ocfg["adv_steps_img"],
+                    per_gpu_batchsize=ocfg["per_gpu_batchsize"], drop_rate=0.0, image_view=ocfg["image_view"],
+                    text_view=ocfg["text_view"], num_gpus=1, num_nodes=1, momentum=ocfg["momentum"], **over)
+    cfg["loss_names"]["itm"] = itm
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype=dtype, pgd_dtype=pgd_dtype)
+    p = O.init_params(ocfg, seed_w, k_seed=k_seed)
+    missing, unexpected = m.load_state_dict({n: t.to(DEV) for n, t in p.items()}, strict=False)
+    assert set(missing) <= {"proj_queue", "proj_queue_ptr"}, missing
+    m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+    m.train()
+    return m, p
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# two-step fixture
+# -------------------------------------------------------------------------------------------------------------------
+
+def _two_step_meta(g):
+    ocfg, B, sw, sb, ragged = cfg_from_meta(O, g["meta"])
+    seed_k, ptr0, momentum, nudge = g["meta2"]
+    ocfg["momentum"] = float(momentum)
+    return ocfg, B, sw, sb, ragged, int(seed_k), int(ptr0), float(nudge)
+
+
+def run_two_step(g, dtype, tol, sabotage=False):
+    """Drives the module through the fixture's two steps and checks every stored quantity; tolerances from `tol`."""
+    ocfg, B, sw, sb, ragged, seed_k, ptr0, nudge = _two_step_meta(g)
+    m, p = make_module(ocfg, sw, dtype, k_seed=seed_k)
+    eng = m.engine
+    if sabotage:                                            # the bug the round-1 fixtures could not see
+        eng.k32 = eng.q32[: eng.layout.ema_end]
+        eng.k_lp = eng.q_lp[: eng.layout.ema_end] if eng.q_lp is not None else None
+    m.queue_ptr = ptr0
+    b0 = dev_batch(O.synthetic_batch(ocfg, B, sb, ragged_text=ragged))
+    rk = m.infer_k(b0)
+    err = {}
+    err["init_k_cls"] = float((rk["cls_feats"].cpu() - torch.from_numpy(g["init_k_cls_feats"])).abs().max())
+    assert err["init_k_cls"] < tol["cls"], err
+    Kq = ocfg["num_negative"]
+    for s in range(2):
+        batch = dev_batch(O.synthetic_batch(ocfg, B, sb + s, ragged_text=ragged))
+        m.zero_grad()
+        ret_loss = m.training_step(batch, s)
+        err[f"s{s}_loss"] = abs(float(ret_loss) - float(g[f"s{s}_moco_loss"]))
+        assert err[f"s{s}_loss"] < tol["loss"], err
+        ret_loss.backward()
+        assert m.queue_ptr == int(g[f"s{s}_ptr_after"]) == int(m.proj_queue_ptr)
+        k_mine = eng.bufs(B).k.cpu()
+        err[f"s{s}_k"] = float((k_mine - torch.from_numpy(g[f"s{s}_k"])).abs().max())
+        assert err[f"s{s}_k"] < tol["k"], err
+        sd = m.state_dict()
+        worst = 0.0
+        for name, dg in zip(g["ema_names"], g[f"s{s}_ema_digest"]):
+            mine = digest(sd[str(name)])
+            np.testing.assert_allclose(mine, dg, rtol=2e-5, atol=1e-5, err_msg=f"step {s} {name}")   # EMA runs on fp32 masters
+            worst = max(worst, float(np.abs(mine[3:] - dg[3:]).max()))
+        err[f"s{s}_ema_head_abs"] = worst
+        np.testing.assert_allclose(sd["k_transformer.blocks.0.attn.qkv.weight"][:8, :64].cpu().numpy(), g[f"s{s}_k_qkv0_w"], atol=1e-6)
+        assert abs(float(m.logged["moco_attack/train/delta"]) - float(g[f"s{s}_delta_log"])) < tol["delta_log"]
+        params = dict(m.named_parameters())
+        worst_g = 0.0
+        for name, dg in zip(g["grad_names"], g[f"s{s}_grad_digest"]):
+            if str(name).startswith("itm_score"):
+                continue
+            mine = digest(params[str(name)].grad)
+            rel = abs(mine[1] - dg[1]) / max(dg[1], 1e-6)
+            worst_g = max(worst_g, rel)
+            assert rel <= tol["grad_norm"], (s, name, mine[1], dg[1])
+        err[f"s{s}_grad_norm_rel"] = worst_g
+        if s == 0:                                          # the fixture's SGD nudge: q <- q - nudge * grad
+            with torch.no_grad():
+                eng.q32.sub_(eng.g32, alpha=nudge)
+            eng.lp_stale = True
+    lo, hi = ptr0 - B, min(ptr0 + 3 * B, Kq)
+    err["queue_block"] = float((m.proj_queue[:, lo:hi].cpu() - torch.from_numpy(g["queue_block_after"])).abs().max())
+    assert err["queue_block"] < tol["k"], err
+    return err
+
+
+TOL_F32 = dict(cls=1e-4, loss=1e-3, k=1e-4, delta_log=1e-6, grad_norm=5e-3)
+# bf16 GEMM operands (8 significant bits), fp32 accumulate / residual stream / softmax / InfoNCE: logits are ~ +-40 at
+# T = 0.07 so a 2^-9 relative operand error moves the loss by O(0.1); k and cls are O(1) vectors.
+TOL_BF16 = dict(cls=4e-2, loss=0.6, k=2e-2, delta_log=2e-4, grad_norm=0.12)
+
+
+@pytest.mark.parametrize("tag", ["L2_B4_ragged", "L12_B2"])
+def test_two_step_fp32_matches_reference_golden(tag):
+    g = load(f"moco2_{tag}.npz")
+    err = run_two_step(g, "f32", TOL_F32)
+    record(f"two_step_f32_{tag}", **err)
+
+
+@pytest.mark.parametrize("tag", ["L2_B4_ragged", "L12_B2"])
+def test_two_step_bf16_tracks_reference_golden(tag):
+    g = load(f"moco2_{tag}.npz")
+    err = run_two_step(g, "bf16", TOL_BF16)
+    record(f"two_step_bf16_{tag}", **err)
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", TOL_F32), ("bf16", TOL_BF16)])
+def test_key_pass_reading_the_query_arena_goes_red(dtype, tol):
+    """Sabotage: bind the query arena as the key arena (an `infer_k` that reads q).  Round 1's fixtures (k == q) could not
+    see this; the two-step fixture must."""
+    g = load("moco2_L2_B4_ragged.npz")
+    with pytest.raises(AssertionError):
+        run_two_step(g, dtype, tol, sabotage=True)
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# the benchmarked bf16 path at 12 layers against the reference golden; PGD in bf16 vs PGD in fp32
+# -------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("pgd_dtype", [None, "f32"])
+def test_bf16_12_layers_against_reference_golden(pgd_dtype):
+    g = load("moco_L12_B2.npz")
+    ocfg, B, sw, sb, ragged = cfg_from_meta(O, g["meta"])
+    m, p = make_module(ocfg, sw, "bf16", pgd_dtype=pgd_dtype)
+    batch = O.synthetic_batch(ocfg, B, sb, ragged_text=ragged)
+    name = "bf16_L12" + ("_pgd_f32" if pgd_dtype else "_pgd_bf16")
+    r = m.infer(dev_batch(batch))
+    e_cls = float((r["cls_feats"].cpu() - torch.from_numpy(g["cls_feats"])).abs().max())
+    e_txt = float((r["text_feats"].cpu() - torch.from_numpy(g["text_feats"])).abs().max())
+    assert e_cls < 4e-2 and e_txt < 0.15, (e_cls, e_txt)                      # features are O(1..4) after the final LayerNorm
+    # --- delta: K = 3 steps of +-lr*eps-normalised ascent, eps-clamped: most pixels saturate at +-eps ---
+    k = torch.from_numpy(g["pgd_k_input"]).to(DEV)
+    att = PGDAttack_moco(dict(m.config))
+    b = dev_batch(batch)
+    delta = att.pgd_attack(m, b, k_modality=k).cpu()
+    eps = ocfg["adv_max_norm_img"]
+    sub, ref = delta[:, :, ::8, ::8], torch.from_numpy(g["pgd_delta_K3_sub"])
+    sat_ref = ref.abs() >= eps * (1 - 1e-6)
+    same_sat = ((sub.abs() >= eps * (1 - 1e-6)) == sat_ref) & (~sat_ref | (torch.sign(sub) == torch.sign(ref)))
+    frac_same = float(same_sat.float().mean())
+    max_dd = float((sub - ref).abs().max())
+    mean_dd = float((sub - ref).abs().mean())
+    l2_rel = float(np.abs(delta.flatten(1).norm(dim=1).numpy() - g["pgd_delta_K3_persample_l2"]).max() / g["pgd_delta_K3_persample_l2"].max())
+    assert float(delta.abs().max()) <= eps + 1e-9
+    # a sign flip of a saturated pixel costs 2*eps; bounds: >= 90 % of sampled pixels in the same saturation state
+    assert frac_same > (0.97 if pgd_dtype else 0.90), frac_same
+    assert mean_dd < (0.05 if pgd_dtype else 0.15) * eps and l2_rel < 0.03, (mean_dd, l2_rel)
+    # --- the full step ---
+    m.zero_grad()
+    m.queue_ptr = 0
+    m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+    m.shadow_momentum_encoder()
+    loss = m.training_step(dev_batch(batch), 0)
+    e_loss = abs(float(loss) - float(g["moco_loss"]))
+    assert e_loss < 0.6, e_loss
+    loss.backward()
+    e_q = float((m.proj_queue[:, :B].cpu() - torch.from_numpy(g["queue_head_after"][:, :B])).abs().max())
+    assert e_q < 2e-2, e_q
+    params = dict(m.named_parameters())
+    worst, worst_name = 0.0, ""
+    for nm, dg in zip(g["grad_names"], g["grad_digest"]):
+        if str(nm).startswith("itm_score"):
+            continue
+        mine = digest(params[str(nm)].grad)
+        rel = abs(mine[1] - dg[1]) / max(dg[1], 1e-6)
+        if rel > worst:
+            worst, worst_name = rel, str(nm)
+    assert worst < 0.15, (worst, worst_name)
+    gq = params["transformer.blocks.0.attn.qkv.weight"].grad[:8, :64].cpu().numpy()
+    cos = float((gq * g["grad_qkv0_w"]).sum() / (np.linalg.norm(gq) * np.linalg.norm(g["grad_qkv0_w"])))
+    assert cos > 0.98, cos
+    record(name, cls=e_cls, text_feats=e_txt, delta_same_saturation_frac=frac_same, delta_max_abs_diff_over_eps=max_dd / eps,
+           delta_mean_abs_diff_over_eps=mean_dd / eps, delta_l2_rel=l2_rel, loss=e_loss, key_queue=e_q,
+           grad_norm_rel_worst=worst, grad_norm_rel_worst_name=worst_name, grad_qkv0_cosine=cos)
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[1]: clean ITM + contrastive
+# -------------------------------------------------------------------------------------------------------------------
+
+def _clean_itm_module(L_, Kq, B, sw, seed_k, dtype, momentum):
+    ocfg = O.default_config(num_layers=L_, num_negative=Kq, per_gpu_batchsize=B, image_view=False, text_view=False,
+                            clean_view=True, momentum=momentum)
+    m, p = make_module(ocfg, sw, dtype, k_seed=seed_k, itm=1, clean_view=True)
+    return ocfg, m, p
+
+
+@pytest.mark.parametrize("tag", ["L2_B4_ragged", "L12_B2"])
+def test_clean_itm_step_matches_reference_pieces(tag):
+    g = load(f"cleanitm_{tag}.npz")
+    B, sw, sb, ragged, L_, Kq, seed_k = [int(x) for x in g["meta"]]
+    ocfg, m, p = _clean_itm_module(L_, Kq, B, sw, seed_k, "f32", 0.9 if L_ == 2 else 0.95)
+    m.itm_labels_override = torch.from_numpy(g["itm_labels"])
+    batch = dev_batch(O.synthetic_batch(ocfg, B, sb, ragged_text=bool(ragged)))
+    m.zero_grad()
+    loss = m.training_step(batch, 0)                                   # itm_loss + itm_wpa_loss + moco_loss (vilt_module.py:475)
+    assert abs(float(loss) - float(g["total_loss"])) < 1e-3
+    assert abs(float(m.logged["moco_loss/clean_loss"]) - float(g["clean_loss"])) < 1e-3
+    assert abs(float(m.logged["itm/train/loss"]) - float(g["itm_loss"])) < 1e-4
+    assert abs(float(m.logged["itm/train/wpa_loss"]) - float(g["itm_wpa_loss"])) < 2e-5
+    loss.backward()
+    pc = m.engine.bufs(B, "moco_clean")
+    np.testing.assert_allclose(pc.q.cpu().numpy(), g["q_original"], atol=1e-4)
+    np.testing.assert_allclose(pc.k.cpu().numpy(), g["k"], atol=1e-4)
+    assert np.array_equal(pc.rows[:, 1].cpu().numpy().astype(np.int64), g["prediction_original"])
+    params = dict(m.named_parameters())
+    for name, dg in zip(g["grad_names"], g["grad_digest"]):
+        mine = digest(params[str(name)].grad)
+        assert abs(mine[1] - dg[1]) <= 5e-3 * max(dg[1], 1e-6) + 1e-7, (name, mine[1], dg[1])
+        np.testing.assert_allclose(mine[3:], dg[3:], atol=5e-3 * dg[2] + 1e-7, err_msg=str(name))
+    assert m.queue_ptr == B                                              # train mode: keys were enqueued
+
+
+def test_clean_itm_full_size_bs64_bf16():
+    """BASELINE configs[1] at its own size (12 layers, bs=64, queue 65536, bf16): size-independent properties.
+    total = itm + wpa + clean; q, k unit-norm; enqueue == keys^T; and linearity of the shared gradient arena: the
+    step's gradients == (ITM backward alone) + (clean-InfoNCE backward alone) from the same state (momentum 1 keeps
+    the key encoder fixed across the three runs)."""
+    from rmcl_amd.vilt.modules import objectives
+    B = 64
+    ocfg, m, p = _clean_itm_module(12, 65536, B, 7, 33, "bf16", 1.0)
+    gen = torch.Generator().manual_seed(11)
+    m.itm_labels_override = (torch.rand(B, generator=gen) < 0.5).long()
+    batch = dev_batch(O.synthetic_batch(ocfg, B, 13, ragged_text=True))
+    q0 = O.init_queue(ocfg, 0).to(DEV)
+    m.zero_grad()
+    loss = m.training_step(batch, 0)
+    itm, wpa, clean = float(m.logged["itm/train/loss"]), float(m.logged["itm/train/wpa_loss"]), float(m.logged["moco_loss/clean_loss"])
+    assert torch.isfinite(loss) and abs(float(loss) - (itm + wpa + clean)) < 1e-3
+    assert 0.3 < itm < 1.5 and 20.0 < clean < 80.0
+    loss.backward()
+    torch.cuda.synchronize()
+    g_both = m.engine.g32.clone()
+    pc = m.engine.bufs(B, "moco_clean")
+    assert float((pc.q.norm(dim=1) - 1).abs().max()) < 1e-5 and float((pc.k.norm(dim=1) - 1).abs().max()) < 1e-5
+    assert torch.equal(m.proj_queue[:, :B].t().contiguous(), pc.k) and m.queue_ptr == B
+    assert torch.equal(m.proj_queue[:, B:], q0[:, B:])
+    parts = []
+    for fn, keys in ((objectives.compute_itm_wpa, ("itm_loss", "itm_wpa_loss")), (objectives.compute_moco_contrastive, ("moco_loss",))):
+        m.zero_grad()
+        m.queue_ptr = 0
+        m.proj_queue.copy_(q0)
+        ret = fn(m, batch)
+        sum(ret[k] for k in keys).backward()
+        torch.cuda.synchronize()
+        parts.append(m.engine.g32.clone())
+    diff = float((g_both - parts[0] - parts[1]).norm() / g_both.norm())
+    assert diff < 1e-5, diff
+    assert float(parts[0].norm()) > 0 and float(parts[1].norm()) > 0
+    record("clean_itm_bs64_bf16", itm=itm, wpa=wpa, clean=clean, arena_linearity_rel=diff)
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# greedy text attack, tensor side (a14), against the reference's own get_grad / split_forward
+# -------------------------------------------------------------------------------------------------------------------
+
+def test_text_attack_tensor_side_matches_reference_golden():
+    g = load("txtatk_L2_B4_ragged.npz")
+    B, sw, sb, ragged, L_, Kq, seed_k, n_cand = [int(x) for x in g["meta"]]
+    ocfg = O.default_config(num_layers=L_, num_negative=Kq, per_gpu_batchsize=B)
+    m, p = make_module(ocfg, sw, "f32", k_seed=seed_k)
+    eng = m.engine
+    batch = dev_batch(O.synthetic_batch(ocfg, B, sb, ragged_text=bool(ragged)))
+    att = GreedyAttack_moco(dict(m.config))
+    pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], batch["image"][0], tag="txtatk")
+    op = eng.make_operand(pb)
+    pb.k.copy_(torch.from_numpy(g["k"]).to(DEV))
+    de = torch.empty(B * pb.d.L, pb.d.D, device=DEV)
+    ce0, grads, q = att.get_grad(m, pb, op, de)
+    np.testing.assert_allclose(q.cpu().numpy(), g["q"], atol=1e-4)
+    assert abs(float(ce0.mean()) - float(g["loss"])) < 1e-3
+    gs = grads.cpu()
+    np.testing.assert_allclose(gs[:, :, ::16].numpy(), g["grads_sub"], atol=5e-3 * np.abs(g["grads_sub"]).max())
+    sal = gs.abs().sum(-1).numpy()
+    np.testing.assert_allclose(sal, g["saliency_l1"], rtol=5e-3, atol=1e-6)
+    for b in range(B):                                                  # the position the reference would attack first
+        sep = int((batch["text_ids"][b] == 102).nonzero()[0])
+        assert int(np.argmax(sal[b, 1:sep])) + 1 == int(g["cand_pos"][b])
+    # candidates: the fixture's sentences through split_forward + the reference's scoring rule (incl. the view quirk)
+    Bc = B * n_cand
+    pc = eng.bufs(Bc, "txtatk_cand")
+    own = torch.arange(B, device=DEV).repeat_interleave(n_cand)
+    pc.text_ids = torch.from_numpy(g["cand_ids"]).to(DEV)
+    pc.text_mask = batch["text_masks"].index_select(0, own)
+    torch.index_select(op.view(B, -1), 0, own, out=pc.patchesT.view(Bc, -1))
+    pc.k.copy_(pb.k.index_select(0, own))
+    cec = att.split_forward(m, pc, Bc).cpu().tolist()
+    picks = att.select(ce0.cpu().tolist(), cec, own.cpu().tolist(), Bc, B)
+    np.testing.assert_allclose(np.array([l for l, _ in picks]), g["cand_loss"], atol=1e-3)
+    assert [j for _, j in picks] == g["cand_best_idx"].tolist()
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# f1: the Adam part of the fused AdamW against torch.optim.AdamW (weight_decay = 0, where HF's AdamW and torch's
+# coincide).  HF 4.2.1's decay ordering (after the update) is restated from its source: parity unpinned, see DESIGN 5.
+# -------------------------------------------------------------------------------------------------------------------
+
+def test_fused_adamw_adam_part_matches_torch():
+    ocfg = O.default_config(num_layers=1, num_negative=1024, per_gpu_batchsize=2, adv_steps_img=1)
+    m, p = make_module(ocfg, 3, "f32", max_steps=100, warmup_steps=0, weight_decay=0.0, learning_rate=1e-3, lr_mult=1.0,
+                       decay_power=1, end_lr=0.0)
+    (opt,), (sch,) = m.configure_optimizers()
+    eng = m.engine
+    ref = eng.q32.clone().requires_grad_(True)
+    topt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    for it in range(4):
+        gr = (torch.randn(eng.g32.numel(), generator=gen) * 0.01).to(DEV)
+        eng.g32.copy_(gr)
+        ref.grad = gr.clone()
+        lr = opt.param_groups[0]["lr"]
+        for gp in topt.param_groups:
+            gp["lr"] = lr
+        opt.step()
+        topt.step()
+        sch["scheduler"].step()
+        assert float((eng.q32 - ref.detach()).abs().max()) < 2e-7 + 1e-6 * lr, it
