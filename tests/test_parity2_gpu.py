@@ -101,7 +101,9 @@ def run_two_step(g, dtype, tol, sabotage=False):
         worst = 0.0
         for name, dg in zip(g["ema_names"], g[f"s{s}_ema_digest"]):
             mine = digest(sd[str(name)])
-            np.testing.assert_allclose(mine, dg, rtol=2e-5, atol=1e-5, err_msg=f"step {s} {name}")   # EMA runs on fp32 masters
+            # the EMA runs on the fp32 masters: exact in step 0; in step 1 q carries the nudge by THIS path's gradients
+            np.testing.assert_allclose(mine, dg, rtol=2e-5 if s == 0 else tol["ema_rtol_s1"], atol=1e-5 if s == 0 else tol["ema_atol_s1"],
+                                       err_msg=f"step {s} {name}")
             worst = max(worst, float(np.abs(mine[3:] - dg[3:]).max()))
         err[f"s{s}_ema_head_abs"] = worst
         np.testing.assert_allclose(sd["k_transformer.blocks.0.attn.qkv.weight"][:8, :64].cpu().numpy(), g[f"s{s}_k_qkv0_w"], atol=1e-6)
@@ -126,10 +128,10 @@ def run_two_step(g, dtype, tol, sabotage=False):
     return err
 
 
-TOL_F32 = dict(cls=1e-4, loss=1e-3, k=1e-4, delta_log=1e-6, grad_norm=5e-3)
+TOL_F32 = dict(cls=1e-4, loss=1e-3, k=1e-4, delta_log=1e-6, grad_norm=5e-3, ema_rtol_s1=2e-5, ema_atol_s1=1e-5)
 # bf16 GEMM operands (8 significant bits), fp32 accumulate / residual stream / softmax / InfoNCE: logits are ~ +-40 at
 # T = 0.07 so a 2^-9 relative operand error moves the loss by O(0.1); k and cls are O(1) vectors.
-TOL_BF16 = dict(cls=4e-2, loss=0.6, k=2e-2, delta_log=2e-4, grad_norm=0.12)
+TOL_BF16 = dict(cls=3e-2, loss=0.25, k=4e-2, delta_log=2e-4, grad_norm=0.12, ema_rtol_s1=1e-3, ema_atol_s1=1e-3)
 
 
 @pytest.mark.parametrize("tag", ["L2_B4_ragged", "L12_B2"])
@@ -169,7 +171,7 @@ def test_bf16_12_layers_against_reference_golden(pgd_dtype):
     r = m.infer(dev_batch(batch))
     e_cls = float((r["cls_feats"].cpu() - torch.from_numpy(g["cls_feats"])).abs().max())
     e_txt = float((r["text_feats"].cpu() - torch.from_numpy(g["text_feats"])).abs().max())
-    assert e_cls < 4e-2 and e_txt < 0.15, (e_cls, e_txt)                      # features are O(1..4) after the final LayerNorm
+    assert e_cls < 2.5e-2 and e_txt < 0.06, (e_cls, e_txt)      # measured 5e-3 / 1.5e-2                      # features are O(1..4) after the final LayerNorm
     # --- delta: K = 3 steps of +-lr*eps-normalised ascent, eps-clamped: most pixels saturate at +-eps ---
     k = torch.from_numpy(g["pgd_k_input"]).to(DEV)
     att = PGDAttack_moco(dict(m.config))
@@ -185,8 +187,8 @@ def test_bf16_12_layers_against_reference_golden(pgd_dtype):
     l2_rel = float(np.abs(delta.flatten(1).norm(dim=1).numpy() - g["pgd_delta_K3_persample_l2"]).max() / g["pgd_delta_K3_persample_l2"].max())
     assert float(delta.abs().max()) <= eps + 1e-9
     # a sign flip of a saturated pixel costs 2*eps; bounds: >= 90 % of sampled pixels in the same saturation state
-    assert frac_same > (0.97 if pgd_dtype else 0.90), frac_same
-    assert mean_dd < (0.05 if pgd_dtype else 0.15) * eps and l2_rel < 0.03, (mean_dd, l2_rel)
+    assert frac_same > (0.999 if pgd_dtype else 0.95), frac_same        # measured 1.000 / 0.981
+    assert mean_dd < (1e-4 if pgd_dtype else 0.06) * eps and l2_rel < 1e-3, (mean_dd, l2_rel)   # measured 1.5e-6 / 1.7e-2
     # --- the full step ---
     m.zero_grad()
     m.queue_ptr = 0
@@ -194,10 +196,10 @@ def test_bf16_12_layers_against_reference_golden(pgd_dtype):
     m.shadow_momentum_encoder()
     loss = m.training_step(dev_batch(batch), 0)
     e_loss = abs(float(loss) - float(g["moco_loss"]))
-    assert e_loss < 0.6, e_loss
+    assert e_loss < 0.1, e_loss                                              # measured 2e-3 / 1.5e-2
     loss.backward()
     e_q = float((m.proj_queue[:, :B].cpu() - torch.from_numpy(g["queue_head_after"][:, :B])).abs().max())
-    assert e_q < 2e-2, e_q
+    assert e_q < 5e-3, e_q                                                   # measured 8e-4
     params = dict(m.named_parameters())
     worst, worst_name = 0.0, ""
     for nm, dg in zip(g["grad_names"], g["grad_digest"]):
@@ -207,10 +209,10 @@ def test_bf16_12_layers_against_reference_golden(pgd_dtype):
         rel = abs(mine[1] - dg[1]) / max(dg[1], 1e-6)
         if rel > worst:
             worst, worst_name = rel, str(nm)
-    assert worst < 0.15, (worst, worst_name)
+    assert worst < 0.05, (worst, worst_name)                                 # measured 1.3e-2 / 3.8e-3
     gq = params["transformer.blocks.0.attn.qkv.weight"].grad[:8, :64].cpu().numpy()
     cos = float((gq * g["grad_qkv0_w"]).sum() / (np.linalg.norm(gq) * np.linalg.norm(g["grad_qkv0_w"])))
-    assert cos > 0.98, cos
+    assert cos > 0.99, cos                                                   # measured 0.9979 / 0.99986
     record(name, cls=e_cls, text_feats=e_txt, delta_same_saturation_frac=frac_same, delta_max_abs_diff_over_eps=max_dd / eps,
            delta_mean_abs_diff_over_eps=mean_dd / eps, delta_l2_rel=l2_rel, loss=e_loss, key_queue=e_q,
            grad_norm_rel_worst=worst, grad_norm_rel_worst_name=worst_name, grad_qkv0_cosine=cos)
@@ -347,7 +349,10 @@ def test_fused_adamw_adam_part_matches_torch():
     topt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0)
     gen = torch.Generator(device="cpu").manual_seed(5)
     for it in range(4):
-        gr = (torch.randn(eng.g32.numel(), generator=gen) * 0.01).to(DEV)
+        # |g| >= 0.05: HF's AdamW adds eps to sqrt(v) BEFORE the bias correction (effective eps ~ 7e-8 at t = 1), torch adds
+        # it after; the two only coincide where |g| >> eps
+        gr = torch.randn(eng.g32.numel(), generator=gen) * 0.01
+        gr = (gr + 0.05 * torch.where(gr >= 0, 1.0, -1.0)).to(DEV)
         eng.g32.copy_(gr)
         ref.grad = gr.clone()
         lr = opt.param_groups[0]["lr"]
@@ -356,4 +361,4 @@ def test_fused_adamw_adam_part_matches_torch():
         opt.step()
         topt.step()
         sch["scheduler"].step()
-        assert float((eng.q32 - ref.detach()).abs().max()) < 2e-7 + 1e-6 * lr, it
+        assert float((eng.q32 - ref.detach()).abs().max()) < 5e-7, it
