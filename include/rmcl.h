@@ -197,8 +197,10 @@ int rmcl_layernorm_bwd(const void* dy, int dt_dy, const float* x, const float* m
 int64_t rmcl_attention_scratch_elems(int B, int H, int N);
 int rmcl_attention_fwd(const void* qkv, const int32_t* mask, void* out, void* probs, float* scores, int B, int N, int H,
                        int dtype, int exact, void* stream);
-int rmcl_attention_bwd(const void* qkv, const int32_t* mask, const void* probs, const void* dout, void* dqkv, float* scores,
-                       void* dscores, int B, int N, int H, int dtype, int exact, void* stream);
+/* `out`: the forward's output (same buffer rmcl_attention_fwd wrote) - with it the bf16 path runs ONE backward kernel
+ * (delta = rowsum(dO * O)); NULL selects the two-kernel form that recomputes delta from P and dP.                 */
+int rmcl_attention_bwd(const void* qkv, const int32_t* mask, const void* probs, const void* dout, const void* out, void* dqkv,
+                       float* scores, void* dscores, int B, int N, int H, int dtype, int exact, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,8 +10,8 @@ extern "C" void rmcl_set_error(const char* msg) { g_err = msg ? msg : ""; }
 
 int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* probs, float* scores, int B, int N, int H, int dt,
                             int exact, hipStream_t s);
-int rmcl_attention_bwd_impl(const void* qkv, const int* mask, const void* probs, const void* dout, void* dqkv, float* scores,
-                            void* dS, int B, int N, int H, int dt, int exact, hipStream_t s);
+int rmcl_attention_bwd_impl(const void* qkv, const int* mask, const void* probs, const void* dout, const void* out, void* dqkv,
+                            float* scores, void* dS, int B, int N, int H, int dt, int exact, hipStream_t s);
 
 // ---- optional in-stream timing of one GEMM class (bench.py roofline leg) ------------------------
 #include <vector>
@@ -104,9 +104,11 @@ int rmcl_dropout_mask_apply(float* x, int64_t n, uint32_t drop_seed, int layer, 
                             (hipStream_t)stream);
 }
 extern int g_st_reserve_cus;
+extern bool g_attn_fused_bwd;
 int rmcl_tune_set(int key, int value) {
   if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }
   if (key == 1) { g_st_reserve_cus = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }   // CUs left free by the activation GEMMs
+  if (key == 2) { g_attn_fused_bwd = value != 0; return 0; }                                    // 0: two-kernel attention backward
   rmcl_set_error("tune_set: unknown key");
   return -1;
 }
@@ -312,10 +314,10 @@ int rmcl_attention_fwd(const void* qkv, const int32_t* mask, void* out, void* pr
   RMCL_REQUIRE(qkv && mask && out && probs && scores, "attention_fwd: NULL argument");
   return rmcl_attention_fwd_impl(qkv, mask, out, probs, scores, B, N, H, dtype, exact, (hipStream_t)stream);
 }
-int rmcl_attention_bwd(const void* qkv, const int32_t* mask, const void* probs, const void* dout, void* dqkv, float* scores,
-                       void* dscores, int B, int N, int H, int dtype, int exact, void* stream) {
+int rmcl_attention_bwd(const void* qkv, const int32_t* mask, const void* probs, const void* dout, const void* out, void* dqkv,
+                       float* scores, void* dscores, int B, int N, int H, int dtype, int exact, void* stream) {
   RMCL_REQUIRE(qkv && mask && probs && dout && dqkv && scores && dscores, "attention_bwd: NULL argument");
-  return rmcl_attention_bwd_impl(qkv, mask, probs, dout, dqkv, scores, dscores, B, N, H, dtype, exact, (hipStream_t)stream);
+  return rmcl_attention_bwd_impl(qkv, mask, probs, dout, out, dqkv, scores, dscores, B, N, H, dtype, exact, (hipStream_t)stream);
 }
 
 }  // extern "C"

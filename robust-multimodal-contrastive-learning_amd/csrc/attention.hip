@@ -47,6 +47,15 @@ __device__ __forceinline__ bf16x8 frag_row_lds(const char* img, int row0, int s,
   return *reinterpret_cast<const bf16x8*>(img + row * 128 + chunk * 16);
 }
 
+// row fragment (A[row = lane&15][k = 32 s + 8 (lane>>4) ..]) out of a TRANSPOSED-read image (stage_rows<true>): the image's 32-byte
+// group swizzle applied to the 16-byte chunk index; 2-way bank conflict among the 16 rows (rows r, r+8 share a slot)
+__device__ __forceinline__ bf16x8 frag_row_ldsT(const char* img, int row0, int s, int lane) {
+  const int row = row0 + (lane & 15);
+  const int c = 4 * s + (lane >> 4);
+  const int cp = (((c >> 1) ^ ((row >> 1) & 3)) << 1) | (c & 1);
+  return *reinterpret_cast<const bf16x8*>(img + row * 128 + cp * 16);
+}
+
 __device__ __forceinline__ bf16x8 frag_row_global(const bf16_t* __restrict__ src, long ld, int row0, int N, int s, int lane) {
   const int row = min(row0 + (lane & 15), N - 1);
   return *reinterpret_cast<const bf16x8*>(src + (long)row * ld + 32 * s + 8 * (lane >> 4));
@@ -380,6 +389,157 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
   }
 }
 
+// ================================================================================== backward: ONE kernel (dQ, dK, dV)
+// One workgroup of NKT waves per (batch, head); wave w owns KEY tile w in phase 1 and QUERY tile w in phase 2.
+//   phase 0: Q, dO, K -> LDS (transposed-read images); K / V row fragments of the wave's key tile -> registers;
+//            delta[q] = sum_d dO[q][d] * O[q][d]  (= rowsum(P * dP); O is the forward's bf16 output) for query tile w
+//   phase 1: for every query tile: S, dP on the MFMA (once - the two-kernel form computed them twice), P and dS in
+//            registers, dV += P^T dO, dK += dS^T Q (16x16x16 MFMAs, accumulators stay in the wave), and the dS^T tile
+//            -> LDS image [key][q] (bf16, written as the transposed-read layout of the 64-column sub-image q / 64)
+//   phase 2: dQ^T = K^T dS^T for the wave's query tile: both operands by ds_read_b64_tr_b16, same permuted k order.
+// Nothing but dqkv is written to HBM; qkv / dO / O are read once per workgroup (+ L1-resident fragment re-reads).
+template <int NKT>
+__global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
+                                                                 const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                                 const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];
+  constexpr int NKP = NKT * 16, NW = NKT, NSUB = (NKP + 63) / 64;
+  char* Qtr = sm;
+  char* Dtr = sm + NKP * 128;
+  char* Ktr = sm + 2 * NKP * 128;
+  char* dSimg = sm + 3 * NKP * 128;                             // NSUB sub-images of [NKP keys][64 q] bf16 (128-B rows)
+  float* Ls = reinterpret_cast<float*>(sm + (3 + NSUB) * NKP * 128);   // lse per query, log2 domain (+inf for pad rows)
+  float* Ds = Ls + NKP;                                         // delta per query
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * 64;
+  const long ld = 3 * D;
+  const bf16_t* base = qkv + (long)b * N * ld + h * 64;
+  const bf16_t* dob = dout + (long)b * N * D + h * 64;
+  const bf16_t* ob = out + (long)b * N * D + h * 64;
+  stage_rows<true, NW>(Qtr, base, ld, N, NKP, wave, lane);
+  stage_rows<true, NW>(Dtr, dob, D, N, NKP, wave, lane);
+  stage_rows<true, NW>(Ktr, base + D, ld, N, NKP, wave, lane);
+  for (int j = t; j < NKP; j += NW * 64) Ls[j] = j < N ? lse[((long)blockIdx.x) * NKP + j] * LOG2E : INFINITY;
+  {                                                            // delta of query tile `wave`: lane = (query lane&15, 16 head dims 16g..)
+    const int q = wave * 16 + (lane & 15);
+    float dl = 0.f;
+    if (q < N) {
+      const uint4* pd = reinterpret_cast<const uint4*>(dob + (long)q * D + 16 * g);
+      const uint4* po = reinterpret_cast<const uint4*>(ob + (long)q * D + 16 * g);
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const uint4 a = pd[v], c = po[v];
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dl = fmaf(__uint_as_float(aw[e] << 16), __uint_as_float(cw[e] << 16), dl);
+          dl = fmaf(__uint_as_float(aw[e] & 0xffff0000u), __uint_as_float(cw[e] & 0xffff0000u), dl);
+        }
+      }
+    }
+    dl = group_sum(dl);
+    if (g == 0) Ds[q] = dl;
+  }
+  // this wave's key tile: K / V row fragments and the key mask stay in registers
+  bf16x8 kf[2], vf[2];
+  const int* mrow = mask + (long)b * N;
+  const int key = wave * 16 + (lane & 15);
+  const float mbk = (key < N && mrow[key] != 0) ? 0.f : -INFINITY;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    kf[s] = frag_row_global(base + D, ld, wave * 16, N, s, lane);
+    vf[s] = frag_row_global(base + 2 * D, ld, wave * 16, N, s, lane);
+  }
+  f32x4 dK[4], dV[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  __syncthreads();
+
+  // ---- phase 1 -------------------------------------------------------------------------------------------------------
+  for (int qt = 0; qt < NKT; ++qt) {
+    // Q / dO row fragments out of the SAME LDS images the transposed reads use (a per-iteration global load would put an
+    // L2 round trip on every one of the 12 short iterations)
+    bf16x8 qf[2], df[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      qf[s] = frag_row_ldsT(Qtr, qt * 16, s, lane);
+      df[s] = frag_row_ldsT(Dtr, qt * 16, s, lane);
+    }
+    const float4 L4 = *reinterpret_cast<const float4*>(Ls + qt * 16 + 4 * g);
+    const float4 D4 = *reinterpret_cast<const float4*>(Ds + qt * 16 + 4 * g);
+    const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+    s16x4 dot[4], qtr[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      dot[dt] = frag_tr16_lds(Dtr, qt * 16, dt, lane);
+      qtr[dt] = frag_tr16_lds(Qtr, qt * 16, dt, lane);
+    }
+    f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], kf[s], S, 0, 0, 0);        // S[q = 4g+r][key = lane&15]
+      dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[s], vf[s], dP, 0, 0, 0);
+    }
+    f32x4 P, dS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      P[r] = __builtin_amdgcn_exp2f(fmaf(S[r], SCALE_L2, mbk - Lr[r]));
+      dS[r] = P[r] * (dP[r] - Dr[r]) * SCALE;
+    }
+    const s16x4 pa = pack4(P), sa = pack4(dS);
+    {                                                          // dS^T tile -> image [key][q]: 4 adjacent q of key lane&15, 8 bytes
+      const int row = wave * 16 + (lane & 15);
+      char* img = dSimg + (qt >> 2) * (NKP * 128);
+      *reinterpret_cast<s16x4*>(img + row * 128 + (((qt & 3) ^ ((row >> 1) & 3)) * 32) + g * 8) = sa;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {                           // swapped operands: dV^T[d = 4g+r][key = lane&15]
+      dV[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dot[dt], pa, dV[dt], 0, 0, 0);   // += dO^T P
+      dK[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtr[dt], sa, dK[dt], 0, 0, 0);   // += Q^T dS
+    }
+  }
+  if (key < N) {
+    bf16_t* o = dqkv + ((long)b * N + key) * ld + h * 64 + 4 * g;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 pk, pv;
+      pk.x = (uint32_t)f2bf(dK[dt][0]) | ((uint32_t)f2bf(dK[dt][1]) << 16);
+      pk.y = (uint32_t)f2bf(dK[dt][2]) | ((uint32_t)f2bf(dK[dt][3]) << 16);
+      pv.x = (uint32_t)f2bf(dV[dt][0]) | ((uint32_t)f2bf(dV[dt][1]) << 16);
+      pv.y = (uint32_t)f2bf(dV[dt][2]) | ((uint32_t)f2bf(dV[dt][3]) << 16);
+      *reinterpret_cast<uint2*>(o + D + 16 * dt) = pk;
+      *reinterpret_cast<uint2*>(o + 2 * D + 16 * dt) = pv;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for query tile `wave` ------------------------------------
+  {
+    const int qt = wave;
+    const char* img = dSimg + (qt >> 2) * (NKP * 128);
+    f32x4 dQ[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+      const bf16x8 sb = frag_tr32_lds(img, 32 * u, qt & 3, lane);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dQ[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr32_lds(Ktr, 32 * u, dt, lane), sb, dQ[dt], 0, 0, 0);
+    }
+    const int q_lane = qt * 16 + (lane & 15);
+    if (q_lane < N) {
+      bf16_t* o = dqkv + ((long)b * N + q_lane) * ld + h * 64 + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(dQ[dt][0]) | ((uint32_t)f2bf(dQ[dt][1]) << 16);
+        pk.y = (uint32_t)f2bf(dQ[dt][2]) | ((uint32_t)f2bf(dQ[dt][3]) << 16);
+        *reinterpret_cast<uint2*>(o + 16 * dt) = pk;
+      }
+    }
+  }
+}
+
 // ================================================================================== launchers
 static inline int nkt_for(int N) { return N <= 64 ? 4 : N <= 128 ? 8 : N <= 192 ? 12 : 16; }
 
@@ -392,6 +552,18 @@ template <int NKT> static int launch_fwd(const bf16_t* qkv, const int* mask, bf1
   RMCL_CHECK_LAUNCH();
   return 0;
 }
+bool g_attn_fused_bwd = true;        // rmcl_tune_set key 2: 0 selects the two-kernel backward (A/B and parity tests)
+
+template <int NKT> static int launch_bwd_fused(const bf16_t* qkv, const int* mask, const bf16_t* dout, const bf16_t* out, const float* lse,
+                                               bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
+  constexpr int NKP = NKT * 16, NSUB = (NKP + 63) / 64;
+  const size_t lds = (size_t)(3 + NSUB) * NKP * 128 + 2 * NKP * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RMCL_LAUNCH(attn_bwd_fused_kernel<NKT>, dim3(B * H), dim3(NKT * 64), lds, s, qkv, mask, dout, out, lse, dqkv, N, H);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int NKT> static int launch_bwd(const bf16_t* qkv, const int* mask, const bf16_t* dout, const float* lse, float* delta,
                                          bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
   const size_t lds1 = (size_t)3 * NKT * 16 * 128 + NKT * 16 * 4, lds2 = (size_t)2 * NKT * 16 * 128 + 2 * NKT * 16 * 4;
@@ -417,12 +589,20 @@ int rmcl_attn_fused_fwd(const void* qkv, const int* mask, void* out, float* lse,
   }
 }
 
-int rmcl_attn_fused_bwd(const void* qkv, const int* mask, const void* dout, const float* lse, float* delta, void* dqkv, int B,
-                        int N, int H, hipStream_t s) {
+int rmcl_attn_fused_bwd(const void* qkv, const int* mask, const void* dout, const void* out, const float* lse, float* delta, void* dqkv,
+                        int B, int N, int H, hipStream_t s) {
   RMCL_REQUIRE(N >= 1 && N <= 256, "fused attention: N must be <= 256");
   const bf16_t* q = (const bf16_t*)qkv;
   const bf16_t* d = (const bf16_t*)dout;
   bf16_t* o = (bf16_t*)dqkv;
+  if (out && g_attn_fused_bwd && N <= 192) {                   // one kernel; needs the forward's output O for delta
+    const bf16_t* ao = (const bf16_t*)out;
+    switch (nkt_for(N)) {
+      case 4: return launch_bwd_fused<4>(q, mask, d, ao, lse, o, B, N, H, s);
+      case 8: return launch_bwd_fused<8>(q, mask, d, ao, lse, o, B, N, H, s);
+      default: return launch_bwd_fused<12>(q, mask, d, ao, lse, o, B, N, H, s);
+    }
+  }
   switch (nkt_for(N)) {
     case 4: return launch_bwd<4>(q, mask, d, lse, delta, o, B, N, H, s);
     case 8: return launch_bwd<8>(q, mask, d, lse, delta, o, B, N, H, s);

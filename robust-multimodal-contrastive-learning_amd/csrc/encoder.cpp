@@ -31,8 +31,8 @@ inline int ldp_of(int N) { return (N + 7) / 8 * 8; }
 
 struct LayerStash {
   float *x_in, *x_mid, *mean1, *rstd1, *mean2, *rstd2;
-  void *qkv, *probs, *u;           // DATA+
-  void *ao, *ln1, *ln2, *h;        // FULL (workspace-aliased otherwise)
+  void *qkv, *probs, *u, *ao;      // DATA+ (ao: the attention output, for the one-kernel attention backward's delta)
+  void *ln1, *ln2, *h;             // FULL (workspace-aliased otherwise)
 };
 
 struct Stash {
@@ -68,8 +68,8 @@ size_t carve_stash(const rmcl_dims& d, int mode, void* base, Stash* st) {
     ls.qkv = b.take_bytes(M * 3 * D * e);
     ls.probs = b.take_bytes((size_t)d.B * d.H * N * ldp_of((int)N) * e);
     ls.u = b.take_bytes(M * d.mlp * e);
+    ls.ao = b.take_bytes(M * D * e);
     if (mode == RMCL_MODE_FULL) {
-      ls.ao = b.take_bytes(M * D * e);
       ls.ln1 = b.take_bytes(M * D * e);
       ls.ln2 = b.take_bytes(M * D * e);
       ls.h = b.take_bytes(M * d.mlp * e);
@@ -253,11 +253,12 @@ int rmcl_attention_fwd_impl(const void* qkv, const int* mask, void* out, void* p
   return 0;
 }
 
-int rmcl_attention_bwd_impl(const void* qkv, const int* mask, const void* probs, const void* dout, void* dqkv, float* scores,
-                            void* dS, int B, int N, int H, int dt, int exact, hipStream_t s) {
-  // bf16 fast path: probs = saved log-sum-exp, scores = scratch for delta (both fp32 [B,H,NKP])
+int rmcl_attention_bwd_impl(const void* qkv, const int* mask, const void* probs, const void* dout, const void* out, void* dqkv,
+                            float* scores, void* dS, int B, int N, int H, int dt, int exact, hipStream_t s) {
+  // bf16 fast path: probs = saved log-sum-exp, scores = scratch for delta (both fp32 [B,H,NKP]); with the forward's output
+  // `out` (stashed in DATA and FULL mode) ONE kernel produces dQ, dK and dV
   if (dt == RMCL_BF16 && !exact && N <= 256)
-    return rmcl_attn_fused_bwd(qkv, mask, dout, (const float*)probs, scores, dqkv, B, N, H, s);
+    return rmcl_attn_fused_bwd(qkv, mask, dout, out, (const float*)probs, scores, dqkv, B, N, H, s);
   const int D = H * 64, ldp = ldp_of(N);
   const size_t e = esz(dt);
   const long sQ1 = (long)N * 3 * D, sP1 = (long)H * N * ldp, sP2 = (long)N * ldp;
@@ -374,7 +375,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     void* ln2 = full ? ls.ln2 : w.ln;
     void* qkv = keep ? ls.qkv : w.qkv;
     void* probs = keep ? ls.probs : w.probs;
-    void* ao = full ? ls.ao : w.ao;
+    void* ao = keep ? ls.ao : w.ao;
     void* h = full ? ls.h : w.h;
     void* u = keep ? ls.u : nullptr;
 
@@ -500,7 +501,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
     }
     if (use_side && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 2), 0));           // dqkv buffer free again
-    RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, co_mask, ls.probs, w.dao, dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
+    RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, co_mask, ls.probs, w.dao, ls.ao, dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
     if (full) {
       if (use_side) { HIP_TRY(hipEventRecord(EV(0, 2 * l + 1), s)); HIP_TRY(hipStreamWaitEvent(cs.s, EV(0, 2 * l + 1), 0)); }
       RMCL_TRY(gemm_dw(cs, dxT, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));

@@ -27,8 +27,8 @@ int rmcl_softmax_fwd(const float* S, long lds, const int* mask, void* P, long ld
 int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* dS, long ldds, int dt, int Z, int N,
                      float scale, hipStream_t s);
 int rmcl_attn_fused_fwd(const void* qkv, const int* mask, void* out, float* lse, int B, int N, int H, hipStream_t s);
-int rmcl_attn_fused_bwd(const void* qkv, const int* mask, const void* dout, const float* lse, float* delta, void* dqkv, int B,
-                        int N, int H, hipStream_t s);
+int rmcl_attn_fused_bwd(const void* qkv, const int* mask, const void* dout, const void* out, const float* lse, float* delta, void* dqkv,
+                        int B, int N, int H, hipStream_t s);
 int rmcl_colsum(const void* X, long ld, int dt, float* out, int M, int N, hipStream_t s);
 
 int rmcl_text_embed_fwd(const long* ids, const float* word, const float* pos, const float* btype0, const float* g,

@@ -124,10 +124,41 @@ def test_attention_fwd_bwd(dt, exact, BN):
     dS = torch.empty(ne, dtype=tdt(dt), device=DEV)
     dqkv = torch.empty(B * N, 3 * D, dtype=tdt(dt), device=DEV)
     check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(out), P(probs), P(scores), B, N, H, dt, exact, stream()))
-    check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), P(dqkv), P(scores), P(dS), B, N, H, dt, exact, stream()))
     tol = 3e-5 if dt == L.F32 else 2e-2
     assert rel_err(out, o_ref) < tol
-    assert rel_err(dqkv, x.grad) < tol
+    # out=None: two-kernel backward (delta from P and dP); out given: ONE kernel (delta = rowsum(dO * O); N <= 192)
+    for with_out in (False, True):
+        dqkv.fill_(float("nan"))
+        check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), P(out) if with_out else None, P(dqkv), P(scores), P(dS),
+                                     B, N, H, dt, exact, stream()))
+        assert rel_err(dqkv, x.grad) < tol, with_out
+
+
+def test_attention_bwd_one_kernel_full_batch():
+    """B = 64 (768 workgroups of 12 waves, 145.5 KiB LDS each): the one-kernel backward against the two-kernel form."""
+    B, N, H, D = 64, 185, 12, 768
+    dt = L.BF16
+    qkv = rnd(B * N, 3 * D, seed=3).to(torch.bfloat16)
+    mask = torch.ones(B, N, dtype=torch.int32)
+    g = torch.Generator().manual_seed(4)
+    for b in range(B):
+        mask[b, int(torch.randint(8, 40, (1,), generator=g)):40] = 0     # ragged text, all image tokens valid
+    mask = mask.to(DEV)
+    dout = rnd(B * N, D, seed=5).to(torch.bfloat16)
+    ne = lib.rmcl_attention_scratch_elems(B, H, N)
+    out = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+    probs = torch.empty(ne, dtype=torch.bfloat16, device=DEV)
+    scores = torch.empty(ne, dtype=torch.float32, device=DEV)
+    dS = torch.empty(ne, dtype=torch.bfloat16, device=DEV)
+    check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(out), P(probs), P(scores), B, N, H, dt, 0, stream()))
+    res = []
+    for with_out in (False, True):
+        dqkv = torch.full((B * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), P(out) if with_out else None, P(dqkv), P(scores), P(dS),
+                                     B, N, H, dt, 0, stream()))
+        res.append(dqkv.float())
+    assert torch.isfinite(res[1]).all()
+    assert rel_err(res[1], res[0]) < 1e-2
 
 
 # --------------------------------------------------------------------------------------- InfoNCE

@@ -359,7 +359,7 @@ def test_overlapped_gradient_sync_is_exact_on_one_rank():
             m.shadow_momentum_encoder()
             loss = m.training_step(batch, 0)
             loss.backward()
-            assert (getattr(m, "_grad_sync", None) is not None) == sync
+            assert (m.step_sync.handle is not None) == sync           # single closure -> the overlapped per-layer path
             opt.step()
             torch.cuda.synchronize()
             outs.append((m.engine.g32.clone(), m.engine.q32.clone()))
