@@ -50,6 +50,8 @@ struct Work {
   float *dx, *dln, *dxn_full, *de;
   void *dxT, *du, *dqkv, *dao, *dS, *dpe;
   void *dxT2, *du2, *dqkv2;   // second copies: weight-gradient GEMMs read them on the side stream
+  void* dxT3;         // third dx copy (grouped weight gradients: one launch per layer reads both of the layer's dx copies)
+  float* ln_rep;      // LayerNorm dgamma/dbeta replica slots (2 * layers + 1), summed into the arena by the grouped kernel
   float* slab;        // split-K partial slabs of the weight-gradient GEMMs
 };
 
@@ -121,6 +123,8 @@ size_t carve_work(const rmcl_dims& d, void* base, Work* w) {
   k.dxT2 = b.take_bytes(M * D * e);
   k.du2 = b.take_bytes(M * d.mlp * e);
   k.dqkv2 = b.take_bytes(M * 3 * D * e);
+  k.dxT3 = b.take_bytes(M * D * e);
+  k.ln_rep = b.take<float>((size_t)(2 * d.layers + 1) * RMCL_LN_REP_FLOATS);
   if (w) *w = k;
   return b.off;
 }
@@ -216,6 +220,8 @@ int ensure_events() {
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { rmcl_set_error(hipGetErrorString(_e)); return (int)_e; } } while (0)
 
 }  // namespace
+
+bool g_dw_grouped = true;            // rmcl_tune_set key 3: 0 selects the per-GEMM weight-gradient path (A/B and parity tests)
 
 extern "C" int rmcl_set_side_stream(void* stream) { g_side = (hipStream_t)stream; return 0; }
 
@@ -447,18 +453,28 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   const uint32_t dth = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
   const float dinv = 1.0f / (1.0f - drop_p);
   const bool lpm = dt != RMCL_F32 || dth != 0;      // a (masked) copy of dx in the GEMM operand type is needed
+  // GROUPED weight gradients (bf16 fast path at the step's shapes): ONE launch per layer computes the four dW, the four bias
+  // gradients and finishes the layer's LayerNorm dgamma/dbeta (gemm_dw_group_kernel); otherwise four split-K GEMMs + slab
+  // reduces + column sums per layer.
+  const int Lr = d->layers;
+  const bool grouped = full && dt == RMCL_BF16 && !d->exact && M % 64 == 0 && M >= 256 && D % 768 == 0 && mlp % 768 == 0 &&
+                       2 * Lr + 1 <= 64 && rmcl_gemm_fast_get_cfg() != 2 && g_dw_grouped;
   const bool use_side = full && lpm && g_side != nullptr;
   if (use_side || full) RMCL_TRY(ensure_events());
-  void* T[2] = {lpm ? w.dxT : nullptr, lpm ? (use_side ? w.dxT2 : w.dxT) : nullptr};
-  void* DU[2] = {w.du, use_side ? w.du2 : w.du};
-  void* DQ[2] = {w.dqkv, use_side ? w.dqkv2 : w.dqkv};
+  // copies of dx in the operand type, written by every LN backward.  Legacy path: ping-pong T[0]/T[1] (with a side stream the
+  // weight gradients of layer l read the copy the chain no longer writes).  Grouped path: rotation over three copies - layer l
+  // reads T[ia] (fc2) and T[ib] (proj) in its one weight-gradient launch while LN backward 1 already writes T[ic] for layer l-1.
+  void* T[3] = {lpm ? w.dxT : nullptr, lpm ? ((use_side || grouped) ? w.dxT2 : w.dxT) : nullptr, lpm ? w.dxT3 : nullptr};
+  void* DU[2] = {w.du, (use_side || grouped) ? w.du2 : w.du};
+  void* DQ[2] = {w.dqkv, (use_side || grouped) ? w.dqkv2 : w.dqkv};
   Ctx cs{c.d, c.P32, c.Plp, c.lay, use_side ? g_side : c.s, c.dt};
-  auto EV = [&](int kind, int l) { return g_ev[(kind * 32 + (l & 31)) & 127]; };   // kind 0: fork, 1: done1, 2: done2
+  auto EV = [&](int kind, int l) { return g_ev[(kind * 32 + (l & 31)) & 127]; };   // kind 0: fork, 1: done1, 2: done2 / side done, 3: main done
+  auto rep_slot = [&](int idx) { return grouped ? w.ln_rep + (size_t)idx * RMCL_LN_REP_FLOATS : nullptr; };   // 0: final norm, 1+2l: ln2, 2+2l: ln1
+  if (grouped) HIP_TRY(hipMemsetAsync(w.ln_rep, 0, (size_t)(2 * Lr + 1) * RMCL_LN_REP_FLOATS * sizeof(float), s));
   int cur = 0;
   RMCL_TRY(rmcl_ln_bwd_lp(dy, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), w.dx, D, 0,
                           full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, T[0], dt,
-                          rmcl_site_seed(drop_seed, d->layers - 1, DROP_SITE_FC2), dth, dinv, s));
-  const int Lr = d->layers;
+                          rmcl_site_seed(drop_seed, d->layers - 1, DROP_SITE_FC2), dth, dinv, rep_slot(0), s));
   // gradient w.r.t. the LayerNorm outputs (dX GEMM -> LN backward): in the operand dtype, like du / dqkv / dao (bf16 mode
   // halves the 36 MB write + read per LayerNorm); fp32 mode is unchanged
   const int dln_dt = lpm ? dt : RMCL_F32;
@@ -466,16 +482,17 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     const LayerStash& ls = st.layer[l];
     void* du = DU[l & 1];
     void* dqkv = DQ[l & 1];
+    const int ia = cur, ib = grouped ? (cur + 1) % 3 : cur ^ 1, ic = grouped ? (cur + 2) % 3 : cur;
     // ---- MLP ----
-    const void* dxT = lpm ? T[cur] : (const void*)w.dx;
-    if (use_side && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(1, l + 2), 0));          // du buffer free again
+    const void* dxT = lpm ? T[ia] : (const void*)w.dx;
+    if (use_side && !grouped && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(1, l + 2), 0));   // du buffer free again
     {
       GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.fc2_w)), du, M, mlp, D, D, mlp, mlp);       // du = (dx W2) * gelu'(u)
       g.epi = EPI_DGELU; g.aux = ls.u; g.ld_aux = mlp; g.tag = GEMM_TAG_DX;
       if (dth) { g.epi |= EPI_DROP_BWD; g.drop_seed = rmcl_site_seed(drop_seed, l, DROP_SITE_HIDDEN); g.drop_thresh = dth; g.drop_inv_keep = dinv; }
       RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
     }
-    if (full) {
+    if (full && !grouped) {
       if (use_side) { HIP_TRY(hipEventRecord(EV(0, 2 * l), s)); HIP_TRY(hipStreamWaitEvent(cs.s, EV(0, 2 * l), 0)); }
       RMCL_TRY(gemm_dw(cs, dxT, D, ls.h, mlp, Gp(c.L(l, y.fc2_w)), D, mlp, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.fc2_b)), M, D, cs.s));
@@ -488,24 +505,24 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, dln_dt, 1, 0));
     }
-    if (use_side && l + 1 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 1), 0));           // T[cur^1] free again
+    if (use_side && l + 1 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 1), 0));           // T[ib] free again (grouped: layer l+1's whole
+                                                                                           // weight-gradient launch has finished)
     RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, dln_dt, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), w.dx, D, 1,
-                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, T[cur ^ 1], dt,
-                            rmcl_site_seed(drop_seed, l, DROP_SITE_PROJ), dth, dinv, s));
-    cur ^= 1;
+                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, T[ib], dt,
+                            rmcl_site_seed(drop_seed, l, DROP_SITE_PROJ), dth, dinv, rep_slot(1 + 2 * l), s));
     // ---- attention ----
-    dxT = lpm ? T[cur] : (const void*)w.dx;
+    const void* dxT_b = lpm ? T[ib] : (const void*)w.dx;
     {
-      GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);          // dao = dx Wproj
+      GemmArgs g = gemm_args(dxT_b, c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);        // dao = dx Wproj
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
     }
-    if (use_side && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 2), 0));           // dqkv buffer free again
+    if (use_side && !grouped && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 2), 0));   // dqkv buffer free again
     RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, co_mask, ls.probs, w.dao, ls.ao, dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
-    if (full) {
+    if (full && !grouped) {
       if (use_side) { HIP_TRY(hipEventRecord(EV(0, 2 * l + 1), s)); HIP_TRY(hipStreamWaitEvent(cs.s, EV(0, 2 * l + 1), 0)); }
-      RMCL_TRY(gemm_dw(cs, dxT, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
-      RMCL_TRY(rmcl_colsum(dxT, D, dt, Gp(c.L(l, y.proj_b)), M, D, cs.s));
+      RMCL_TRY(gemm_dw(cs, dxT_b, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
+      RMCL_TRY(rmcl_colsum(dxT_b, D, dt, Gp(c.L(l, y.proj_b)), M, D, cs.s));
       RMCL_TRY(gemm_dw(cs, dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(dqkv, 3 * D, dt, Gp(c.L(l, y.qkv_b)), M, 3 * D, cs.s));
       if (use_side) HIP_TRY(hipEventRecord(EV(2, l), cs.s));
@@ -515,14 +532,38 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, dln_dt, 1, 0));
     }
-    if (use_side) HIP_TRY(hipStreamWaitEvent(s, EV(1, l), 0));                             // T[cur^1] free again
+    if (use_side && !grouped) HIP_TRY(hipStreamWaitEvent(s, EV(1, l), 0));                 // T[ic] free again
     RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, dln_dt, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
-                            full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, T[cur ^ 1], dt,
-                            rmcl_site_seed(drop_seed, l - 1, DROP_SITE_FC2), l > 0 ? dth : 0u, dinv, s));
-    cur ^= 1;
-    if (full) {                                                                            // layer l's gradients are complete after
-                                                                                           // this event (+ EV(2, l) on the side stream)
-      HIP_TRY(hipEventRecord(EV(3, l), s));
+                            full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, T[ic], dt,
+                            rmcl_site_seed(drop_seed, l - 1, DROP_SITE_FC2), l > 0 ? dth : 0u, dinv, rep_slot(2 + 2 * l), s));
+    cur = ic;
+    // EV(3, l): everything of layer l that runs on the main stream is enqueued (with the grouped launch on the SAME stream that
+    // includes the launch, recorded below)
+    if (full && (use_side || !grouped)) HIP_TRY(hipEventRecord(EV(3, l), s));
+    if (grouped) {
+      // everything the layer's weight gradients read is final: both dx copies, du, dqkv, the stash, the LN replicas
+      if (use_side) HIP_TRY(hipStreamWaitEvent(cs.s, EV(3, l), 0));
+      DwGroupArgs a{};
+      const void* As[4] = {dxT, du, dxT_b, dqkv};                                          // dY of fc2, fc1, proj, qkv
+      const void* Bs[4] = {ls.h, ls.ln2, ls.ao, ls.ln1};                                   // their inputs X
+      const int64_t wo[4] = {y.fc2_w, y.fc1_w, y.proj_w, y.qkv_w}, bo[4] = {y.fc2_b, y.fc1_b, y.proj_b, y.qkv_b};
+      const int nout[4] = {D, mlp, D, 3 * D}, kin[4] = {mlp, D, D, D};
+      a.tile_base[0] = 0;
+      for (int q = 0; q < 4; ++q) {
+        a.A[q] = (const unsigned short*)As[q]; a.B[q] = (const unsigned short*)Bs[q];
+        a.C[q] = Gp(c.L(l, wo[q])); a.bias[q] = Gp(c.L(l, bo[q]));
+        a.lda[q] = nout[q]; a.ldb[q] = kin[q]; a.ldc[q] = kin[q]; a.tiles_n[q] = kin[q] / 192;
+        a.tile_base[q + 1] = a.tile_base[q] + (nout[q] / 192) * (kin[q] / 192);
+      }
+      a.K = M;
+      a.rep = w.ln_rep; a.G = G; a.D = D;
+      a.nslots = 0;
+      auto add_slot = [&](int idx, int64_t gw, int64_t gb) { a.slot[a.nslots] = idx; a.g_gamma[a.nslots] = gw; a.g_beta[a.nslots] = gb; ++a.nslots; };
+      add_slot(1 + 2 * l, c.L(l, y.ln2_w), c.L(l, y.ln2_b));
+      add_slot(2 + 2 * l, c.L(l, y.ln1_w), c.L(l, y.ln1_b));
+      if (l == Lr - 1) add_slot(0, y.norm_w, y.norm_b);
+      RMCL_TRY(rmcl_launch_dw_group(a, cs.s));
+      HIP_TRY(hipEventRecord(EV(use_side ? 2 : 3, l), cs.s));
     }
   }
   if (full) { g_grad_layers = Lr; g_grad_side = use_side; }

@@ -479,6 +479,158 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
   if (wm == 0) __builtin_amdgcn_s_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// All weight gradients of ONE encoder layer in ONE launch: dW_g[Nout, Kin] += dY_g^T X_g for the layer's four linear
+// layers (fc2, fc1, proj, qkv), the four bias gradients, and the finish of the layer's LayerNorm dgamma / dbeta replicas.
+// One workgroup per 192x192 output tile (4x16 + 16x4 + 4x4 + 12x4 = 192 tiles at D = 768), each streaming ALL tokens as
+// its K dimension ([K][M] x [K][N] form, both operands through ds_read_b64_tr_b16, one phase per k-tile) and adding its
+// tile into the gradient arena in the epilogue: no split-K slabs, no ordered-reduce kernel, no column-sum kernels
+// (round 1: 4 GEMM + 4 slab-reduce + 4 colsum launches per layer).  Bitwise reproducible for the weight matrices: a tile
+// is accumulated by one workgroup in k order.
+// Bias gradient = column sums of dY = the A operand: one extra MFMA per A fragment against a fragment of ones, only on the
+// k-tiles with kt % tiles_n == tn (every (row-tile, k-tile) pair is covered exactly once by the tiles_n tiles of that row
+// band, so the extra work is spread evenly) and only by one of the four waves that hold the same fragment; float atomics
+// (<= tiles_n addends per element).
+__global__ __launch_bounds__(512) void gemm_dw_group_kernel(DwGroupArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // ---- LayerNorm replica finish: workgroups 0 .. 3*nslots-1, 256 columns each --------------------------------------
+  if ((int)blockIdx.x < a.nslots * ((a.D + 255) / 256) && t < 256) {
+    const int per = (a.D + 255) / 256, si = blockIdx.x / per, c = (blockIdx.x % per) * 256 + t;
+    if (c < a.D) {
+      const float* base = a.rep + (long)a.slot[si] * (32 * 2 * 1024);
+      float sg = 0.f, sb = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) { sg += base[r * 2048 + c]; sb += base[r * 2048 + 1024 + c]; }
+      a.G[a.g_gamma[si] + c] += sg;
+      a.G[a.g_beta[si] + c] += sb;
+    }
+  }
+  // ---- tile of this workgroup: XCD-aware slot -> tile id (slots of one XCD are consecutive tile ids) ------------------
+  const int ntiles = a.tile_base[4];
+  const int id = st_tile_id(blockIdx.x, 0, gridDim.x, ntiles);
+  if (id < 0) return;
+  int gi = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q) gi += (id >= a.tile_base[q]) ? 1 : 0;
+  const int local = id - a.tile_base[gi], tn_cnt = a.tiles_n[gi];
+  // inside a GEMM: bands of 4 column tiles x all row tiles, like st_tile_setup
+  int tr, tc;
+  {
+    const int tm_cnt = (a.tile_base[gi + 1] - a.tile_base[gi]) / tn_cnt;
+    const int band = local / (tm_cnt * 4), rem = local - band * (tm_cnt * 4);
+    tr = rem >> 2;
+    tc = band * 4 + (rem & 3);
+  }
+  const int m0 = tr * ST_T, n0 = tc * ST_T;
+  GemmArgs g{};
+  g.C = a.C[gi]; g.ldc = a.ldc[gi]; g.M = 1 << 30; g.N = 1 << 30; g.alpha = 1.0f; g.epi = EPI_ACCUM; g.lda = a.lda[gi]; g.ldb = a.ldb[gi];
+
+  STCtx c;
+  c.A = a.A[gi];
+  c.B = a.B[gi];
+  c.wave = wave;
+  c.kstep_a = 64 * (long)g.lda;
+  c.kstep_b = 64 * (long)g.ldb;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int k = 8 * (lane >> 4) + q;
+    const int c8 = (wm * 96 + i * 16) / 4 + p;
+    c.aoffi[i] = k * 384 + (((c8 >> 1) ^ (st_gk(k) << 1)) * 16) + (c8 & 1) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int q = (lane & 15) >> 2, p = lane & 3;
+    const int k = 8 * (lane >> 4) + q;
+    const int c8 = (wn * 48 + j * 16) / 4 + p;
+    c.boffj[j] = k * 384 + (((c8 >> 1) ^ (st_gk(k) << 1)) * 16) + (c8 & 1) * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int lin = (wave * 3 + q) * 64 + lane;              // 16-byte chunk index in the [64][24] image of a [K][cols] operand
+    const int k = lin / 24, c16 = (lin - k * 24) ^ (st_gk(k) << 1);
+    c.oa[q] = (uint32_t)k * (uint32_t)g.lda + m0 + c16 * 8;
+    c.ob[q] = (uint32_t)k * (uint32_t)g.ldb + n0 + c16 * 8;
+  }
+  const int nk = a.K / 64;
+  st_stage_op(c.A, c.oa, 0, smem, wave);
+  st_stage_op(c.B, c.ob, 0, smem + ST_OP_BYTES, wave);
+  st_stage_op(c.A, c.oa, c.kstep_a, smem + ST_STAGE, wave);
+  st_stage_op(c.B, c.ob, c.kstep_b, smem + ST_STAGE + ST_OP_BYTES, wave);
+  st_wait_vm<6>();
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (wm == 1) __builtin_amdgcn_s_barrier();                 // skew: group 1 runs one barrier behind group 0
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x4 acc[6][3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  // bias: fragment index pair handled by this wave (the 4 wn waves of a row group hold identical A fragments)
+  const int bi0 = wn, bi1 = wn + 4;                            // i = bi0, and i = bi1 when < 6
+  bf16x8 ones;
+  {
+    union { bf16x8 v; uint32_t w[4]; } u;
+    u.w[0] = u.w[1] = u.w[2] = u.w[3] = 0x3f803f80u;
+    ones = u.v;
+  }
+  auto bias_step = [&](const char* cur) {                      // column sums of the A tile in LDS stage `cur` (both k-steps)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (i == bi0) accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, st_ld_b<false>(cur, c.aoffi[i], s), accb[0], 0, 0, 0);
+        if (i == bi1) accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, st_ld_b<false>(cur, c.aoffi[i], s), accb[1], 0, 0, 0);
+      }
+    }
+  };
+  int sc = 0, sn = 2, kt = 0;
+  int bias_in = tc % tn_cnt;                                   // k-tiles until this tile's next bias turn (kt % tn_cnt == tc)
+  for (; kt + 2 < nk; ++kt) {
+    if (a.bias[gi] && bias_in == 0) bias_step(smem + sc * ST_STAGE);
+    st_tile<0, false, false, 1>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, kt + 2);
+    bias_in = bias_in == 0 ? tn_cnt - 1 : bias_in - 1;
+    sc = sc == 2 ? 0 : sc + 1;
+    sn = sn == 2 ? 0 : sn + 1;
+  }
+  if (a.bias[gi] && bias_in == 0) bias_step(smem + sc * ST_STAGE);
+  st_tile<1, false, false, 1>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+  bias_in = bias_in == 0 ? tn_cnt - 1 : bias_in - 1;
+  sc = sc == 2 ? 0 : sc + 1;
+  if (a.bias[gi] && bias_in == 0) bias_step(smem + sc * ST_STAGE);
+  st_tile<2, false, false, 1>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+
+  STTile T{};
+  T.m0 = m0; T.n0 = n0; T.m_end = m0 + ST_T; T.zoff = 0;
+  st_epilogue_lds<ST_AUX_NONE, float, false>(acc, g, T, wm, wn, lane, wave, smem + sc * ST_STAGE + wm * (ST_STAGE / 2));
+  if (a.bias[gi] && lane < 16) {
+    float* bp = a.bias[gi] + m0 + wm * 96 + lane;
+    atomicAdd(bp + bi0 * 16, accb[0][0]);
+    if (bi1 < 6) atomicAdd(bp + bi1 * 16, accb[1][0]);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+}
+
+int rmcl_launch_dw_group(const DwGroupArgs& a, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    attr = true;
+  }
+  const int ntiles = a.tile_base[4];
+  RMCL_REQUIRE(a.K % 64 == 0 && a.K >= 256, "dw_group: tokens must be a multiple of 64 (>= 256)");
+  RMCL_REQUIRE(ntiles >= a.nslots * ((a.D + 255) / 256), "dw_group: too few tiles for the LayerNorm finish");
+  RMCL_LAUNCH(gemm_dw_group_kernel, dim3(ntiles), dim3(512), ST_LDS, s, a);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
 bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
   if (g.nb1 > 1 || g.nb2 > 1) return false;
   if (g.N % ST_T != 0 || g.K % 64 != 0 || g.K < 128) return false;

@@ -22,7 +22,24 @@ int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, 
                 int relu, hipStream_t s);
 int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
                    const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
-                   int relu, void* dx_copy, int copy_dt, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
+                   int relu, void* dx_copy, int copy_dt, uint32_t dseed, uint32_t dthresh, float dinv, float* rep_slot, hipStream_t s);
+#define RMCL_LN_REP_FLOATS (32 * 2 * 1024)      // one LayerNorm's dgamma/dbeta replica slot (norm_softmax.hip LN_REP x 2 x LN_REP_LD)
+
+// all weight gradients of one encoder layer in one launch (gemm_st.hip)
+struct DwGroupArgs {
+  const unsigned short* A[4];
+  const unsigned short* B[4];
+  float* C[4];
+  float* bias[4];
+  int lda[4], ldb[4], ldc[4], tiles_n[4], tile_base[5];
+  int K;
+  const float* rep;
+  float* G;
+  int nslots, D;
+  int slot[3];
+  long g_gamma[3], g_beta[3];
+};
+int rmcl_launch_dw_group(const DwGroupArgs& a, hipStream_t s);
 int rmcl_softmax_fwd(const float* S, long lds, const int* mask, void* P, long ldp, int dt, int Z, int N, int H, hipStream_t s);
 int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* dS, long ldds, int dt, int Z, int N,
                      float scale, hipStream_t s);

@@ -234,17 +234,20 @@ int rmcl_ln_bwd(const void* dy, long lddy, int dt_dy, const float* x, long ldx, 
                 const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
                 int relu, hipStream_t s) {
   return rmcl_ln_bwd_lp(dy, lddy, dt_dy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, dbeta, M, D, relu, nullptr, RMCL_BF16, 0, 0,
-                        1.0f, s);
+                        1.0f, nullptr, s);
 }
 
 int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ldx, const float* mean, const float* rstd,
                    const float* w, const float* b, float* dx, long lddx, int add, float* dgamma, float* dbeta, int M, int D,
-                   int relu, void* dx_copy, int copy_dt, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
+                   int relu, void* dx_copy, int copy_dt, uint32_t dseed, uint32_t dthresh, float dinv, float* rep_slot, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0 && D <= 256 * LN_MAXV && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0, "layernorm bwd: bad D/ld");
   if (M <= 0) return 0;
   const bool wg = dgamma != nullptr;
   dim3 grid(cdiv(M, 4 * LNB_ITERS(wg)));
-  float* rep = (wg && D <= LN_REP_LD && grid.x >= 4 * LN_REP) ? ln_rep_buffer() : nullptr;
+  // rep_slot: a caller-owned, pre-zeroed replica region (RMCL_LN_REP_FLOATS floats) - dgamma/dbeta then stay in the replicas
+  // and the CALLER sums them into the gradient arena later (the per-layer weight-gradient kernel does, off the critical path)
+  RMCL_REQUIRE(!rep_slot || (wg && D <= LN_REP_LD), "layernorm bwd: replica slot needs dgamma and D <= 1024");
+  float* rep = rep_slot ? rep_slot : ((wg && D <= LN_REP_LD && grid.x >= 4 * LN_REP) ? ln_rep_buffer() : nullptr);
 #define LN_BWD_LAUNCH(TG, WGv, RLv) \
   do { if (D <= 768) RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, 3>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
               dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv, rep); \
@@ -259,7 +262,7 @@ int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ld
   }
 #undef LN_BWD_LAUNCH
   RMCL_CHECK_LAUNCH();
-  if (rep) {
+  if (rep && !rep_slot) {
     RMCL_LAUNCH(ln_rep_finish_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, rep, dgamma, dbeta, D);
     RMCL_CHECK_LAUNCH();
   }

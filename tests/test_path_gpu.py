@@ -514,3 +514,47 @@ def test_short_training_run_reduces_loss_and_keeps_state_consistent():
     diff = float((e.q32[: e.layout.ema_end] - e.k32).abs().max())
     assert 0 < diff < 0.1                                                   # k trails q (m = 0.999), never equal after updates
     assert torch.equal(e.q_lp.float()[:1000], e.q32[:1000].to(torch.bfloat16).float())   # bf16 shadow refreshed by AdamW
+
+
+def test_grouped_weight_gradients_match_per_gemm_path_bs64():
+    """B = 64: the per-layer weight-gradient launch (four dW + four bias gradients + the LayerNorm dgamma/dbeta finish in ONE
+    kernel, no split-K slabs) against the per-GEMM path (split-K slabs + ordered reduce + column-sum kernels) on the same step.
+    Same bf16 operands, fp32 accumulation: only the summation order differs.  EVERY gradient of the arena is compared."""
+    from rmcl_amd._lib import lib
+    ocfg = O.default_config(num_layers=3, num_negative=1024, per_gpu_batchsize=64, adv_steps_img=1)
+    m, p = build_module(ocfg, 5, "bf16")
+    batch = dev_batch(O.synthetic_batch(ocfg, 64, 9, ragged_text=True))
+    grads, losses = [], []
+    try:
+        for grouped in (1, 0, 1):
+            lib.rmcl_tune_set(3, grouped)
+            m.zero_grad()
+            m.queue_ptr = 0
+            m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+            m.shadow_momentum_encoder()
+            loss = m.training_step(batch, 0)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads.append(m.engine.g32.clone())
+            losses.append(float(loss))
+    finally:
+        lib.rmcl_tune_set(3, 1)
+    assert losses[0] == losses[1] == losses[2]
+    params = dict(m.named_parameters())
+    lay = m.engine.layout
+    worst = 0.0
+    for name, prm in params.items():
+        if name.startswith("k_") or name.startswith("itm_score"):
+            continue
+        off = prm.grad.data_ptr() - m.engine.g32.data_ptr()
+        assert off % 4 == 0
+        a = grads[0][off // 4: off // 4 + prm.numel()]
+        b = grads[1][off // 4: off // 4 + prm.numel()]
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+        worst = max(worst, rel)
+        assert rel < 2e-4, (name, rel)
+    # the grouped launch accumulates every weight tile in one workgroup in k order: bitwise reproducible run to run
+    for l in range(3):
+        base = lay.layer0 + l * lay.layer_stride
+        for off, n in ((lay.qkv_w, 3 * 768 * 768), (lay.proj_w, 768 * 768), (lay.fc1_w, 3072 * 768), (lay.fc2_w, 3072 * 768)):
+            assert torch.equal(grads[0][base + off: base + off + n], grads[2][base + off: base + off + n]), (l, off)
