@@ -43,7 +43,24 @@ typedef struct rmcl_dims {
   int vocab;    /* 30522                                                             */
   int dtype;    /* RMCL_F32 or RMCL_BF16: operand type of the encoder GEMMs          */
   int exact;    /* 1: force the exact-f32 matrix-core GEMM (bf16 operands widened)   */
+  int Pp;       /* patches of the position table ((image_size/patch)^2 = 144); 0 = P. Differs from P for zero-padded
+                   batches of smaller images, where P = selected patches per sample (rmcl_ragged)                  */
 } rmcl_dims;
+
+/* Zero-padded batch of smaller images (VisionTransformer.visual_embed, vision_transformer.py:559-677): `patches` then
+ * holds the P SELECTED patches of every sample (rmcl_patch_select + rmcl_im2patch_sel; pad slots are zero rows, which the
+ * key mask drops like the reference's), and the position embedding of a sample is the G0 x G0 table resized to its (h, w).
+ * All arrays are device pointers owned by the caller.                                                              */
+typedef struct rmcl_ragged {
+  const int32_t* sel;      /* [B, sel_ld] flat patch index (row * gw + col) of every selected slot                   */
+  const int32_t* counts;   /* [B] valid slots per sample (slots >= counts[b] are pads)                              */
+  const int32_t* hw;       /* [B, 2] valid patch rows / columns of every sample (x_h, x_w)                           */
+  int sel_ld;              /* row pitch of sel                                                                        */
+  int gw;                  /* patch columns of the padded batch (Wmax / patch)                                       */
+  int G0;                  /* side of the position table (12)                                                         */
+  float* pos_tok;          /* scratch [B, P+1, D] f32: resized position rows (forward writes, every pass)            */
+  float* dpos_tok;         /* scratch [B, P+1, D] f32: their gradient (backward, mode FULL)                          */
+} rmcl_ragged;
 
 /* Element offsets into a parameter arena.  Names follow the reference state dict. */
 typedef struct rmcl_layout {
@@ -99,6 +116,16 @@ int64_t rmcl_heads_stash_bytes(const rmcl_dims* d);
  * GEMM view of PatchEmbed's Conv2d (vilt/modules/vision_transformer.py:397-409).                */
 int rmcl_im2patch_f32(const float* img, float* patches, int B, int C, int Hh, int Ww, int ps, int to_image, void* stream);
 
+/* Patch geometry of a zero-padded batch [B,C,Hh,Ww] (vision_transformer.py:563-567,605-651): per sample the selection list
+ * sel[b, :] (valid patches row-major, then the first non-valid patch repeated; pitch (Hh/ps)*(Ww/ps)), counts[b] valid
+ * patches and hw[b] = (x_h, x_w).  The caller picks n = min(max counts, max_image_len) and, for a sample with MORE than n
+ * valid patches, overwrites its row with a random subset like the reference's multinomial draw.                      */
+int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, int32_t* sel, int32_t* counts, int32_t* hw, void* stream);
+/* image <-> compact rows [B*n, C*ps*ps] of the selected patches (pad slots: zero rows / not written back; to_image=1 zeroes
+ * the image first).                                                                                                  */
+int rmcl_im2patch_sel(float* img, float* patches, const int32_t* sel, const int32_t* counts, int sel_ld, int B, int n, int C, int Hh,
+                      int Ww, int ps, int to_image, void* stream);
+
 /* out[dtype] = a + d1 + d2 (d1/d2 may be NULL): `img_init + img_delta` (attack/pgd_attack_vilt.py:144)
  * and the attacked view of objectives.py:176, fused with the cast to the GEMM operand type.      */
 int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* out, int dtype, int64_t n, void* stream);
@@ -109,11 +136,12 @@ int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* ou
  * in `dtype`; co_mask out [B,N] int32 (N = L+1+P); xn out [B*N, D] f32.
  * drop_p > 0 enables the reference's dropout sites (BertEmbeddings dropout, pos_drop, proj_drop, both Mlp
  * drops; vision_transformer.py:279-285,330-331,667) with a counter-based RNG: masks are a pure function
- * of (drop_seed, site, element), so the backward, given the same seed, regenerates them.            */
+ * of (drop_seed, site, element), so the backward, given the same seed, regenerates them.
+ * ragged: NULL for full-size images (dense fixed-order patches), else the selection of a zero-padded batch.  */
 int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
                          const int64_t* text_ids, const int64_t* text_mask, const void* patches,
                          int32_t* co_mask, void* stash, void* workspace, float* xn,
-                         uint32_t drop_seed, float drop_p, void* stream);
+                         uint32_t drop_seed, float drop_p, const rmcl_ragged* ragged, void* stream);
 
 /* Backward of the above.  dxn: gradient wrt xn, [B*N,D] f32, or [B,D] (row 0 of every sample)
  * when cls_only=1.  dpatches (optional) receives d loss/d patches [B*P,patch_k] in `dtype`
@@ -124,7 +152,8 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
                           const int64_t* text_ids, const void* patches, const int32_t* co_mask,
                           void* stash, void* workspace, const float* dxn, int cls_only,
-                          void* dpatches, float* dtext, float* grads32, uint32_t drop_seed, float drop_p, void* stream);
+                          void* dpatches, float* dtext, float* grads32, uint32_t drop_seed, float drop_p,
+                          const rmcl_ragged* ragged, void* stream);
 
 /* Pooler + MoCo head + L2 normalise (vilt/modules/heads.py:10-20,129-143; objectives.py:264-269).
  * pool32: arena that owns the pooler (always the query arena); head32: arena that owns the

@@ -181,7 +181,10 @@ def tensor_digest(t: torch.Tensor) -> np.ndarray:
     return torch.cat([torch.stack([f.sum(), f.norm(), f.abs().max()]), head]).numpy()
 
 
-def run_moco(tag, cfg, B, seed_w, seed_b, ragged):
+RAGGED_SIZES = [(384, 352), (320, 384), (384, 384), (224, 288)]     # zero-padded to 384 x 384; 132 / 120 / 144 / 63 valid patches
+
+
+def run_moco(tag, cfg, B, seed_w, seed_b, ragged, sizes=None):
     torch.manual_seed(1234)
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -192,7 +195,7 @@ def run_moco(tag, cfg, B, seed_w, seed_b, ragged):
     h.load_oracle_params({n: t for n, t in p.items()})
     h.proj_queue.copy_(O.init_queue(cfg, 0))
     h.train()
-    batch = O.synthetic_batch(cfg, B, seed_b, ragged_text=ragged)
+    batch = O.synthetic_batch(cfg, B, seed_b, ragged_text=ragged, sizes=sizes)
     out = {}
 
     # (1) plain infer, both encoders
@@ -206,11 +209,27 @@ def run_moco(tag, cfg, B, seed_w, seed_b, ragged):
         G = cfg["image_size"] // cfg["patch_size"]
         flat = pi[..., 0] * G + pi[..., 1]
         img_f = r["image_feats"]
-        dense = torch.zeros_like(img_f)
-        dense[:, 0] = img_f[:, 0]
-        for b in range(B):
-            dense[b, 1 + flat[b]] = img_f[b, 1:]
-        out["image_feats"] = dense.numpy()
+        if sizes is None:
+            dense = torch.zeros_like(img_f)
+            dense[:, 0] = img_f[:, 0]
+            for b in range(B):
+                dense[b, 1 + flat[b]] = img_f[b, 1:]
+            out["image_feats"] = dense.numpy()
+        else:
+            # zero-padded batch: the reference keeps the valid patches in row-major order and pads with randomly drawn
+            # NON-valid patches, which are all identical tokens - no un-permutation needed; the draw itself is recorded
+            # (a sample with exactly n valid patches comes back as a random PERMUTATION of them - multinomial without
+            # replacement over all of them, :633-636: its valid tokens are put back in row-major order here)
+            img_f = img_f.clone()
+            msk = r["image_masks"]
+            for b in range(B):
+                nv = int(msk[b, 1:].sum())
+                order = torch.argsort(flat[b, :nv])
+                img_f[b, 1:1 + nv] = img_f[b, 1:1 + nv][order]
+                flat[b, :nv] = flat[b, :nv][order]
+            out["image_feats"] = img_f.numpy()
+            out["patch_index_flat"] = flat.numpy()
+            out["image_masks"] = r["image_masks"].numpy()
 
     # (2) PGD alone (K steps and 1 step), momentum copies == query weights here, k from infer_k
     with torch.no_grad():
@@ -260,6 +279,8 @@ def run_moco(tag, cfg, B, seed_w, seed_b, ragged):
     ids = batch["text_ids"]
     out["grad_word_rows"] = we[ids[0, :4]][:, :64].numpy().copy()
     out["meta"] = np.array([B, seed_w, seed_b, int(ragged), cfg["num_layers"], cfg["num_negative"], cfg["adv_steps_img"]])
+    if sizes is not None:
+        out["sizes"] = np.array(sizes)
     path = os.path.join(ROOT, "tests", "golden", f"moco_{tag}.npz")
     np.savez_compressed(path, **out)
     print(tag, "moco_loss", out["moco_loss"], "bytes", os.path.getsize(path))
@@ -508,6 +529,10 @@ if __name__ == "__main__":
     if want("moco"):
         run_moco("L2_B4_ragged", small, 4, 11, 21, True)
         run_moco("L12_B2", full, 2, 12, 22, False)
+    if want("ragged"):
+        run_moco("L2_B4_raggedimg", small, 4, 11, 21, True, sizes=RAGGED_SIZES)
+        # no full-size image in the batch: n = 132 selected patches (N = 173 tokens != 185), position table still 12 x 12
+        run_moco("L2_B3_raggedimg2", small, 3, 11, 23, True, sizes=[(384, 352), (320, 384), (224, 288)])
     if want("itm"):
         run_itm("L2_B4_ragged", small, 4, 11, 21, True)
         run_itm("L12_B2", full, 2, 12, 22, False)

@@ -130,7 +130,7 @@ def init_queue(cfg: dict, seed: int = 0, dtype=torch.float32) -> Tensor:
     return torch.randn(cfg["proj_dim"], cfg["num_negative"], generator=g, dtype=torch.float32).to(dtype)
 
 
-def synthetic_batch(cfg: dict, B: int, seed: int, ragged_text: bool = False, dtype=torch.float32) -> dict:
+def synthetic_batch(cfg: dict, B: int, seed: int, ragged_text: bool = False, dtype=torch.float32, sizes=None) -> dict:
     """Synthetic batch in the layout of BaseDataset.collate (vilt/datasets/base_dataset.py:167-245):
     image = list of views, view 0 = [B,3,H,W] in [-1,1] (transforms/utils.py:48-50)."""
     g = torch.Generator(device="cpu")
@@ -150,6 +150,14 @@ def synthetic_batch(cfg: dict, B: int, seed: int, ragged_text: bool = False, dty
     else:
         ids[:, -1] = 102
     ids[:, 0] = 101
+    if sizes is not None:
+        # zero-padded batch of smaller images (BaseDataset.collate pads bottom/right with zeros, base_dataset.py:192-206;
+        # MinMaxResize makes every side a multiple of 32, transforms/utils.py:5-26): sample b keeps img[:, :h, :w]
+        for b, (h, w) in enumerate(sizes):
+            img[b, :, h:, :] = 0
+            img[b, :, :, w:] = 0
+        hm, wm = max(h for h, _ in sizes), max(w for _, w in sizes)
+        img = img[:, :, :hm, :wm].contiguous()
     false_img = torch.roll(img, shifts=1, dims=0)
     return {
         "image": [img], "false_image_0": [false_img],
@@ -218,6 +226,79 @@ def visual_embed_dense(p: Params, pre: str, img: Tensor, cfg: dict, drop_mask: O
     return x, m
 
 
+def ragged_geometry(img: Tensor, P: int):
+    """Per-sample valid-patch grid of a zero-padded batch (vision_transformer.py:563-567): pixel mask (sum_c != 0) sampled
+    by nearest-neighbour resize = the top-left pixel of every patch; x_h / x_w = valid rows in column 0 / columns in row 0."""
+    m = (img.sum(dim=1) != 0)[:, ::P, ::P].long()                 # [B, Gh, Gw]
+    return m, m[:, :, 0].sum(dim=1), m[:, 0, :].sum(dim=1)
+
+
+def ragged_select(mask: Tensor, max_image_len: int, select: Optional[Tensor] = None) -> Tuple[Tensor, int]:
+    """Patch selection of visual_embed (vision_transformer.py:605-651): per sample the valid patches in row-major order, padded
+    to n = min(max valid count, max_image_len) with non-valid patches.  The reference draws the pads (and, when a sample has
+    MORE than n valid patches, the kept subset) with torch.multinomial; all non-valid patches of a zero-padded batch are
+    identical (conv(0) + bias, zero position embedding, masked as keys), so the pad choice is immaterial: this restatement
+    pads with the first non-valid patch.  A sample with more than n valid patches needs the reference's draw: pass it as
+    ``select`` [B, n] (flat patch indices), e.g. captured from the reference's returned patch_index."""
+    B = mask.shape[0]
+    flat = mask.flatten(1)
+    counts = flat.sum(1)
+    n = int(counts.max())
+    if isinstance(max_image_len, int) and max_image_len > 0:
+        n = min(n, max_image_len)
+    if select is not None:
+        assert select.shape == (B, n)
+        return select, n
+    out = torch.zeros(B, n, dtype=torch.int64)
+    for b in range(B):
+        v = flat[b].nonzero().flatten()
+        if v.numel() > n:
+            raise ValueError("sample has more valid patches than max_image_len: pass the reference's selection")
+        nv = (1 - flat[b]).nonzero().flatten()
+        out[b, : v.numel()] = v
+        if v.numel() < n:
+            out[b, v.numel():] = nv[0]
+    return out, n
+
+
+def resize_pos_embed(pos: Tensor, G0: int, h: int, w: int) -> Tensor:
+    """Bilinear, align_corners=True resize of the [G0*G0, D] spatial position table to [h, w, D] (vision_transformer.py:570-583)."""
+    D = pos.shape[-1]
+    sp = pos.t().reshape(1, D, G0, G0)
+    r = F.interpolate(sp, size=(h, w), mode="bilinear", align_corners=True)
+    return r[0].permute(1, 2, 0)
+
+
+def visual_embed(p: Params, pre: str, img: Tensor, cfg: dict, select: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Tensor]:
+    """VisionTransformer.visual_embed (vision_transformer.py:559-677) for any zero-padded batch: patch projection, per-sample
+    position-embedding resize, valid-patch selection / padding, cls token.  Returns (x [B, 1+n, D], mask [B, 1+n], select)."""
+    P = cfg["patch_size"]
+    G0 = cfg["image_size"] // P
+    W = p[pre + "transformer.patch_embed.proj.weight"]
+    D = W.shape[0]
+    B = img.shape[0]
+    Gw = img.shape[3] // P
+    m, xh, xw = ragged_geometry(img, P)
+    sel, n = ragged_select(m, cfg.get("max_image_len", -1), select)
+    xp = patchify(img, P) @ W.reshape(D, -1).t() + p[pre + "transformer.patch_embed.proj.bias"]      # [B, Gh*Gw, D]
+    pos_tab = p[pre + "transformer.pos_embed"][0, 1:]
+    rows = []
+    masks = []
+    for b in range(B):
+        h, w = int(xh[b]), int(xw[b])
+        pe = torch.zeros(img.shape[2] // P, Gw, D, dtype=xp.dtype)
+        pe[:h, :w] = resize_pos_embed(pos_tab, G0, h, w)
+        pe = pe.reshape(-1, D)
+        rows.append(xp[b, sel[b]] + pe[sel[b]])
+        masks.append(m[b].flatten()[sel[b]])
+    x = torch.stack(rows)
+    cls = (p[pre + "transformer.cls_token"][0] + p[pre + "transformer.pos_embed"][0, :1]).expand(B, -1, -1)
+    x = torch.cat([cls, x], dim=1)
+    mask = torch.cat([torch.ones(B, 1, dtype=torch.int64), torch.stack(masks)], dim=1)
+    return x, mask, sel
+
+
+
 def attention(p: Params, b: str, x: Tensor, mask: Tensor, H: int) -> Tensor:
     """Attention.forward (vision_transformer.py:309-332): qkv features ordered (which, head, d)."""
     B, N, C = x.shape
@@ -247,7 +328,8 @@ def block(p: Params, b: str, x: Tensor, mask: Tensor, H: int, drop: Optional[dic
 
 
 def infer(p: Params, cfg: dict, ids: Tensor, text_masks: Tensor, img: Tensor, key: bool = False,
-          image_token_type_idx: int = 1, word_embeds: Optional[Tensor] = None, drop: Optional[dict] = None) -> dict:
+          image_token_type_idx: int = 1, word_embeds: Optional[Tensor] = None, drop: Optional[dict] = None,
+          select: Optional[Tensor] = None) -> dict:
     """ViLTransformerSS.infer (vilt_module.py:275-351) / infer_k (:353-418).
     ``key=True`` uses the k_* momentum copies but the *query* pooler (:405)."""
     pre = "k_" if key else ""
@@ -256,7 +338,12 @@ def infer(p: Params, cfg: dict, ids: Tensor, text_masks: Tensor, img: Tensor, ke
     if "text" in drop:                                     # BertEmbeddings.dropout
         te = te * drop["text"]
     te = te + p[pre + "token_type_embeddings.weight"][0]
-    ie, im = visual_embed_dense(p, pre, img, cfg, drop.get("image"))
+    S = cfg["image_size"]
+    if img.shape[2] == S and img.shape[3] == S and select is None and bool((patch_mask(img, cfg["patch_size"]) == 1).all()):
+        ie, im = visual_embed_dense(p, pre, img, cfg, drop.get("image"))
+    else:                                                   # zero-padded batch of smaller images
+        assert "image" not in drop
+        ie, im, _ = visual_embed(p, pre, img, cfg, select)
     ie = ie + p[pre + "token_type_embeddings.weight"][image_token_type_idx]
     x = torch.cat([te, ie], dim=1)
     m = torch.cat([text_masks, im], dim=1)

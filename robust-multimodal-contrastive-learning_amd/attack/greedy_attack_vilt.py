@@ -98,7 +98,7 @@ class GreedyAttack_moco(GreedyAttack):
         nc = self.n_candidates
         Bc = Bn * nc
         pb = eng.bind_batch(ids_host.to(dev), masks, batch["image"][0], tag="txtatk")
-        pc = eng.bufs(Bc, "txtatk_cand")
+        pc = None                                                   # candidate buffers: same image geometry, one row per candidate
         op = eng.make_operand(pb)                                   # clean image, shared by every loop
         de = torch.empty(Bn * Lt, pb.d.D, device=dev)
         k = k_modality.to(dev, torch.float32).contiguous()
@@ -134,6 +134,7 @@ class GreedyAttack_moco(GreedyAttack):
             while len(rows) < Bc:                                      # pad to the fixed candidate batch
                 rows.append(ids_host[0].clone()); owner.append(0)
             own = torch.tensor(owner, device=dev)
+            pc = eng.twin(pb, "txtatk_cand", owner=own)
             pc.text_ids = torch.stack(rows).to(dev)
             pc.text_mask = masks.index_select(0, own)
             torch.index_select(op.view(Bn, -1), 0, own, out=pc.patchesT.view(Bc, -1))

@@ -65,5 +65,5 @@ class PGDAttack_moco(PGDAttack):
         delta_p = self.attack_patches(pl_module, pb, k_modality)
         B = img_init.shape[0]
         # the reference leaves batch['image'][0] = img_init + delta_{K-1} behind (:144)
-        batch["image"][0] = img_init.to(eng.device) + eng.patches_to_image(pb.delta_prev, B)
-        return eng.patches_to_image(delta_p, B)
+        batch["image"][0] = img_init.to(eng.device) + eng.patches_to_image(pb.delta_prev, pb)
+        return eng.patches_to_image(delta_p, pb)

@@ -213,6 +213,15 @@ int rmcl_heads_backward(const rmcl_dims* d, const float* pool32, const float* he
 int rmcl_im2patch_f32(const float* img, float* patches, int B, int C, int Hh, int Ww, int ps, int to_image, void* stream) {
   return rmcl_im2patch(img, patches, B, C, Hh, Ww, ps, to_image, (hipStream_t)stream);
 }
+int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, int32_t* sel, int32_t* counts, int32_t* hw, void* stream) {
+  RMCL_REQUIRE(img && sel && counts && hw, "patch_select: NULL argument");
+  return rmcl_patch_select(img, B, C, Hh, Ww, ps, sel, counts, hw, (hipStream_t)stream);
+}
+int rmcl_im2patch_sel(float* img, float* patches, const int32_t* sel, const int32_t* counts, int sel_ld, int B, int n, int C, int Hh,
+                      int Ww, int ps, int to_image, void* stream) {
+  RMCL_REQUIRE(img && patches && sel && counts && n > 0, "im2patch_sel: NULL argument");
+  return rmcl_im2patch_sel(img, patches, sel, counts, sel_ld, B, n, C, Hh, Ww, ps, to_image, (hipStream_t)stream);
+}
 int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* out, int dtype, int64_t n, void* stream) {
   RMCL_REQUIRE(a && out, "add_cast: NULL argument");
   return rmcl_k_add_cast(a, d1, d2, out, dtype, n, (hipStream_t)stream);

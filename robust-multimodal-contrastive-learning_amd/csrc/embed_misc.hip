@@ -148,7 +148,7 @@ int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, l
 __global__ __launch_bounds__(256) void image_assemble_fwd_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                                                  const float* __restrict__ pos, const float* __restrict__ vtype1,
                                                                  float* __restrict__ x, int B, int P, int L, int N, int D,
-                                                                 uint32_t dseed, uint32_t dthresh, float dinv) {
+                                                                 uint32_t dseed, uint32_t dthresh, float dinv, long pos_bstride) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int dv = D / 4;
   if (i >= (long)B * (P + 1) * dv) return;
@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void image_assemble_fwd_kernel(const float* __
   const int tok = (int)((i / dv) % (P + 1)), b = (int)(i / ((long)dv * (P + 1)));
   const float4 a = tok == 0 ? *reinterpret_cast<const float4*>(cls + c)
                             : *reinterpret_cast<const float4*>(pe + ((long)b * P + tok - 1) * D + c);
-  const float4 p = *reinterpret_cast<const float4*>(pos + (long)tok * D + c);
+  // pos_bstride = 0: the shared position table; (P+1)*D: per-sample rows (zero-padded batches: resized per image)
+  const float4 p = *reinterpret_cast<const float4*>(pos + (long)b * pos_bstride + (long)tok * D + c);
   const float4 t = *reinterpret_cast<const float4*>(vtype1 + c);
   float4 o = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
   if (dthresh) {                                              // pos_drop (vision_transformer.py:667), before the token type
@@ -167,10 +168,10 @@ __global__ __launch_bounds__(256) void image_assemble_fwd_kernel(const float* __
   *reinterpret_cast<float4*>(x + ((long)b * N + L + tok) * D + c) = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
 }
 int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos, const float* vtype1, float* x, int B, int P,
-                            int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
+                            int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, int pos_per_sample, hipStream_t s) {
   RMCL_REQUIRE(D % 4 == 0, "image_assemble: D%4");
   RMCL_LAUNCH(image_assemble_fwd_kernel, dim3(cdiv((long)B * (P + 1) * (D / 4), 256)), dim3(256), 0, s, pe, cls, pos, vtype1, x, B, P, L, N, D,
-              dseed, dthresh, dinv);
+              dseed, dthresh, dinv, pos_per_sample ? (long)(P + 1) * D : 0L);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -181,7 +182,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void image_assemble_bwd_kernel(const float* __restrict__ dx, T* __restrict__ dpe,
                                                                  float* __restrict__ dpos, float* __restrict__ dcls,
                                                                  float* __restrict__ dvtype1, int B, int P, int L, int N, int D,
-                                                                 uint32_t dseed, uint32_t dthresh, float dinv) {
+                                                                 uint32_t dseed, uint32_t dthresh, float dinv, float* __restrict__ dpos_tok) {
   const int tok = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
   if (c >= D) return;
   float acc = 0.f, acc_raw = 0.f;
@@ -191,18 +192,19 @@ __global__ __launch_bounds__(256) void image_assemble_bwd_kernel(const float* __
     acc += v;
     acc_raw += raw;
     if (tok > 0) dpe[((long)b * P + tok - 1) * D + c] = from_f32<T>(v);
+    if (dpos_tok) dpos_tok[((long)b * (P + 1) + tok) * D + c] = v;     // per-sample position rows: scattered by pos_resize_bwd
   }
   if (dpos) {
-    atomicAdd(dpos + (long)tok * D + c, acc);
+    if (!dpos_tok) atomicAdd(dpos + (long)tok * D + c, acc);
     atomicAdd(dvtype1 + c, acc_raw);                         // the token type is added after pos_drop
     if (tok == 0) atomicAdd(dcls + c, acc);
   }
 }
 int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,
-                            int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
+                            int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, float* dpos_tok, hipStream_t s) {
   dim3 grid(P + 1, cdiv(D, 256));
-  if (dt == RMCL_F32) RMCL_LAUNCH(image_assemble_bwd_kernel<float>, grid, dim3(256), 0, s, dx, (float*)dpe, dpos, dcls, dvtype1, B, P, L, N, D, dseed, dthresh, dinv);
-  else RMCL_LAUNCH(image_assemble_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dx, (bf16_t*)dpe, dpos, dcls, dvtype1, B, P, L, N, D, dseed, dthresh, dinv);
+  if (dt == RMCL_F32) RMCL_LAUNCH(image_assemble_bwd_kernel<float>, grid, dim3(256), 0, s, dx, (float*)dpe, dpos, dcls, dvtype1, B, P, L, N, D, dseed, dthresh, dinv, dpos_tok);
+  else RMCL_LAUNCH(image_assemble_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, dx, (bf16_t*)dpe, dpos, dcls, dvtype1, B, P, L, N, D, dseed, dthresh, dinv, dpos_tok);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -228,6 +230,157 @@ __global__ __launch_bounds__(256) void im2patch_kernel(const float* __restrict__
 int rmcl_im2patch(const float* img, float* pat, int B, int C, int Hh, int Ww, int ps, int to_image, hipStream_t s) {
   RMCL_REQUIRE(ps % 4 == 0 && Hh % ps == 0 && Ww % ps == 0, "im2patch: image sides must be multiples of the patch size");
   RMCL_LAUNCH(im2patch_kernel, dim3(cdiv((long)B * C * Hh * Ww / 4, 256)), dim3(256), 0, s, img, pat, B, C, Hh, Ww, ps, to_image);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Zero-padded batches of smaller images (VisionTransformer.visual_embed, vision_transformer.py:559-677; collate pads
+// bottom/right with zeros, base_dataset.py:192-206).
+//   patch_select : per sample, pixel mask (sum_c != 0) sampled at each patch's top-left pixel (:563-565), x_h / x_w (:566-567),
+//                  and the selection list: valid patches in row-major order, then the first non-valid patch repeated (the
+//                  reference draws the pads at random among the non-valid patches, which are all identical tokens).
+//   im2patch_sel : image <-> compact patch rows [B*n, C*ps*ps] of the selected patches (the patch GEMM then runs on n, not
+//                  Gh*Gw, patches per sample; pad rows are zero)
+//   pos_resize   : per-sample bilinear, align_corners=True resize of the G0 x G0 position table to (h, w) (:570-583) evaluated
+//                  at the selected patches, and its transpose (scatter-add) for the position-embedding gradient.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patch_select_kernel(const float* __restrict__ img, int C, int Hh, int Ww, int ps,
+                                                           int* __restrict__ sel, int* __restrict__ counts, int* __restrict__ hw) {
+  __shared__ int flag[1024];
+  const int b = blockIdx.x, gh = Hh / ps, gw = Ww / ps, G = gh * gw;
+  for (int p = threadIdx.x; p < G; p += 256) {
+    const int py = p / gw, px = p % gw;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += img[(((long)b * C + c) * Hh + (long)py * ps) * Ww + (long)px * ps];
+    flag[p] = s != 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int h = 0, w = 0, n = 0, first_pad = -1;
+    for (int py = 0; py < gh; ++py) h += flag[py * gw];
+    for (int px = 0; px < gw; ++px) w += flag[px];
+    for (int p = 0; p < G; ++p) {
+      if (flag[p]) sel[(long)b * G + n++] = p;
+      else if (first_pad < 0) first_pad = p;
+    }
+    for (int k = n; k < G; ++k) sel[(long)b * G + k] = first_pad < 0 ? 0 : first_pad;
+    counts[b] = n;
+    hw[2 * b] = h;
+    hw[2 * b + 1] = w;
+  }
+}
+int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, int* sel, int* counts, int* hw, hipStream_t s) {
+  RMCL_REQUIRE(Hh % ps == 0 && Ww % ps == 0 && (Hh / ps) * (Ww / ps) <= 1024, "patch_select: sides must be multiples of the patch size, <= 1024 patches");
+  RMCL_LAUNCH(patch_select_kernel, dim3(B), dim3(256), 0, s, img, C, Hh, Ww, ps, sel, counts, hw);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// one float4 of a selected patch row per thread; sel_ld = row pitch of `sel`; to_image: scatter rows k < counts[b] back
+__global__ __launch_bounds__(256) void im2patch_sel_kernel(float* __restrict__ img, float* __restrict__ pat, const int* __restrict__ sel,
+                                                           const int* __restrict__ counts, int sel_ld, int B, int n, int C, int Hh, int Ww, int ps,
+                                                           int to_image) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int kq = C * ps * ps / 4;
+  if (i >= (long)B * n * kq) return;
+  const int e = (int)(i % kq) * 4;
+  const int k = (int)((i / kq) % n), b = (int)(i / ((long)kq * n));
+  const int gw = Ww / ps, p = sel[(long)b * sel_ld + k];
+  const int py = p / gw, px = p % gw;
+  const int c = e / (ps * ps), ky = (e / ps) % ps, kx = e % ps;
+  float* ip = img + (((long)b * C + c) * Hh + (long)py * ps + ky) * Ww + (long)px * ps + kx;
+  float* pp = pat + ((long)b * n + k) * ((long)C * ps * ps) + e;
+  if (to_image) {
+    if (k < counts[b]) *reinterpret_cast<float4*>(ip) = *reinterpret_cast<const float4*>(pp);
+  } else {
+    *reinterpret_cast<float4*>(pp) = k < counts[b] ? *reinterpret_cast<const float4*>(ip) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+int rmcl_im2patch_sel(float* img, float* pat, const int* sel, const int* counts, int sel_ld, int B, int n, int C, int Hh, int Ww, int ps,
+                      int to_image, hipStream_t s) {
+  RMCL_REQUIRE(ps % 4 == 0 && Hh % ps == 0 && Ww % ps == 0, "im2patch_sel: image sides must be multiples of the patch size");
+  if (to_image) {
+    hipError_t e = hipMemsetAsync(img, 0, (size_t)B * C * Hh * Ww * sizeof(float), s);
+    if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+  }
+  RMCL_LAUNCH(im2patch_sel_kernel, dim3(cdiv((long)B * n * (C * ps * ps / 4), 256)), dim3(256), 0, s, img, pat, sel, counts, sel_ld, B, n, C, Hh, Ww, ps,
+              to_image);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// source index and weight of torch's bilinear align_corners=True resize (upsample_bilinear2d): src = dst * (in-1)/(out-1)
+__device__ __forceinline__ void bilin_src(int dst, int in, int out, int& i0, int& i1, float& l1) {
+  const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)dst;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// pos_tok[b, 0] = table[0]; pos_tok[b, 1+k] = resized spatial table at the k-th selected patch (0 for pad slots)
+__global__ __launch_bounds__(256) void pos_resize_fwd_kernel(const float* __restrict__ table, const int* __restrict__ sel, const int* __restrict__ counts,
+                                                             const int* __restrict__ hw, int sel_ld, int gw, int G0, int B, int n, int D,
+                                                             float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int dv = D / 4;
+  if (i >= (long)B * (n + 1) * dv) return;
+  const int c = (int)(i % dv) * 4, tok = (int)((i / dv) % (n + 1)), b = (int)(i / ((long)dv * (n + 1)));
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tok == 0) {
+    o = *reinterpret_cast<const float4*>(table + c);
+  } else if (tok - 1 < counts[b]) {
+    const int p = sel[(long)b * sel_ld + tok - 1], py = p / gw, px = p % gw;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilin_src(py, G0, hw[2 * b], y0, y1, ly);
+    bilin_src(px, G0, hw[2 * b + 1], x0, x1, lx);
+    const float4 v00 = *reinterpret_cast<const float4*>(table + (long)(1 + y0 * G0 + x0) * D + c);
+    const float4 v01 = *reinterpret_cast<const float4*>(table + (long)(1 + y0 * G0 + x1) * D + c);
+    const float4 v10 = *reinterpret_cast<const float4*>(table + (long)(1 + y1 * G0 + x0) * D + c);
+    const float4 v11 = *reinterpret_cast<const float4*>(table + (long)(1 + y1 * G0 + x1) * D + c);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+  }
+  *reinterpret_cast<float4*>(out + ((long)b * (n + 1) + tok) * D + c) = o;
+}
+int rmcl_pos_resize_fwd(const float* table, const int* sel, const int* counts, const int* hw, int sel_ld, int gw, int G0, int B, int n, int D,
+                        float* out, hipStream_t s) {
+  RMCL_REQUIRE(D % 4 == 0, "pos_resize: D%4");
+  RMCL_LAUNCH(pos_resize_fwd_kernel, dim3(cdiv((long)B * (n + 1) * (D / 4), 256)), dim3(256), 0, s, table, sel, counts, hw, sel_ld, gw, G0, B, n, D, out);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// transpose of the above: dtable += scatter(dpos_tok) (float atomics: a table row collects from many (sample, patch) pairs)
+__global__ __launch_bounds__(256) void pos_resize_bwd_kernel(const float* __restrict__ dtok, const int* __restrict__ sel, const int* __restrict__ counts,
+                                                             const int* __restrict__ hw, int sel_ld, int gw, int G0, int B, int n, int D,
+                                                             float* __restrict__ dtable) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)B * (n + 1) * D) return;
+  const int c = (int)(i % D), tok = (int)((i / D) % (n + 1)), b = (int)(i / ((long)D * (n + 1)));
+  const float g = dtok[i];
+  if (tok == 0) { atomicAdd(dtable + c, g); return; }
+  if (tok - 1 >= counts[b]) return;
+  const int p = sel[(long)b * sel_ld + tok - 1], py = p / gw, px = p % gw;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bilin_src(py, G0, hw[2 * b], y0, y1, ly);
+  bilin_src(px, G0, hw[2 * b + 1], x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  atomicAdd(dtable + (long)(1 + y0 * G0 + x0) * D + c, g * hy * hx);
+  atomicAdd(dtable + (long)(1 + y0 * G0 + x1) * D + c, g * hy * lx);
+  atomicAdd(dtable + (long)(1 + y1 * G0 + x0) * D + c, g * ly * hx);
+  atomicAdd(dtable + (long)(1 + y1 * G0 + x1) * D + c, g * ly * lx);
+}
+int rmcl_pos_resize_bwd(const float* dtok, const int* sel, const int* counts, const int* hw, int sel_ld, int gw, int G0, int B, int n, int D,
+                        float* dtable, hipStream_t s) {
+  RMCL_LAUNCH(pos_resize_bwd_kernel, dim3(cdiv((long)B * (n + 1) * D, 256)), dim3(256), 0, s, dtok, sel, counts, hw, sel_ld, gw, G0, B, n, D, dtable);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

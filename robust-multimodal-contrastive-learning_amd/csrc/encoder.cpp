@@ -304,7 +304,7 @@ void rmcl_param_layout(const rmcl_dims* d, rmcl_layout* o) {
   o->eln_w = take(D); o->eln_b = take(D);
   o->vtype = take(2 * D);
   o->cls = take(D);
-  o->pos_img = take((int64_t)(d->P + 1) * D);
+  o->pos_img = take((int64_t)((d->Pp > 0 ? d->Pp : d->P) + 1) * D);
   o->patch_w = take(D * d->patch_k);
   o->patch_b = take(D);
   o->layer0 = off;
@@ -334,8 +334,10 @@ int64_t rmcl_workspace_bytes(const rmcl_dims* d) { return (int64_t)carve_work(*d
 
 int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
                          const int64_t* text_mask, const void* patches, int32_t* co_mask, void* stash, void* workspace,
-                         float* xn, uint32_t drop_seed, float drop_p, void* stream) {
+                         float* xn, uint32_t drop_seed, float drop_p, const rmcl_ragged* ragged, void* stream) {
   RMCL_TRY(check_dims(d));
+  RMCL_REQUIRE(!ragged || (ragged->sel && ragged->counts && ragged->hw && ragged->pos_tok), "encoder_forward: incomplete rmcl_ragged");
+  RMCL_REQUIRE(ragged || d->Pp == 0 || d->Pp == d->P, "encoder_forward: P != Pp needs the rmcl_ragged selection");
   RMCL_REQUIRE(params32 && text_ids && text_mask && patches && co_mask && workspace && xn, "encoder_forward: NULL argument");
   RMCL_REQUIRE(d->dtype == RMCL_F32 || params_lp, "encoder_forward: bf16 mode needs the bf16 shadow arena");
   RMCL_REQUIRE(mode == RMCL_MODE_INFER || stash, "encoder_forward: stash required unless mode is INFER");
@@ -365,8 +367,14 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     g.epi = EPI_BIAS; g.bias = c.V(y.patch_b); g.tag = GEMM_TAG_PATCH;
     RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
   }
-  RMCL_TRY(rmcl_image_assemble_fwd(w.pe, c.V(y.cls), c.V(y.pos_img), c.V(y.vtype) + D, x0, B, P, L, N, D,
-                                   rmcl_site_seed(drop_seed, 0, DROP_SITE_IMAGE), dth, dinv, s));
+  if (ragged) {
+    // zero-padded batch: per-sample position rows = the table resized to each image's (h, w), gathered at its selected
+    // patches (vision_transformer.py:570-600, 645-650); recomputed every pass from the arena of THIS pass (query or momentum)
+    RMCL_TRY(rmcl_pos_resize_fwd(c.V(y.pos_img), ragged->sel, ragged->counts, ragged->hw, ragged->sel_ld, ragged->gw, ragged->G0, B, P, D,
+                                 ragged->pos_tok, s));
+  }
+  RMCL_TRY(rmcl_image_assemble_fwd(w.pe, c.V(y.cls), ragged ? ragged->pos_tok : c.V(y.pos_img), c.V(y.vtype) + D, x0, B, P, L, N, D,
+                                   rmcl_site_seed(drop_seed, 0, DROP_SITE_IMAGE), dth, dinv, ragged ? 1 : 0, s));
   RMCL_TRY(rmcl_co_mask((const long*)text_mask, patches, dt, co_mask, B, L, P, 3, d->patch_k / 3, s));
 
   float* x = x0;
@@ -420,8 +428,10 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 
 int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
                           const void* patches, const int32_t* co_mask, void* stash, void* workspace, const float* dxn,
-                          int cls_only, void* dpatches, float* dtext, float* G, uint32_t drop_seed, float drop_p, void* stream) {
+                          int cls_only, void* dpatches, float* dtext, float* G, uint32_t drop_seed, float drop_p,
+                          const rmcl_ragged* ragged, void* stream) {
   RMCL_TRY(check_dims(d));
+  RMCL_REQUIRE(!ragged || mode != RMCL_MODE_FULL || ragged->dpos_tok, "encoder_backward: rmcl_ragged.dpos_tok needed in FULL mode");
   RMCL_REQUIRE(mode == RMCL_MODE_DATA || mode == RMCL_MODE_FULL, "encoder_backward: mode must be DATA or FULL");
   RMCL_REQUIRE(params32 && stash && workspace && dxn && co_mask, "encoder_backward: NULL argument");
   RMCL_REQUIRE(mode != RMCL_MODE_FULL || (G && text_ids && patches), "encoder_backward: FULL mode needs grads32, text_ids, patches");
@@ -571,7 +581,11 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
 
   // ---- embeddings ----
   RMCL_TRY(rmcl_image_assemble_bwd(w.dx, w.dpe, dt, full ? Gp(y.pos_img) : nullptr, full ? Gp(y.cls) : nullptr,
-                                   full ? Gp(y.vtype) + D : nullptr, B, P, L, N, D, rmcl_site_seed(drop_seed, 0, DROP_SITE_IMAGE), dth, dinv, s));
+                                   full ? Gp(y.vtype) + D : nullptr, B, P, L, N, D, rmcl_site_seed(drop_seed, 0, DROP_SITE_IMAGE), dth, dinv,
+                                   (ragged && full) ? ragged->dpos_tok : nullptr, s));
+  if (ragged && full)                                          // position-table gradient through the per-sample resize
+    RMCL_TRY(rmcl_pos_resize_bwd(ragged->dpos_tok, ragged->sel, ragged->counts, ragged->hw, ragged->sel_ld, ragged->gw, ragged->G0, B, P, D,
+                                 Gp(y.pos_img), s));
   if (dpatches) {
     GemmArgs g = gemm_args(w.dpe, c.W(y.patch_w), dpatches, B * P, d->patch_k, D, D, d->patch_k, d->patch_k);
     RMCL_TRY(gemm(c, g, dt, dt, 1, 0));

@@ -73,9 +73,30 @@ struct SWCtx {
   int wave;
 };
 
-// one k-tile; LAST: no staging (the last k-tile of the output tile)
-template <bool B_KC, bool LAST>
-__device__ __forceinline__ void sw_ktile(f32x4 (&acc)[6][6], const SWCtx& c, const char* cur, char* oth, int t1) {
+// GELU'(aux) epilogue operand through LDS: one 24 KiB unit (32 image rows x 768 B) of the [96][768 B] image of an aux chunk
+// (48 tile rows per wave group: image row r -> tile row (r / 48) * 96 + ch * 48 + r % 48), whole rows, 16 bytes per lane;
+// the 16-byte chunk of row r at chunk ^ (r & 7) like the output image (the swizzle is applied to the SOURCE address).
+struct SWAux {
+  const bf16_t* aux;
+  long ld;
+  int m0, n0, M;
+};
+__device__ __forceinline__ void sw_stage_aux(const SWAux& x, int ch, int unit, char* area, int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int L = unit * SW_UNIT + (wave * 3 + q) * 1024 + lane * 16;
+    const int r = L / 768, p = (L - r * 768) >> 4;
+    const int trow = (r / 48) * 96 + ch * 48 + (r % 48);
+    const long m = min(x.m0 + trow, x.M - 1);
+    const bf16_t* src = x.aux + m * x.ld + x.n0 + ((p ^ (r & 7)) << 3);
+    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(area + unit * SW_UNIT + (wave * 3 + q) * 1024), 16, 0, 0);
+  }
+}
+
+// one k-tile; LAST: no staging (the last k-tile of the output tile).  AUXST (with LAST): the buffer that would take tile
+// t+1 takes chunk 0 of the epilogue's aux operand instead, one unit per phase like the operand staging it replaces.
+template <bool B_KC, bool LAST, bool AUXST = false>
+__device__ __forceinline__ void sw_ktile(f32x4 (&acc)[6][6], const SWCtx& c, const char* cur, char* oth, int t1, const SWAux* ax = nullptr, int lane = 0) {
   bf16x8 a[3][2], b[3][2];
   // ---- P1: rows-lo x B0
 #pragma unroll
@@ -86,7 +107,7 @@ __device__ __forceinline__ void sw_ktile(f32x4 (&acc)[6][6], const SWCtx& c, con
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int s = 0; s < 2; ++s) a[i][s] = sw_ld<true>(cur, i * 2048 + c.aoff[s], s);
-  if (!LAST) { sw_stage(c.A, c.oa, (long)t1 * 64, oth, c.wave); sw_wait_vm<3>(); } else { sw_wait_vm<0>(); }
+  if (!LAST) { sw_stage(c.A, c.oa, (long)t1 * 64, oth, c.wave); sw_wait_vm<3>(); } else { sw_wait_vm<0>(); if (AUXST) sw_stage_aux(*ax, 0, 0, oth, c.wave, lane); }
   SW_PHASE_BEGIN();
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -101,6 +122,7 @@ __device__ __forceinline__ void sw_ktile(f32x4 (&acc)[6][6], const SWCtx& c, con
 #pragma unroll
     for (int s = 0; s < 2; ++s) b[j][s] = B_KC ? sw_ld<true>(cur + 2 * SW_UNIT, j * 2048 + c.boff[s], s) : sw_ld<false>(cur + 2 * SW_UNIT, c.boffj[j], s);
   if (!LAST) sw_stage(c.B, c.ob0, (long)t1 * c.kstep_b, oth + SW_UNIT, c.wave);
+  else if (AUXST) sw_stage_aux(*ax, 0, 1, oth, c.wave, lane);
   SW_PHASE_BEGIN();
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -115,6 +137,7 @@ __device__ __forceinline__ void sw_ktile(f32x4 (&acc)[6][6], const SWCtx& c, con
 #pragma unroll
     for (int s = 0; s < 2; ++s) a[i][s] = sw_ld<true>(cur, (3 + i) * 2048 + c.aoff[s], s);
   if (!LAST) sw_stage(c.B, c.ob1, (long)t1 * c.kstep_b, oth + 2 * SW_UNIT, c.wave);
+  else if (AUXST) sw_stage_aux(*ax, 0, 2, oth, c.wave, lane);
   SW_PHASE_BEGIN();
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -234,8 +257,21 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     char* oth = (it & 1) ? buf0 : buf1;
     sw_ktile<B_KC, false>(acc, c, cur, oth, it + 1);
   }
-  sw_ktile<B_KC, true>(acc, c, (it & 1) ? buf1 : buf0, nullptr, 0);
+  // GELU'(aux) epilogue with bf16 output: the aux tile (the stashed pre-activation, cold in HBM by the time the backward
+  // runs) comes through LDS - chunk 0 is fetched by LDS-DMA into the idle buffer DURING the last k-tile, chunk 1 while chunk
+  // 0 is converted and stored; whole 768-byte rows instead of the fragment layout's 32-byte pieces.
+  constexpr bool AUX_LDS = AUX == SW_AUX_DGELU && sizeof(TO) == 2;
+  char* last_cur = (it & 1) ? buf1 : buf0;
+  char* aux_area = (it & 1) ? buf0 : buf1;                     // free during the last k-tile
+  SWAux ax{reinterpret_cast<const bf16_t*>(g.aux), (long)g.ld_aux, m0, n0, g.M};
+  if constexpr (AUX_LDS) {
+    sw_ktile<B_KC, true, true>(acc, c, last_cur, aux_area, 0, &ax, lane);
+    sw_wait_vm<0>();
+  } else {
+    sw_ktile<B_KC, true>(acc, c, last_cur, nullptr, 0);
+  }
   if (wm == 0) __builtin_amdgcn_s_barrier();
+  if constexpr (AUX_LDS) __builtin_amdgcn_s_barrier();         // every wave's aux DMA has landed
 
   // epilogue (order as gemm_st.hip: alpha, bias, gelu'(aux), stash, gelu, residual)
   const int epi = g.epi;
@@ -248,8 +284,10 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     // group: 48 rows x 768 B images of the output and, when stashed, of the pre-activation; 16-byte chunk c of row r at
     // c ^ (r & 7).  (Both groups are barrier-aligned here; every wave executes the same 4 barriers.)
     constexpr int ROWB = 768, PIECES = 48, ROWS = 48, IMG = ROWS * ROWB;   // 36 KiB per image
-    char* img = smem + wm * (2 * IMG);
-    const bool stash = (epi & EPI_SAVE_PREACT) != 0;
+    // (AUX_LDS: no stash image exists - the two output images live in the buffer the last k-tile was read from, the aux
+    // image in the other one)
+    char* img = AUX_LDS ? last_cur + wm * IMG : smem + wm * (2 * IMG);
+    const bool stash = !AUX_LDS && (epi & EPI_SAVE_PREACT) != 0;
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
@@ -262,9 +300,16 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
 #pragma unroll
         for (int il = 0; il < 3; ++il) {
           const long mr = min(mb + (ch * 3 + il) * 16, g.M - 1);
+          const int arow = wm * 48 + il * 16 + (lane & 15);      // row of the aux image
 #pragma unroll
-          for (int j = 0; j < 3; ++j)
-            if (AUX == SW_AUX_DGELU) pre[il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+          for (int j = 0; j < 3; ++j) {
+            if constexpr (AUX_LDS) {
+              const int e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);
+              pre[il][j] = *reinterpret_cast<const uint2*>(aux_area + arow * ROWB + (((e8 >> 1) ^ (arow & 7)) * 16) + (e8 & 1) * 8);
+            } else if (AUX == SW_AUX_DGELU) {
+              pre[il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+            }
+          }
         }
 #pragma unroll
         for (int il = 0; il < 3; ++il) {
@@ -299,6 +344,12 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
         }
       }
       __builtin_amdgcn_s_barrier();                          // the group's images of this chunk are complete
+      if constexpr (AUX_LDS) {                                 // (both groups are past their aux reads of chunk 0: fetch chunk 1)
+        if (ch == 0) {
+#pragma unroll
+          for (int u = 0; u < 3; ++u) sw_stage_aux(ax, 1, u, aux_area, wave, lane);
+        }
+      }
       int tg = (wave & 3) * 64 + lane;
       asm volatile("" : "+v"(tg));
 #pragma unroll
@@ -312,7 +363,8 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
           if (stash) *reinterpret_cast<float4*>(C2 + dst) = *reinterpret_cast<const float4*>(img + IMG + row * ROWB + cp * 16);
         }
       }
-      __builtin_amdgcn_s_barrier();                          // images consumed
+      if constexpr (AUX_LDS) { if (ch == 0) sw_wait_vm<0>(); }
+      __builtin_amdgcn_s_barrier();                          // images consumed (AUX_LDS: and chunk 1's aux has landed)
     }
   } else {
 #pragma unroll

@@ -57,9 +57,16 @@ int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, floa
 int rmcl_gather_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, hipStream_t s);
 int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, int add, hipStream_t s);
 int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos, const float* vtype1, float* x, int B, int P,
-                            int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
+                            int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, int pos_per_sample, hipStream_t s);
 int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,
-                            int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
+                            int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, float* dpos_tok, hipStream_t s);
+int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, int* sel, int* counts, int* hw, hipStream_t s);
+int rmcl_im2patch_sel(float* img, float* pat, const int* sel, const int* counts, int sel_ld, int B, int n, int C, int Hh, int Ww, int ps,
+                      int to_image, hipStream_t s);
+int rmcl_pos_resize_fwd(const float* table, const int* sel, const int* counts, const int* hw, int sel_ld, int gw, int G0, int B, int n, int D,
+                        float* out, hipStream_t s);
+int rmcl_pos_resize_bwd(const float* dtok, const int* sel, const int* counts, const int* hw, int sel_ld, int gw, int G0, int B, int n, int D,
+                        float* dtable, hipStream_t s);
 int rmcl_im2patch(const float* img, float* pat, int B, int C, int Hh, int Ww, int ps, int to_image, hipStream_t s);
 int rmcl_k_add_cast(const float* a, const float* d1, const float* d2, void* out, int dt, long n, hipStream_t s);
 int rmcl_cast(const float* in, void* out, int dt, long n, hipStream_t s);

@@ -27,12 +27,13 @@ def stream_ptr() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_dims(cfg: dict, B: int, dtype: int, exact: bool) -> L.Dims:
+def make_dims(cfg: dict, B: int, dtype: int, exact: bool, P: int = None) -> L.Dims:
+    """P: image patches per sample in this pass (default: the full grid); the position table always has the full grid."""
     ps = cfg["patch_size"]
     g = cfg["image_size"] // ps
-    return L.Dims(B=B, L=cfg["max_text_len"], P=g * g, D=cfg["hidden_size"], H=cfg["num_heads"],
+    return L.Dims(B=B, L=cfg["max_text_len"], P=g * g if P is None else P, D=cfg["hidden_size"], H=cfg["num_heads"],
                   layers=cfg["num_layers"], mlp=cfg["hidden_size"] * cfg["mlp_ratio"], patch_k=3 * ps * ps,
-                  proj=128, vocab=cfg["vocab_size"], dtype=dtype, exact=int(exact))
+                  proj=128, vocab=cfg["vocab_size"], dtype=dtype, exact=int(exact), Pp=g * g)
 
 
 def param_specs(cfg: dict, lay: L.Layout) -> List[Tuple[str, int, Tuple[int, ...]]]:
@@ -81,10 +82,12 @@ EMA_GROUPS = ("text_embeddings", "token_type_embeddings", "transformer", "moco_h
 class PassBuffers:
     """Everything sized by the per-GPU batch B (allocated once, reused every step)."""
 
-    def __init__(self, eng: "Engine", B: int, dtype=None):
+    def __init__(self, eng: "Engine", B: int, dtype=None, P=None):
         dev = eng.device
         self.dtype = eng.dtype if dtype is None else dtype       # arithmetic of the passes run through these buffers
-        d = eng.dims(B, self.dtype)
+        d = eng.dims(B, self.dtype, P)
+        self.geom = None                # RaggedGeometry of a zero-padded batch (None: full-size images, dense patches)
+        self.ragged = None              # the rmcl_ragged struct handed to the encoder passes (own pos_tok / dpos_tok scratch)
         self.B = B
         self.d = d
         N = d.L + 1 + d.P
@@ -116,7 +119,22 @@ class PassBuffers:
         self.nce_ws = u8(lib.rmcl_infonce_ws_bytes(B, I64(eng.num_negative)))
         self.text_ids = None
         self.text_mask = None
+        self.pos_tok = self.dpos_tok = None      # per-sample position rows of a zero-padded batch and their gradient (lazy)
         self.drop = {L.MODE_INFER: (0, 0.0), L.MODE_DATA: (0, 0.0), L.MODE_FULL: (0, 0.0)}
+
+
+class RaggedGeometry:
+    """Patch selection of a zero-padded batch [B,3,Hmax,Wmax] (VisionTransformer.visual_embed, vision_transformer.py:559-651):
+    sel [B, cap] int32 flat patch indices (valid patches row-major, then pads), counts [B], hw [B,2] = (x_h, x_w), n slots."""
+
+    def __init__(self, sel, counts, hw, n, gh, gw, shape):
+        self.sel, self.counts, self.hw, self.n, self.gh, self.gw, self.shape = sel, counts, hw, n, gh, gw, shape
+
+    def take(self, owner: torch.Tensor) -> "RaggedGeometry":
+        """geometry of the batch [owner[0], owner[1], ...] (candidate sentences of the text attack reuse their sample's image)"""
+        return RaggedGeometry(self.sel.index_select(0, owner).contiguous(), self.counts.index_select(0, owner).contiguous(),
+                              self.hw.index_select(0, owner).contiguous(), self.n, self.gh, self.gw,
+                              (int(owner.numel()),) + tuple(self.shape[1:]))
 
 
 class Engine:
@@ -156,23 +174,49 @@ class Engine:
             lib.rmcl_set_side_stream(C.c_void_p(self.dw_stream.cuda_stream))
 
     # ---- geometry ------------------------------------------------------------------------------
-    def dims(self, B: int, dtype=None) -> L.Dims:
+    def dims(self, B: int, dtype=None, P=None) -> L.Dims:
         dt = self.dtype if dtype is None else dtype
-        return make_dims(self.cfg, B, dt, getattr(self, "exact", False) or dt == L.F32)
+        return make_dims(self.cfg, B, dt, getattr(self, "exact", False) or dt == L.F32, P)
 
-    def bufs(self, B: int, tag: str = "moco", dtype=None) -> PassBuffers:
-        """Per-(batch size, objective) buffers: each objective keeps its own FULL stash so that several
+    def bufs(self, B: int, tag: str = "moco", dtype=None, P=None) -> PassBuffers:
+        """Per-(batch size, patches per sample, objective) buffers: each objective keeps its own FULL stash so that several
         task losses of one training_step can be backpropagated after all forwards have run."""
-        if (B, tag) not in self._bufs:
-            self._bufs[(B, tag)] = PassBuffers(self, B, dtype)
-        return self._bufs[(B, tag)]
+        key = (B, tag) if P is None else (B, tag, P)
+        if key not in self._bufs:
+            self._bufs[key] = PassBuffers(self, B, dtype, P)
+        return self._bufs[key]
+
+    def twin(self, pb: PassBuffers, tag: str, dtype=None, owner: torch.Tensor = None) -> PassBuffers:
+        """Buffers of another pass over the SAME images (same patch geometry): the key encoder, another view, the fp32 PGD
+        twin; with `owner` the batch [owner[i]] (text-attack candidates).  Shares nothing but the geometry."""
+        B = pb.B if owner is None else int(owner.numel())
+        geom = pb.geom if (pb.geom is None or owner is None) else pb.geom.take(owner)
+        pv = self.bufs(B, tag, dtype, None if pb.geom is None else pb.geom.n)
+        self._set_geometry(pv, geom)
+        return pv
+
+    def _set_geometry(self, pb: PassBuffers, geom):
+        pb.geom = geom
+        pb.ragged = None
+        if geom is not None:
+            g0 = self.cfg["image_size"] // self.cfg["patch_size"]
+            if pb.pos_tok is None:
+                pb.pos_tok = torch.empty(pb.B, pb.d.P + 1, pb.d.D, dtype=torch.float32, device=self.device)
+                pb.dpos_tok = torch.empty(pb.B, pb.d.P + 1, pb.d.D, dtype=torch.float32, device=self.device)
+            pb.ragged = L.Ragged(sel=geom.sel.data_ptr(), counts=geom.counts.data_ptr(), hw=geom.hw.data_ptr(),
+                                 sel_ld=geom.sel.shape[1], gw=geom.gw, G0=g0, pos_tok=pb.pos_tok.data_ptr(),
+                                 dpos_tok=pb.dpos_tok.data_ptr())
+
+    @staticmethod
+    def _rg(pb: PassBuffers):
+        return C.byref(pb.ragged) if pb.ragged is not None else None
 
     def pgd_bufs(self, pb: PassBuffers) -> PassBuffers:
         """Buffers of the PGD inner loop: `pb` itself, or (pgd_dtype="f32" on a bf16 engine) an fp32 twin that shares the
         batch, the keys and the perturbation buffers with `pb`."""
         if self.pgd_dtype is None or self.pgd_dtype == pb.dtype:
             return pb
-        pp = self.bufs(pb.B, "pgd_f32", self.pgd_dtype)
+        pp = self.twin(pb, "pgd_f32", self.pgd_dtype)
         pp.text_ids, pp.text_mask, pp.patches32 = pb.text_ids, pb.text_mask, pb.patches32
         pp.delta, pp.delta_prev, pp.k = pb.delta, pb.delta_prev, pb.k
         return pp
@@ -199,33 +243,85 @@ class Engine:
         self.g32.zero_()
 
     # ---- per-step data -------------------------------------------------------------------------
-    def bind_batch(self, text_ids: torch.Tensor, text_mask: torch.Tensor, image: torch.Tensor, tag: str = "moco") -> PassBuffers:
-        B, Cc, Hh, Ww = image.shape
+    def patch_geometry(self, img: torch.Tensor, select: torch.Tensor = None):
+        """None for a batch of full-size images (every patch of the image_size x image_size grid valid), else the
+        RaggedGeometry of the zero-padded batch.  One device->host copy of B counts (n sizes the launches).
+        config["dense_images"] = True skips the check for image_size x image_size inputs (synthetic benchmarks)."""
+        B, Cc, Hh, Ww = img.shape
         ps = self.cfg["patch_size"]
-        g = self.cfg["image_size"] // ps
-        if Cc != 3 or Hh != g * ps or Ww != g * ps:
-            raise NotImplementedError(
-                f"dense visual_embed path needs {g * ps}x{g * ps} images (got {Hh}x{Ww}); the ragged "
-                "select/pad path of vision_transformer.py:605-651 is not built yet")
-        pb = self.bufs(B, tag)
+        S = self.cfg["image_size"]
+        if Cc != 3 or Hh % ps or Ww % ps:
+            raise ValueError(f"images must be [B,3,H,W] with H, W multiples of patch_size={ps} (got {tuple(img.shape)}); "
+                             "MinMaxResize of the reference rounds both sides to multiples of 32 (transforms/utils.py:5-26)")
+        if Hh == S and Ww == S and select is None and self.cfg.get("dense_images", False):
+            return None
+        gh, gw = Hh // ps, Ww // ps
+        if gh * gw > 1024:
+            raise ValueError(f"at most 1024 patches per image ({gh}x{gw} given)")
+        sel = torch.empty(B, gh * gw, dtype=torch.int32, device=self.device)
+        counts = torch.empty(B, dtype=torch.int32, device=self.device)
+        hw = torch.empty(B, 2, dtype=torch.int32, device=self.device)
+        check(lib.rmcl_patch_select(P(img), B, 3, Hh, Ww, ps, P(sel), P(counts), P(hw), stream_ptr()), "patch_select")
+        cnt = counts.cpu()
+        if Hh == S and Ww == S and select is None and bool((cnt == gh * gw).all()):
+            return None
+        n = int(cnt.max())
+        mil = self.cfg.get("max_image_len", -1)
+        if isinstance(mil, int) and mil > 0:
+            n = min(n, mil)                                                # vision_transformer.py:602-616
+        if n + 1 + self.cfg["max_text_len"] > 256 and self.dtype == L.BF16:
+            raise NotImplementedError(f"{n} image patches + text exceed the 256-token limit of the fused attention kernels")
+        if select is not None:                                             # the caller's draw (parity tests: the reference's)
+            sel = select.to(self.device, torch.int32).contiguous()
+            assert sel.shape == (B, n), (tuple(sel.shape), (B, n))
+            counts = torch.minimum(counts, torch.full_like(counts, n))
+        else:
+            over = (cnt > n).nonzero().flatten().tolist()
+            for b in over:                                                 # more valid patches than max_image_len: the reference
+                v = int(cnt[b])                                            # keeps a random subset (multinomial w/o replacement, :633-636)
+                keep = torch.multinomial(torch.ones(v).float(), n).to(self.device)
+                sel[b, :n] = sel[b, :v].index_select(0, keep)
+            if over:
+                counts = torch.minimum(counts, torch.full_like(counts, n))
+        return RaggedGeometry(sel, counts, hw, n, gh, gw, (B, 3, Hh, Ww))
+
+    def bind_batch(self, text_ids: torch.Tensor, text_mask: torch.Tensor, image: torch.Tensor, tag: str = "moco",
+                   select: torch.Tensor = None) -> PassBuffers:
+        img = image.to(self.device, torch.float32).contiguous()
+        B, Cc, Hh, Ww = img.shape
+        ps = self.cfg["patch_size"]
+        geom = self.patch_geometry(img, select)
+        pb = self.bufs(B, tag, None, None if geom is None else geom.n)
+        self._set_geometry(pb, geom)
         pb.text_ids = text_ids.to(self.device, torch.int64).contiguous()
         pb.text_mask = text_mask.to(self.device, torch.int64).contiguous()
-        img = image.to(self.device, torch.float32).contiguous()
-        check(lib.rmcl_im2patch_f32(P(img), P(pb.patches32), B, 3, Hh, Ww, ps, 0, stream_ptr()), "im2patch")
+        if geom is None:
+            check(lib.rmcl_im2patch_f32(P(img), P(pb.patches32), B, 3, Hh, Ww, ps, 0, stream_ptr()), "im2patch")
+        else:
+            check(lib.rmcl_im2patch_sel(P(img), P(pb.patches32), P(geom.sel), P(geom.counts), geom.sel.shape[1], B, geom.n, 3, Hh, Ww,
+                                        ps, 0, stream_ptr()), "im2patch_sel")
         return pb
 
     def bind_text(self, like: PassBuffers, text_ids: torch.Tensor, text_mask: torch.Tensor, tag: str) -> PassBuffers:
         """Buffers of another objective/view for the same images (`like.patches32` is shared) with other text."""
-        pv = self.bufs(like.B, tag)
+        pv = self.twin(like, tag)
         pv.text_ids = text_ids.to(self.device, torch.int64).contiguous()
         pv.text_mask = text_mask.to(self.device, torch.int64).contiguous()
         pv.patches32 = like.patches32
         return pv
 
-    def patches_to_image(self, pat: torch.Tensor, B: int) -> torch.Tensor:
-        S = self.cfg["image_size"]
-        out = torch.empty(B, 3, S, S, dtype=torch.float32, device=self.device)
-        check(lib.rmcl_im2patch_f32(P(out), P(pat), B, 3, S, S, self.cfg["patch_size"], 1, stream_ptr()), "patch2im")
+    def patches_to_image(self, pat: torch.Tensor, pb: PassBuffers) -> torch.Tensor:
+        """patch rows (delta, gradients) of `pb`'s batch back to image layout [B,3,H,W] (zero outside the selected patches)."""
+        ps = self.cfg["patch_size"]
+        if pb.geom is None:
+            S = self.cfg["image_size"]
+            out = torch.empty(pb.B, 3, S, S, dtype=torch.float32, device=self.device)
+            check(lib.rmcl_im2patch_f32(P(out), P(pat), pb.B, 3, S, S, ps, 1, stream_ptr()), "patch2im")
+            return out
+        g = pb.geom
+        out = torch.empty(g.shape, dtype=torch.float32, device=self.device)
+        check(lib.rmcl_im2patch_sel(P(out), P(pat), P(g.sel), P(g.counts), g.sel.shape[1], pb.B, g.n, 3, g.shape[2], g.shape[3], ps, 1,
+                                    stream_ptr()), "patch2im_sel")
         return out
 
     def make_operand(self, pb: PassBuffers, d1=None, d2=None, out=None) -> torch.Tensor:
@@ -248,8 +344,8 @@ class Engine:
         p32, plp = (self.k32, self.k_lp) if key else (self.q32, self.q_lp)
         stash = {L.MODE_INFER: None, L.MODE_DATA: pb.stash_data, L.MODE_FULL: pb.stash_full}[mode]
         check(lib.rmcl_encoder_forward(C.byref(pb.d), mode, P(p32), P(plp), P(pb.text_ids), P(pb.text_mask), P(patchesT),
-                                       P(pb.co_mask), P(stash), P(pb.workspace), P(pb.xn), C.c_uint32(seed), F(p), stream_ptr()),
-              "encoder_forward")
+                                       P(pb.co_mask), P(stash), P(pb.workspace), P(pb.xn), C.c_uint32(seed), F(p), self._rg(pb),
+                                       stream_ptr()), "encoder_forward")
 
     def heads_forward(self, pb: PassBuffers, key: bool, want_q: bool = True):
         head = self.k32 if key else self.q32
@@ -274,7 +370,8 @@ class Engine:
         seed, p = pb.drop[mode]
         check(lib.rmcl_encoder_backward(C.byref(pb.d), mode, P(self.q32), P(self.q_lp), P(pb.text_ids), P(patchesT),
                                         P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), int(cls_only), P(dpatches), P(dtext),
-                                        P(self.g32 if mode == L.MODE_FULL else None), C.c_uint32(seed), F(p), stream_ptr()), "encoder_backward")
+                                        P(self.g32 if mode == L.MODE_FULL else None), C.c_uint32(seed), F(p), self._rg(pb), stream_ptr()),
+              "encoder_backward")
 
     def pgd_step(self, pb: PassBuffers, lr: float, eps: float):
         per = pb.d.P * pb.d.patch_k

@@ -206,7 +206,7 @@ def compute_moco_contrastive(pl_module, batch):
     op = eng.make_operand(pb)
     # The momentum-encoder forward (infer_k under no_grad, :262-265) and the clean query forward (:267-275)
     # are independent: they run on two HIP streams so each fills the other's tile-quantisation tails.
-    pk = eng.bufs(B, "key")
+    pk = eng.twin(pb, "key")
     pk.text_ids, pk.text_mask = pb.text_ids, pb.text_mask
     main = torch.cuda.current_stream()
     side = eng.side_stream
@@ -266,7 +266,10 @@ def compute_moco_contrastive(pl_module, batch):
             pl_module.pgd_attacker.attack_patches(pl_module, pb, k)        # compute_pgd (:319-323)
         check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3,
                                           pb.d.patch_k // 3, stream_ptr()), "delta_norm")
-        pl_module.log(f"moco_attack/{phase}/delta", _scalar(pb.loss_sum / float(pb.delta.numel() // 3)))
+        # mean over ALL pixels of the (padded) batch image like torch.linalg.norm(delta, dim=1).mean() (:184); the pad pixels of
+        # a zero-padded batch carry delta = 0 and are not stored in the patch layout
+        n_pix = pb.delta.numel() // 3 if pb.geom is None else pb.B * pb.geom.shape[2] * pb.geom.shape[3]
+        pl_module.log(f"moco_attack/{phase}/delta", _scalar(pb.loss_sum / float(n_pix)))
         # attacked view = img + delta_{K-1} + delta_K  (pgd_attack_vilt.py:144 + objectives.py:176)
         op_att = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pb.patchesT_full)
         loss_i = _attacked_view(pl_module, pb, op_att, k, "img", "PGD_success_rate", prediction_original, ret, phase)

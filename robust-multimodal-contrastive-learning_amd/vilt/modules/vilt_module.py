@@ -213,9 +213,15 @@ class ViLTransformerSS(nn.Module):
         d = pb.d
         N = d.L + 1 + d.P
         x = pb.xn.view(pb.B, N, d.D)
-        g = self.config["image_size"] // self.config["patch_size"]
-        ii, jj = torch.meshgrid(torch.arange(g), torch.arange(g), indexing="ij")
-        patch_index = torch.stack([ii, jj], dim=-1).reshape(1, g * g, 2).expand(pb.B, -1, -1)
+        if pb.geom is None:
+            g = self.config["image_size"] // self.config["patch_size"]
+            ii, jj = torch.meshgrid(torch.arange(g), torch.arange(g), indexing="ij")
+            patch_index = torch.stack([ii, jj], dim=-1).reshape(1, g * g, 2).expand(pb.B, -1, -1)
+            grid_hw = (g, g)
+        else:                                                  # zero-padded batch: (row, col) of every selected slot
+            sel = pb.geom.sel[:, : pb.geom.n].to(torch.int64)
+            patch_index = torch.stack([sel // pb.geom.gw, sel % pb.geom.gw], dim=-1)
+            grid_hw = (pb.geom.gh, pb.geom.gw)
         ret = {
             "text_feats": x[:, : d.L].clone(),
             "image_feats": x[:, d.L:].clone(),
@@ -224,7 +230,7 @@ class ViLTransformerSS(nn.Module):
             "image_masks": pb.co_mask[:, d.L:].to(torch.int64),
             "text_ids": text_ids,
             "text_masks": text_masks,
-            "patch_index": (patch_index, (g, g)),
+            "patch_index": (patch_index, grid_hw),
         }
         if not key:
             ret["image_labels"] = None

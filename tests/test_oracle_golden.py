@@ -10,12 +10,15 @@ from tests.golden_util import cfg_from_meta, digest, load
 torch.set_num_threads(8)
 
 
-@pytest.fixture(scope="module", params=["L2_B4_ragged", "L12_B2"])
+@pytest.fixture(scope="module", params=["L2_B4_ragged", "L12_B2", "L2_B4_raggedimg", "L2_B3_raggedimg2"])
 def moco_case(request):
+    """L2_B4_raggedimg: a zero-padded batch of 384x352 / 320x384 / 384x384 / 224x288 images - per-sample position-embedding
+    resize, valid-patch selection and padding (vision_transformer.py:564-651)."""
     g = load(f"moco_{request.param}.npz")
     cfg, B, sw, sb, ragged = cfg_from_meta(O, g["meta"])
     p = O.init_params(cfg, sw)
-    batch = O.synthetic_batch(cfg, B, sb, ragged_text=ragged)
+    sizes = [tuple(int(v) for v in r) for r in g["sizes"]] if "sizes" in g.files else None
+    batch = O.synthetic_batch(cfg, B, sb, ragged_text=ragged, sizes=sizes)
     queue = O.init_queue(cfg, 0)
     return g, cfg, p, batch, queue
 

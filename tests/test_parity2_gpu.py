@@ -362,3 +362,37 @@ def test_fused_adamw_adam_part_matches_torch():
         topt.step()
         sch["scheduler"].step()
         assert float((eng.q32 - ref.detach()).abs().max()) < 5e-7, it
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# zero-padded batches of smaller images on the bf16 path (N = 173 tokens != 185: ragged row tiles in every GEMM, 11 key
+# tiles + padding in the fused attention, position rows resized per sample)
+# -------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["L2_B4_raggedimg", "L2_B3_raggedimg2"])
+def test_bf16_ragged_images_track_reference_golden(tag):
+    g = load(f"moco_{tag}.npz")
+    ocfg, B, sw, sb, ragged = cfg_from_meta(O, g["meta"])
+    sizes = [tuple(int(v) for v in r) for r in g["sizes"]]
+    m, p = make_module(ocfg, sw, "bf16")
+    batch = O.synthetic_batch(ocfg, B, sb, ragged_text=ragged, sizes=sizes)
+    r = m.infer(dev_batch(batch))
+    e_cls = float((r["cls_feats"].cpu() - torch.from_numpy(g["cls_feats"])).abs().max())
+    np.testing.assert_array_equal(r["image_masks"].cpu().numpy(), g["image_masks"])
+    valid = torch.from_numpy(g["image_masks"]) == 1
+    e_img = float((r["image_feats"].cpu() - torch.from_numpy(g["image_feats"]))[valid].abs().max())
+    assert e_cls < 3e-2 and e_img < 0.1, (e_cls, e_img)
+    m.zero_grad()
+    loss = m.training_step(dev_batch(batch), 0)
+    e_loss = abs(float(loss) - float(g["moco_loss"]))
+    assert e_loss < 0.25, e_loss
+    loss.backward()
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for nm, dg in zip(g["grad_names"], g["grad_digest"]):
+        if str(nm).startswith("itm_score"):
+            continue
+        mine = digest(params[str(nm)].grad)
+        worst = max(worst, abs(mine[1] - dg[1]) / max(dg[1], 1e-6))
+    assert worst < 0.12, worst
+    record(f"bf16_{tag}", cls=e_cls, image_feats=e_img, loss=e_loss, grad_norm_rel_worst=worst)

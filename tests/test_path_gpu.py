@@ -40,12 +40,15 @@ def dev_batch(batch):
             for k, v in batch.items()}
 
 
-@pytest.fixture(scope="module", params=["L2_B4_ragged", "L12_B2"])
+@pytest.fixture(scope="module", params=["L2_B4_ragged", "L12_B2", "L2_B4_raggedimg", "L2_B3_raggedimg2"])
 def case(request):
+    """L2_B4_raggedimg: zero-padded batch of 384x352 / 320x384 / 384x384 / 224x288 images (reference: per-sample position-
+    embedding resize + valid-patch selection / padding, vision_transformer.py:564-651) - the on-device ragged visual_embed."""
     g = load(f"moco_{request.param}.npz")
     ocfg, B, sw, sb, ragged = cfg_from_meta(O, g["meta"])
     m, p = build_module(ocfg, sw, "f32")
-    batch = O.synthetic_batch(ocfg, B, sb, ragged_text=ragged)
+    sizes = [tuple(int(v) for v in r) for r in g["sizes"]] if "sizes" in g.files else None
+    batch = O.synthetic_batch(ocfg, B, sb, ragged_text=ragged, sizes=sizes)
     return g, ocfg, m, p, batch
 
 
@@ -56,7 +59,14 @@ def test_infer_matches_reference_golden(case):
     np.testing.assert_allclose(r["raw_cls_feats"].cpu().numpy(), g["raw_cls_feats"], atol=2e-4)
     np.testing.assert_allclose(r["text_feats"].cpu().numpy(), g["text_feats"], atol=2e-4)
     np.testing.assert_allclose(r["image_feats"].cpu().numpy(), g["image_feats"], atol=2e-4)
-    assert r["image_masks"].shape == (batch["text_ids"].shape[0], 145) and bool((r["image_masks"] == 1).all())
+    if "image_masks" in g.files:                             # zero-padded batch: masks and the selected (row, col) of every valid slot
+        np.testing.assert_array_equal(r["image_masks"].cpu().numpy(), g["image_masks"])
+        pi, (gh, gw) = r["patch_index"]
+        flat = (pi[..., 0] * gw + pi[..., 1]).cpu().numpy()
+        valid = g["image_masks"][:, 1:] == 1
+        np.testing.assert_array_equal(flat[valid], g["patch_index_flat"][valid])
+    else:
+        assert r["image_masks"].shape == (batch["text_ids"].shape[0], 145) and bool((r["image_masks"] == 1).all())
     rk = m.infer_k(dev_batch(batch))                         # momentum copies == query weights at init
     np.testing.assert_allclose(rk["cls_feats"].cpu().numpy(), g["cls_feats"], atol=1e-4)
 
