@@ -62,6 +62,20 @@ typedef struct rmcl_ragged {
   float* dpos_tok;         /* scratch [B, P+1, D] f32: their gradient (backward, mode FULL)                          */
 } rmcl_ragged;
 
+/* LayerNorm folded into the GEMM that consumes it (forward passes that keep no LayerNorm output: INFER and DATA mode, bf16,
+ * dropout off): y = LN(x) W^T + b = rstd * (bf16(x) W'^T - mean * s) + c.  rmcl_ln_fold derives, from an fp32 arena,
+ *   wf [layers][3D + mlp][D] bf16 : W' = W * gamma for qkv (norm1) then fc1 (norm2)
+ *   sc [layers][2][3D + mlp] f32  : s = row sums of W', c = W beta + bias
+ * and must be re-run whenever that arena changes (optimizer step, momentum update, checkpoint load).  Passing the pair to
+ * rmcl_encoder_forward removes the 2 LayerNorm launches per layer (the producer GEMMs emit the bf16 copy of the residual
+ * stream and per-row partial sums in their epilogues); NULL keeps the separate LayerNorm kernels.                       */
+typedef struct rmcl_fold {
+  const void* wf;
+  const float* sc;
+} rmcl_fold;
+int64_t rmcl_ln_fold_elems(const rmcl_dims* d, int which);   /* which = 0: elements of wf (bf16), 1: elements of sc (f32) */
+int rmcl_ln_fold(const rmcl_dims* d, const float* params32, void* wf, float* sc, void* stream);
+
 /* Element offsets into a parameter arena.  Names follow the reference state dict. */
 typedef struct rmcl_layout {
   int64_t word, pos, btype, eln_w, eln_b;      /* text_embeddings.{word,position,token_type}_embeddings, LayerNorm */
@@ -141,7 +155,7 @@ int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* ou
 int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
                          const int64_t* text_ids, const int64_t* text_mask, const void* patches,
                          int32_t* co_mask, void* stash, void* workspace, float* xn,
-                         uint32_t drop_seed, float drop_p, const rmcl_ragged* ragged, void* stream);
+                         uint32_t drop_seed, float drop_p, const rmcl_ragged* ragged, const rmcl_fold* fold, void* stream);
 
 /* Backward of the above.  dxn: gradient wrt xn, [B*N,D] f32, or [B,D] (row 0 of every sample)
  * when cls_only=1.  dpatches (optional) receives d loss/d patches [B*P,patch_k] in `dtype`

@@ -106,10 +106,12 @@ int rmcl_dropout_mask_apply(float* x, int64_t n, uint32_t drop_seed, int layer, 
 extern int g_st_reserve_cus;
 extern bool g_attn_fused_bwd;
 extern bool g_dw_grouped;
+extern int g_attn_fwd_waves;
 int rmcl_tune_set(int key, int value) {
   if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }
   if (key == 1) { g_st_reserve_cus = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }   // CUs left free by the activation GEMMs
   if (key == 2) { g_attn_fused_bwd = value != 0; return 0; }                                    // 0: two-kernel attention backward
+  if (key == 4) { g_attn_fwd_waves = value; return 0; }                                          // waves per workgroup of the attention forward
   if (key == 3) { g_dw_grouped = value != 0; return 0; }                                        // 0: per-GEMM weight gradients (split-K slabs)
   rmcl_set_error("tune_set: unknown key");
   return -1;
@@ -212,6 +214,17 @@ int rmcl_heads_backward(const rmcl_dims* d, const float* pool32, const float* he
 
 int rmcl_im2patch_f32(const float* img, float* patches, int B, int C, int Hh, int Ww, int ps, int to_image, void* stream) {
   return rmcl_im2patch(img, patches, B, C, Hh, Ww, ps, to_image, (hipStream_t)stream);
+}
+int64_t rmcl_ln_fold_elems(const rmcl_dims* d, int which) {
+  const int64_t rows = 3 * (int64_t)d->D + d->mlp;
+  return which == 0 ? (int64_t)d->layers * rows * d->D : (int64_t)d->layers * 2 * rows;
+}
+int rmcl_ln_fold(const rmcl_dims* d, const float* params32, void* wf, float* sc, void* stream) {
+  RMCL_REQUIRE(d && params32 && wf && sc, "ln_fold: NULL argument");
+  rmcl_layout y;
+  rmcl_param_layout(d, &y);
+  return rmcl_ln_fold_launch(params32, y.layer0, y.layer_stride, d->layers, y.ln1_w, y.ln1_b, y.qkv_w, y.qkv_b, y.ln2_w, y.ln2_b, y.fc1_w,
+                             y.fc1_b, d->D, d->mlp, (unsigned short*)wf, sc, (hipStream_t)stream);
 }
 int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, int32_t* sel, int32_t* counts, int32_t* hw, void* stream) {
   RMCL_REQUIRE(img && sel && counts && hw, "patch_select: NULL argument");

@@ -25,7 +25,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define SCALE_L2 (SCALE * LOG2E)   // scores are kept in the log2 domain: v_exp_f32 is exp2, so exp(s - m) costs one subtract + one v_exp
-#define ATT_QW 8            // waves per workgroup of the forward kernel: 12 query tiles -> 1-2 per wave
+int g_attn_fwd_waves = 8;    // waves per workgroup of the forward kernel (rmcl_tune_set key 4: 6, 8 or 12): 12 query tiles -> 1-2 per wave
 #define ATT_DQW 8           // dQ kernel: its 96 score/dP accumulators + hoisted fragments need > 256 VGPRs, so one wave per SIMD
 
 // ---- staging: rows [0,N) of a [*, 64] bf16 slice (row pitch ld elements) -> LDS image of NKP rows x 128 B
@@ -106,7 +106,7 @@ __device__ __forceinline__ void fill_maskbias(float* mb, const int* __restrict__
 }
 
 // ================================================================================== forward
-template <int NKT>
+template <int NKT, int ATT_QW>
 __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
                                                        bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
@@ -545,12 +545,18 @@ static inline int nkt_for(int N) { return N <= 64 ? 4 : N <= 128 ? 8 : N <= 192 
 
 long rmcl_attn_stat_elems(int B, int H, int N) { return (long)B * H * nkt_for(N) * 16; }
 
-template <int NKT> static int launch_fwd(const bf16_t* qkv, const int* mask, bf16_t* out, float* lse, int B, int N, int H, hipStream_t s) {
+template <int NKT, int QW> static int launch_fwd_w(const bf16_t* qkv, const int* mask, bf16_t* out, float* lse, int B, int N, int H, hipStream_t s) {
   const size_t lds = (size_t)2 * NKT * 16 * 128 + NKT * 16 * 4;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  RMCL_LAUNCH(attn_fwd_kernel<NKT>, dim3(B * H), dim3(ATT_QW * 64), lds, s, qkv, mask, out, lse, N, H);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>((attn_fwd_kernel<NKT, QW>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RMCL_LAUNCH((attn_fwd_kernel<NKT, QW>), dim3(B * H), dim3(QW * 64), lds, s, qkv, mask, out, lse, N, H);
   RMCL_CHECK_LAUNCH();
   return 0;
+}
+template <int NKT> static int launch_fwd(const bf16_t* qkv, const int* mask, bf16_t* out, float* lse, int B, int N, int H, hipStream_t s) {
+  if (g_attn_fwd_waves == 6) return launch_fwd_w<NKT, 6>(qkv, mask, out, lse, B, N, H, s);
+  if (g_attn_fwd_waves == 12) return launch_fwd_w<NKT, 12>(qkv, mask, out, lse, B, N, H, s);
+  if (g_attn_fwd_waves == 4) return launch_fwd_w<NKT, 4>(qkv, mask, out, lse, B, N, H, s);
+  return launch_fwd_w<NKT, 8>(qkv, mask, out, lse, B, N, H, s);
 }
 bool g_attn_fused_bwd = true;        // rmcl_tune_set key 2: 0 selects the two-kernel backward (A/B and parity tests)
 

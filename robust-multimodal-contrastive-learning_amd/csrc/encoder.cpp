@@ -50,6 +50,8 @@ struct Work {
   float *dx, *dln, *dxn_full, *de;
   void *dxT, *du, *dqkv, *dao, *dS, *dpe;
   void *dxT2, *du2, *dqkv2;   // second copies: weight-gradient GEMMs read them on the side stream
+  void *xb_in, *xb_mid;   // LayerNorm fold: bf16 copies of the residual stream (block input / after attention)
+  float *part_in, *part_mid;   // and the per-row partial sums [M][16][2] the producer GEMMs emit
   void* dxT3;         // third dx copy (grouped weight gradients: one launch per layer reads both of the layer's dx copies)
   float* ln_rep;      // LayerNorm dgamma/dbeta replica slots (2 * layers + 1), summed into the arena by the grouped kernel
   float* slab;        // split-K partial slabs of the weight-gradient GEMMs
@@ -124,6 +126,10 @@ size_t carve_work(const rmcl_dims& d, void* base, Work* w) {
   k.du2 = b.take_bytes(M * d.mlp * e);
   k.dqkv2 = b.take_bytes(M * 3 * D * e);
   k.dxT3 = b.take_bytes(M * D * e);
+  k.xb_in = b.take_bytes(M * D * 2);
+  k.xb_mid = b.take_bytes(M * D * 2);
+  k.part_in = b.take<float>(M * 2 * 4 * (D / 192 + 1));
+  k.part_mid = b.take<float>(M * 2 * 4 * (D / 192 + 1));
   k.ln_rep = b.take<float>((size_t)(2 * d.layers + 1) * RMCL_LN_REP_FLOATS);
   if (w) *w = k;
   return b.off;
@@ -334,7 +340,7 @@ int64_t rmcl_workspace_bytes(const rmcl_dims* d) { return (int64_t)carve_work(*d
 
 int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
                          const int64_t* text_mask, const void* patches, int32_t* co_mask, void* stash, void* workspace,
-                         float* xn, uint32_t drop_seed, float drop_p, const rmcl_ragged* ragged, void* stream) {
+                         float* xn, uint32_t drop_seed, float drop_p, const rmcl_ragged* ragged, const rmcl_fold* fold, void* stream) {
   RMCL_TRY(check_dims(d));
   RMCL_REQUIRE(!ragged || (ragged->sel && ragged->counts && ragged->hw && ragged->pos_tok), "encoder_forward: incomplete rmcl_ragged");
   RMCL_REQUIRE(ragged || d->Pp == 0 || d->Pp == d->P, "encoder_forward: P != Pp needs the rmcl_ragged selection");
@@ -377,6 +383,23 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
                                    rmcl_site_seed(drop_seed, 0, DROP_SITE_IMAGE), dth, dinv, ragged ? 1 : 0, s));
   RMCL_TRY(rmcl_co_mask((const long*)text_mask, patches, dt, co_mask, B, L, P, 3, d->patch_k / 3, s));
 
+  // LayerNorm folded into the consuming GEMMs (gemm.h EPI_LNFOLD / EPI_ROWSTAT): passes that keep no LayerNorm output
+  // (INFER, DATA), bf16, dropout off, and only where every GEMM involved runs on the 192-row tile kernels
+  bool folded = fold && fold->wf && fold->sc && !full && dt == RMCL_BF16 && !d->exact && dth == 0 && D % 192 == 0;
+  const int fold_rows = 3 * D + d->mlp, nparts = 4 * (D / 192);
+  if (folded) {
+    GemmArgs t1 = gemm_args(w.xb_in, fold->wf, w.qkv, M, 3 * D, D, D, D, 3 * D);
+    t1.epi = EPI_LNFOLD; t1.ln_s = fold->sc; t1.ln_c = fold->sc; t1.ln_part = w.part_in; t1.ln_nparts = nparts; t1.ln_cols = D;
+    GemmArgs t2 = gemm_args(w.xb_mid, fold->wf, w.h, M, d->mlp, D, D, D, d->mlp);
+    t2.epi = EPI_LNFOLD | EPI_GELU | EPI_SAVE_PREACT; t2.C2 = w.u; t2.ln_s = fold->sc; t2.ln_c = fold->sc; t2.ln_part = w.part_mid; t2.ln_nparts = nparts; t2.ln_cols = D;
+    GemmArgs t3 = gemm_args(w.ao, c.W(c.L(0, y.proj_w)), w.x_mid, M, D, D, D, D, D);
+    t3.epi = EPI_BIAS | EPI_RESIDUAL | EPI_ROWSTAT; t3.bias = c.V(y.norm_b); t3.aux = w.x_a; t3.ld_aux = D; t3.C2 = w.xb_mid; t3.ln_part = w.part_mid; t3.ln_nparts = nparts;
+    GemmArgs t4 = gemm_args(w.h, c.W(c.L(0, y.fc2_w)), w.x_a, M, D, d->mlp, d->mlp, d->mlp, D);
+    t4.epi = t3.epi; t4.bias = t3.bias; t4.aux = w.x_mid; t4.ld_aux = D; t4.C2 = w.xb_in; t4.ln_part = w.part_in; t4.ln_nparts = nparts;
+    folded = rmcl_gemm_routes_to_tile192(t1, 1, 1) && rmcl_gemm_routes_to_tile192(t2, 1, 1) && rmcl_gemm_routes_to_tile192(t3, 1, 1) &&
+             rmcl_gemm_routes_to_tile192(t4, 1, 1);
+  }
+  const bf16_t* fw = folded ? (const bf16_t*)fold->wf : nullptr;
   float* x = x0;
   for (int l = 0; l < d->layers; ++l) {
     LayerStash ls{};
@@ -392,9 +415,17 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     void* ao = keep ? ls.ao : w.ao;
     void* h = full ? ls.h : w.h;
     void* u = keep ? ls.u : nullptr;
+    const float* sc_l = folded ? fold->sc + (long)l * 2 * fold_rows : nullptr;        // s[0..rows), c[rows..2 rows)
 
-    RMCL_TRY(rmcl_ln_fwd(x, D, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), 1e-6f, ln1, D, dt, m1, r1, M, D, 0, s));
-    {
+    if (folded && l > 0) {
+      // qkv = LN1(x) Wqkv^T + b: A = the bf16 copy of x the previous fc2 epilogue wrote, row statistics from its partial sums
+      GemmArgs g = gemm_args(w.xb_in, fw + (long)l * fold_rows * D, qkv, M, 3 * D, D, D, D, 3 * D);
+      g.epi = EPI_LNFOLD; g.tag = GEMM_TAG_QKV;
+      g.ln_s = sc_l; g.ln_c = sc_l + fold_rows; g.ln_part = w.part_in; g.ln_nparts = nparts; g.ln_cols = D; g.ln_eps = 1e-6f;
+      g.ln_mean = keep ? m1 : nullptr; g.ln_rstd = keep ? r1 : nullptr;
+      RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
+    } else {
+      RMCL_TRY(rmcl_ln_fwd(x, D, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), 1e-6f, ln1, D, dt, m1, r1, M, D, 0, s));
       GemmArgs g = gemm_args(ln1, c.W(c.L(l, y.qkv_w)), qkv, M, 3 * D, D, D, D, 3 * D);
       g.epi = EPI_BIAS; g.bias = c.V(c.L(l, y.qkv_b)); g.tag = GEMM_TAG_QKV;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
@@ -403,11 +434,18 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     {
       GemmArgs g = gemm_args(ao, c.W(c.L(l, y.proj_w)), x_mid, M, D, D, D, D, D);
       g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = D; g.tag = GEMM_TAG_PROJ;
+      if (folded) { g.epi |= EPI_ROWSTAT; g.C2 = w.xb_mid; g.ln_part = w.part_mid; g.ln_nparts = nparts; }
       with_drop(g, l, DROP_SITE_PROJ);
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
     }
-    RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2, D, dt, m2, r2, M, D, 0, s));
-    {
+    if (folded) {
+      GemmArgs g = gemm_args(w.xb_mid, fw + ((long)l * fold_rows + 3 * D) * D, h, M, d->mlp, D, D, D, d->mlp);
+      g.epi = EPI_LNFOLD | EPI_GELU | (u ? EPI_SAVE_PREACT : 0); g.C2 = u; g.tag = GEMM_TAG_FC1;
+      g.ln_s = sc_l + 3 * D; g.ln_c = sc_l + fold_rows + 3 * D; g.ln_part = w.part_mid; g.ln_nparts = nparts; g.ln_cols = D; g.ln_eps = 1e-6f;
+      g.ln_mean = keep ? m2 : nullptr; g.ln_rstd = keep ? r2 : nullptr;
+      RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
+    } else {
+      RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2, D, dt, m2, r2, M, D, 0, s));
       GemmArgs g = gemm_args(ln2, c.W(c.L(l, y.fc1_w)), h, M, d->mlp, D, D, D, d->mlp);
       g.epi = EPI_BIAS | EPI_GELU | (u ? EPI_SAVE_PREACT : 0); g.bias = c.V(c.L(l, y.fc1_b)); g.C2 = u; g.tag = GEMM_TAG_FC1;
       with_drop(g, l, DROP_SITE_HIDDEN);
@@ -416,6 +454,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     {
       GemmArgs g = gemm_args(h, c.W(c.L(l, y.fc2_w)), x_out, M, D, d->mlp, d->mlp, d->mlp, D);
       g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.fc2_b)); g.aux = x_mid; g.ld_aux = D; g.tag = GEMM_TAG_FC2;
+      if (folded && l + 1 < d->layers) { g.epi |= EPI_ROWSTAT; g.C2 = w.xb_in; g.ln_part = w.part_in; g.ln_nparts = nparts; }
       with_drop(g, l, DROP_SITE_FC2);
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
     }

@@ -25,6 +25,11 @@ enum {
   EPI_COLSUM = 256,
   EPI_DROPOUT = 512,    // dropout on the result (after bias / GELU, before the residual add): mask(drop_seed, m*ldc+n)
   EPI_DROP_BWD = 1024,  // with EPI_DGELU: also multiply by the forward dropout mask of the hidden activation     // TN only: blocks with blockIdx.y==0 atomically add column sums of A (= bias grad) into bias_grad[m]
+  // LayerNorm folded into the GEMM that consumes it (bf16 192x192 / 192x384 kernels only, N_in = ln_cols):
+  //   y = LN(x) W^T + b  =  rstd_m * (bf16(x) W'^T - mean_m * s_n) + c_n,  W' = W * gamma (columns), s_n = sum_k W'_nk, c_n = W beta + b
+  EPI_LNFOLD = 2048,    // consumer: A = bf16 copy of the residual stream, B = W'; row statistics from ln_part; per-column ln_s / ln_c
+  EPI_ROWSTAT = 4096,   // producer (fp32 output = the residual stream): also store its bf16 copy to C2 and per-row partial
+                        // (sum, sum of squares) of this tile's columns to ln_part[m][tile_n * 4 + wave column]
 };
 
 enum {
@@ -51,6 +56,15 @@ struct GemmArgs {
   int tag;                // profiling class (GEMM_TAG_*), 0 = untagged
   uint32_t drop_seed, drop_thresh;   // dropout site seed, p * 2^32
   float drop_inv_keep;               // 1 / (1 - p)
+  // LayerNorm fold (EPI_LNFOLD / EPI_ROWSTAT)
+  const float* ln_s;                 // [N] column sums of W'
+  const float* ln_c;                 // [N] W beta + bias
+  float* ln_part;                    // [M][ln_nparts][2] partial (sum, sum of squares) of the LN input rows
+  float* ln_mean;                    // consumer, optional: [M] mean / rstd written by the tile_n == 0 tiles (stash for the backward)
+  float* ln_rstd;
+  int ln_nparts;                     // partials per row (4 per 192-column tile of the producer)
+  int ln_cols;                       // row width of the LN input (768)
+  float ln_eps;
 };
 
 #ifdef __cplusplus

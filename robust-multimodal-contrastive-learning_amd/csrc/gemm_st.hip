@@ -286,9 +286,12 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
 // the tile's last k-tile, which nothing reads any more and the next tile's DMA overwrites only two phases later.
 // Barriers: s_barrier is workgroup-wide, the two groups stand at different epilogue steps when it releases (they run one
 // barrier apart), and both execute the same number (2 + 2 * chunks), so the skew survives the epilogue.
-template <int AUX, typename TO, bool DROP>
+// LNF = 1: LayerNorm-folded consumer (EPI_LNFOLD): v = rstd_m * (acc - mean_m * s_n) + c_n, row statistics from the
+//          producer's partials (this group's 96 rows, one thread each, into `rowstat`: 192 x (mean, rstd) in LDS)
+// LNF = 2: producer (EPI_ROWSTAT): bf16 copy of the fp32 output + per-row partial sums of this wave's 48 columns
+template <int AUX, typename TO, bool DROP, int LNF = 0>
 __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const GemmArgs& g, const STTile& T, int wm, int wn, int lane, int wave,
-                                                char* scratch) {
+                                                char* scratch, float* rowstat = nullptr) {
   constexpr int ESZ = sizeof(TO), RI = ESZ == 2 ? 3 : 2, NCH = 6 / RI, ROWS = RI * 16, ROWB = 192 * ESZ, PIECES = ROWB / 16;
   const int epi = g.epi;
   TO* C = reinterpret_cast<TO*>(g.C) + T.zoff;
@@ -296,9 +299,32 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
   asm volatile("" : "+v"(lane));
   const int nb = T.n0 + wn * 48 + 4 * (lane >> 4);
   const int mb = T.m0 + wm * 96 + (lane & 15);
-  float4 bias[3];
+  float4 bias[3], lns[LNF == 1 ? 3 : 1];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j = 0; j < 3; ++j) {
+    if constexpr (LNF == 1) {
+      bias[j] = *reinterpret_cast<const float4*>(g.ln_c + nb + j * 16);
+      lns[j] = *reinterpret_cast<const float4*>(g.ln_s + nb + j * 16);
+    } else {
+      bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if constexpr (LNF == 1) {
+    const int tgs = (wave & 3) * 64 + lane;
+    if (tgs < 96) {
+      const int row = wm * 96 + tgs;
+      const long m = min(T.m0 + row, g.M - 1);
+      const float4* pp = reinterpret_cast<const float4*>(g.ln_part + m * (long)(g.ln_nparts * 2));
+      float s1 = 0.f, s2 = 0.f;
+      for (int q = 0; q < g.ln_nparts / 2; ++q) { const float4 v = pp[q]; s1 += v.x + v.z; s2 += v.y + v.w; }
+      const float inv = 1.0f / (float)g.ln_cols, mean = s1 * inv;
+      const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + g.ln_eps);
+      rowstat[2 * row] = mean;
+      rowstat[2 * row + 1] = rstd;
+      if (T.n0 == 0 && g.ln_mean && T.m0 + row < T.m_end) { g.ln_mean[m] = mean; g.ln_rstd[m] = rstd; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();                              // the other group's last reads of this stage have retired
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -318,10 +344,19 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       const int i = ch * RI + il;
       const int m = mb + i * 16;
       const bool live = m < T.m_end;
+      float mean_m = 0.f, rstd_m = 1.f, ps1 = 0.f, ps2 = 0.f;
+      if constexpr (LNF == 1) {
+        const float2 ms = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
+        mean_m = ms.x; rstd_m = ms.y;
+      }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float v[4] = {g.alpha * acc[i][j][0] + bias[j].x, g.alpha * acc[i][j][1] + bias[j].y, g.alpha * acc[i][j][2] + bias[j].z,
                       g.alpha * acc[i][j][3] + bias[j].w};
+        if constexpr (LNF == 1) {
+          v[0] = fmaf(rstd_m, acc[i][j][0] - mean_m * lns[j].x, bias[j].x); v[1] = fmaf(rstd_m, acc[i][j][1] - mean_m * lns[j].y, bias[j].y);
+          v[2] = fmaf(rstd_m, acc[i][j][2] - mean_m * lns[j].z, bias[j].z); v[3] = fmaf(rstd_m, acc[i][j][3] - mean_m * lns[j].w, bias[j].w);
+        }
         if (DROP && (epi & EPI_DROP_BWD)) {
           const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
 #pragma unroll
@@ -343,6 +378,10 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
           for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, (uint32_t)ci + r, g.drop_thresh, g.drop_inv_keep);
         }
         if (AUX == ST_AUX_RES) { v[0] += res[il][j].x; v[1] += res[il][j].y; v[2] += res[il][j].z; v[3] += res[il][j].w; }
+        if constexpr (LNF == 2) {
+          ps1 += (v[0] + v[1]) + (v[2] + v[3]);
+          ps2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
         // image: row il*16 + lane%16, element column wn*48 + j*16 + 4*(lane/16); 16-byte chunk index XOR (row & 7)
         const int row = il * 16 + (lane & 15);
         if constexpr (ESZ == 2) {
@@ -356,6 +395,12 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
           const int c16 = (wn * 12 + j * 4 + (lane >> 4)) ^ (row & 7);
           *reinterpret_cast<float4*>(scratch + row * ROWB + c16 * 16) = make_float4(v[0], v[1], v[2], v[3]);
         }
+      }
+      if constexpr (LNF == 2) {                                // this wave's 48 columns of row m: sum over the 4 lane groups
+        ps1 += __shfl_xor(ps1, 16, 64); ps1 += __shfl_xor(ps1, 32, 64);
+        ps2 += __shfl_xor(ps2, 16, 64); ps2 += __shfl_xor(ps2, 32, 64);
+        if (lane < 16 && live)
+          *reinterpret_cast<float2*>(g.ln_part + ((long)m * g.ln_nparts + (T.n0 / ST_T) * 4 + wn) * 2) = make_float2(ps1, ps2);
       }
     }
     __builtin_amdgcn_s_barrier();                            // the group's image of this chunk is complete
@@ -377,6 +422,12 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
             *reinterpret_cast<float4*>(dst) = o;
+            if constexpr (LNF == 2) {                          // bf16 copy of the residual stream: the next GEMM's A operand
+              uint2 pk;
+              pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
+              pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+              *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C2) + (long)m * g.ldc + T.n0 + (cp ^ (row & 7)) * 4) = pk;
+            }
           } else {
             *reinterpret_cast<float4*>(dst) = w;
           }
@@ -388,7 +439,7 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
   __builtin_amdgcn_s_barrier();                              // the OTHER group (one barrier behind) has consumed its last image too:
 }                                                            // the next tile's LDS-DMA may now target this stage
 
-template <bool A_KC, bool B_KC, int AUX, typename TO, bool DROP, int PH>
+template <bool A_KC, bool B_KC, int AUX, typename TO, bool DROP, int PH, int LNF = 0>
 __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile, int xflags) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -472,7 +523,8 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
     }
     // the stage the tile's last k-tile was read from (sc has already moved on when the stream continues): 24 KiB per group
     const int s_free = nid >= 0 ? (sc == 0 ? 2 : sc - 1) : sc;
-    st_epilogue_lds<AUX, TO, DROP>(acc, g, cur, wm, wn, lane, wave, smem + s_free * ST_STAGE + wm * (ST_STAGE / 2));
+    st_epilogue_lds<AUX, TO, DROP, LNF>(acc, g, cur, wm, wn, lane, wave, smem + s_free * ST_STAGE + wm * (ST_STAGE / 2),
+                                        reinterpret_cast<float*>(smem + ST_LDS));
     if (nid < 0) break;
     cur = nxt;
   }
@@ -640,8 +692,15 @@ bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
     if (b_kc || g.M % ST_T != 0 || (g.epi & ~EPI_ACCUM)) return false;
     return true;
   }
-  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_ACCUM | EPI_DROPOUT | EPI_DROP_BWD)) return false;
+  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_ACCUM | EPI_DROPOUT | EPI_DROP_BWD | EPI_LNFOLD | EPI_ROWSTAT)) return false;
   if ((g.epi & EPI_RESIDUAL) && (g.epi & EPI_DGELU)) return false;
+  if (g.epi & EPI_LNFOLD) {                                       // consumer: plain bias-less bf16 GEMM on [rows][K] x [cols][K]
+    if (!b_kc || (g.epi & ~EPI_LNFOLD) || !g.ln_s || !g.ln_c || !g.ln_part || g.ln_nparts % 2 || g.ln_nparts <= 0 || g.ln_cols <= 0) return false;
+  }
+  if (g.epi & EPI_ROWSTAT) {                                      // producer: fp32 residual-stream output of [rows][K] x [cols][K]
+    if (!b_kc || (g.epi & ~(EPI_ROWSTAT | EPI_BIAS | EPI_RESIDUAL)) || !(g.epi & EPI_RESIDUAL) || !g.ln_part || !g.C2 || g.ln_nparts != 4 * (g.N / ST_T))
+      return false;
+  }
   return true;
 }
 
@@ -698,7 +757,30 @@ static int launch_st(const GemmArgs& g, int dt_out, hipStream_t s) {
   return launch_st2<B_KC, ST_AUX_NONE>(g, dt_out, s);
 }
 
+template <int AUX, typename TO, int LNF>
+static int launch_st_lnf(const GemmArgs& g, hipStream_t s) {
+  static bool attr = false;
+  constexpr int LDS = ST_LDS + (LNF == 1 ? 2048 : 0);
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_st_kernel<true, true, AUX, TO, false, 2, LNF>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = cdiv(g.M, tm);
+  const int grid = min(tm * tn, max(8, st_num_cus() - g_st_reserve_cus));
+  RMCL_LAUNCH((gemm_st_kernel<true, true, AUX, TO, false, 2, LNF>), dim3(grid), dim3(512), LDS, s, g, tm, tn, rows, g_st_xflags);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
 int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s) {
+  if (g.epi & EPI_LNFOLD) {
+    RMCL_REQUIRE(a_kc && b_kc && dt_out == RMCL_BF16, "gemm_st: the LayerNorm-folded form is [rows][K] x [cols][K] with bf16 output");
+    return launch_st_lnf<ST_AUX_NONE, bf16_t, 1>(g, s);
+  }
+  if (g.epi & EPI_ROWSTAT) {
+    RMCL_REQUIRE(a_kc && b_kc && dt_out == RMCL_F32, "gemm_st: the row-statistics producer writes the fp32 residual stream");
+    return launch_st_lnf<ST_AUX_RES, float, 2>(g, s);
+  }
   if (!a_kc) {
     RMCL_REQUIRE(dt_out == RMCL_F32 && !b_kc, "gemm_st: the [K][M] x [K][N] form writes fp32");
     return launch_st3<false, false, ST_AUX_NONE, float>(g, s);

@@ -174,7 +174,9 @@ __device__ __forceinline__ void sw_store4(TO* p, const float (&v)[4]) {
   }
 }
 
-template <bool B_KC, int AUX, typename TO>
+// LNF = 1: LayerNorm folded into this GEMM (EPI_LNFOLD, gemm.h): A = bf16 copy of the residual stream, B = W * gamma;
+// v = rstd_m * (acc - mean_m * s_n) + c_n with the row statistics summed from the producer's partials into LDS.
+template <bool B_KC, int AUX, typename TO, int LNF = 0>
 __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -288,14 +290,37 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     // image in the other one)
     char* img = AUX_LDS ? last_cur + wm * IMG : smem + wm * (2 * IMG);
     const bool stash = !AUX_LDS && (epi & EPI_SAVE_PREACT) != 0;
+    float* rowstat = reinterpret_cast<float*>(smem + SW_LDS);  // LNF: 192 x (mean, rstd), beyond the two operand buffers
+    if constexpr (LNF == 1) {
+      if (t < 192) {
+        const long m = min(m0 + t, g.M - 1);
+        const float4* pp = reinterpret_cast<const float4*>(g.ln_part + m * (long)(g.ln_nparts * 2));
+        float s1 = 0.f, s2 = 0.f;
+        for (int q = 0; q < g.ln_nparts / 2; ++q) { const float4 v = pp[q]; s1 += v.x + v.z; s2 += v.y + v.w; }
+        const float inv = 1.0f / (float)g.ln_cols, mean = s1 * inv;
+        const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + g.ln_eps);
+        rowstat[2 * t] = mean;
+        rowstat[2 * t + 1] = rstd;
+        if (n0 == 0 && g.ln_mean && m0 + t < m_end) { g.ln_mean[m] = mean; g.ln_rstd[m] = rstd; }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
-        float4 bias[3];
+        float4 bias[3], lns[LNF == 1 ? 3 : 1];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 3; ++j) {
+          if constexpr (LNF == 1) {
+            bias[j] = *reinterpret_cast<const float4*>(g.ln_c + nb + j * 16);
+            lns[j] = *reinterpret_cast<const float4*>(g.ln_s + nb + j * 16);
+          } else {
+            bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
         uint2 pre[AUX == SW_AUX_DGELU ? 3 : 1][3];
 #pragma unroll
         for (int il = 0; il < 3; ++il) {
@@ -315,10 +340,19 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
         for (int il = 0; il < 3; ++il) {
           const int i = ch * 3 + il;
           const int row = il * 16 + (lane & 15);
+          float mean_m = 0.f, rstd_m = 1.f;
+          if constexpr (LNF == 1) {
+            const float2 ms = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
+            mean_m = ms.x; rstd_m = ms.y;
+          }
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const f32x4 av = acc[i][hb * 3 + j];
             float v[4] = {g.alpha * av[0] + bias[j].x, g.alpha * av[1] + bias[j].y, g.alpha * av[2] + bias[j].z, g.alpha * av[3] + bias[j].w};
+            if constexpr (LNF == 1) {
+              v[0] = fmaf(rstd_m, av[0] - mean_m * lns[j].x, bias[j].x); v[1] = fmaf(rstd_m, av[1] - mean_m * lns[j].y, bias[j].y);
+              v[2] = fmaf(rstd_m, av[2] - mean_m * lns[j].z, bias[j].z); v[3] = fmaf(rstd_m, av[3] - mean_m * lns[j].w, bias[j].w);
+            }
             if (AUX == SW_AUX_DGELU) {
               const uint2 u = pre[il][j];
               v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
@@ -411,7 +445,10 @@ bool rmcl_gemm_sw_supported(const GemmArgs& g, int a_kc, int b_kc) {
   if (!a_kc || g.nb1 > 1 || g.nb2 > 1 || g.splitk > 1) return false;
   if (g.N % 384 != 0 || g.K % 64 != 0 || g.K < 128) return false;
   if ((long)g.M * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
-  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU)) return false;   // (residual epilogue: 72 more live registers spill; N = 768 anyway)
+  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_LNFOLD)) return false;   // (residual epilogue: 72 more live registers spill; N = 768 anyway)
+  if (g.epi & EPI_LNFOLD) {
+    if (!b_kc || (g.epi & (EPI_BIAS | EPI_DGELU)) || !g.ln_s || !g.ln_c || !g.ln_part || g.ln_nparts % 2 || g.ln_nparts <= 0 || g.ln_cols <= 0) return false;
+  }
   return true;
 }
 
@@ -445,6 +482,23 @@ static int launch_sw(const GemmArgs& g, int dt_out, hipStream_t s) {
   return launch_sw2<B_KC, SW_AUX_NONE>(g, dt_out, s);
 }
 
+static int launch_sw_lnf(const GemmArgs& g, hipStream_t s) {
+  static bool attr = false;
+  constexpr int LDS = SW_LDS + 2048;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int tm = cdiv(g.M, 192), tn = g.N / 384, rows = cdiv(g.M, tm);
+  RMCL_LAUNCH((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1>), dim3(tm * tn), dim3(512), LDS, s, g, tm, tn, rows);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
 int rmcl_launch_gemm_sw(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s) {
+  if (g.epi & EPI_LNFOLD) {
+    RMCL_REQUIRE(b_kc && dt_out == RMCL_BF16, "gemm_sw: the LayerNorm-folded form is [rows][K] x [cols][K] with bf16 output");
+    return launch_sw_lnf(g, s);
+  }
   return b_kc ? launch_sw<true>(g, dt_out, s) : launch_sw<false>(g, dt_out, s);
 }

@@ -160,6 +160,15 @@ class Engine:
         self.g32 = z(lay.total)
         self.q_lp = z(lay.total, torch.bfloat16) if self.dtype == L.BF16 else None
         self.k_lp = z(lay.ema_end, torch.bfloat16) if self.dtype == L.BF16 else None
+        # LayerNorm folded into the qkv / fc1 GEMMs of the passes that keep no LayerNorm output (include/rmcl.h rmcl_fold):
+        # W' = W * gamma (bf16) + the s / c vectors per arena, re-derived whenever the fp32 masters change
+        self.fold = {}
+        self.fold_stale = {"q": True, "k": True}
+        if self.dtype == L.BF16 and os.environ.get("RMCL_NO_LN_FOLD", "0") != "1" and float(cfg.get("drop_rate", 0.0)) == 0.0:
+            nw, ns = lib.rmcl_ln_fold_elems(C.byref(d0), 0), lib.rmcl_ln_fold_elems(C.byref(d0), 1)
+            for a in ("q", "k"):
+                wf, sc = z(nw, torch.bfloat16), z(ns)
+                self.fold[a] = (wf, sc, L.Fold(wf=wf.data_ptr(), sc=sc.data_ptr()))
         self.specs = param_specs(cfg, lay)
         self._bufs: Dict[tuple, PassBuffers] = {}
         self.lp_stale = True
@@ -234,10 +243,24 @@ class Engine:
             check(lib.rmcl_cast_f32(P(self.q32), P(self.q_lp), L.BF16, I64(self.q32.numel()), stream_ptr()), "cast")
             check(lib.rmcl_cast_f32(P(self.k32), P(self.k_lp), L.BF16, I64(self.k32.numel()), stream_ptr()), "cast")
         self.lp_stale = False
+        self.fold_stale = {"q": True, "k": True}
+
+    def fold_of(self, key: bool):
+        """rmcl_fold of the arena a pass reads (None: separate LayerNorm kernels), refreshed if its masters changed."""
+        a = "k" if key else "q"
+        if a not in self.fold:
+            return None
+        wf, sc, st = self.fold[a]
+        if self.fold_stale[a]:
+            d0 = self.dims(1)
+            check(lib.rmcl_ln_fold(C.byref(d0), P(self.k32 if key else self.q32), P(wf), P(sc), stream_ptr()), "ln_fold")
+            self.fold_stale[a] = False
+        return C.byref(st)
 
     def ema(self, m: float):
         n = self.layout.ema_end
         check(lib.rmcl_ema_f32(P(self.k32), P(self.q32), P(self.k_lp), F(m), I64(n), stream_ptr()), "ema")
+        self.fold_stale["k"] = True
 
     def zero_grads(self):
         self.g32.zero_()
@@ -345,7 +368,8 @@ class Engine:
         stash = {L.MODE_INFER: None, L.MODE_DATA: pb.stash_data, L.MODE_FULL: pb.stash_full}[mode]
         check(lib.rmcl_encoder_forward(C.byref(pb.d), mode, P(p32), P(plp), P(pb.text_ids), P(pb.text_mask), P(patchesT),
                                        P(pb.co_mask), P(stash), P(pb.workspace), P(pb.xn), C.c_uint32(seed), F(p), self._rg(pb),
-                                       stream_ptr()), "encoder_forward")
+                                       self.fold_of(key) if (mode != L.MODE_FULL and pb.dtype == L.BF16) else None, stream_ptr()),
+              "encoder_forward")
 
     def heads_forward(self, pb: PassBuffers, key: bool, want_q: bool = True):
         head = self.k32 if key else self.q32

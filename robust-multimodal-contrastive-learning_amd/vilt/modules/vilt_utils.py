@@ -73,6 +73,7 @@ class FusedAdamW:
                                  P(self.seg_wd), int(self.seg_end.numel()), F(self.param_groups[0]["lr"]), F(self.betas[0]),
                                  F(self.betas[1]), F(self.eps), self.t, F(self.grad_scale), I64(e.q32.numel()), stream_ptr()),
               "adamw")
+        e.fold_stale["q"] = True
 
 
 class PolySchedule:

@@ -396,3 +396,42 @@ def test_bf16_ragged_images_track_reference_golden(tag):
         worst = max(worst, abs(mine[1] - dg[1]) / max(dg[1], 1e-6))
     assert worst < 0.12, worst
     record(f"bf16_{tag}", cls=e_cls, image_feats=e_img, loss=e_loss, grad_norm_rel_worst=worst)
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# LayerNorm folded into the qkv / fc1 GEMMs (INFER / DATA passes at the 192-row-tile shapes, i.e. B = 64): against the
+# separate-LayerNorm path on the same weights, and both against the fp32 CPU oracle
+# -------------------------------------------------------------------------------------------------------------------
+
+def test_layernorm_fold_matches_separate_layernorm_bs64():
+    B = 64
+    ocfg = O.default_config(num_layers=3, num_negative=1024, per_gpu_batchsize=B, adv_steps_img=2)
+    m, p = make_module(ocfg, 5, "bf16")
+    assert m.engine.fold, "the LayerNorm fold is expected to be active on the bf16 engine"
+    batch = O.synthetic_batch(ocfg, B, 9, ragged_text=True)
+    dev = dev_batch(batch)
+    with torch.no_grad():
+        ref = O.infer(p, ocfg, batch["text_ids"], batch["text_masks"], batch["image"][0])
+    fold = m.engine.fold
+    outs = {}
+    for name in ("fold", "separate"):
+        m.engine.fold = fold if name == "fold" else {}
+        r = m.infer(dev)
+        k = torch.nn.functional.normalize(torch.randn(B, 128, generator=torch.Generator().manual_seed(3)), dim=1).to(DEV)
+        delta = PGDAttack_moco(dict(m.config)).pgd_attack(m, dev_batch(batch), k_modality=k)
+        outs[name] = (r["cls_feats"].cpu(), r["text_feats"].cpu(), r["image_feats"].cpu(), delta.cpu())
+    m.engine.fold = fold
+    e = {}
+    for name in outs:
+        e[name + "_cls_vs_oracle"] = float((outs[name][0] - ref["cls_feats"]).abs().max())
+        e[name + "_text_vs_oracle"] = float((outs[name][1] - ref["text_feats"]).abs().max())
+    e["fold_vs_separate_cls"] = float((outs["fold"][0] - outs["separate"][0]).abs().max())
+    e["fold_vs_separate_feats"] = float((outs["fold"][2] - outs["separate"][2]).abs().max())
+    eps = ocfg["adv_max_norm_img"]
+    sat = lambda d: torch.sign(d) * (d.abs() >= eps * (1 - 1e-6))
+    e["delta_same_saturation_frac"] = float((sat(outs["fold"][3]) == sat(outs["separate"][3])).float().mean())
+    record("ln_fold_bs64", **e)
+    # the folded path must be as close to the fp32 oracle as the separate-LayerNorm bf16 path (same error class)
+    assert e["fold_cls_vs_oracle"] < max(2e-2, 2.0 * e["separate_cls_vs_oracle"]), e
+    assert e["fold_text_vs_oracle"] < max(6e-2, 2.0 * e["separate_text_vs_oracle"]), e
+    assert e["fold_vs_separate_cls"] < 2e-2 and e["delta_same_saturation_frac"] > 0.95, e
