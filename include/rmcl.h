@@ -76,6 +76,11 @@ typedef struct rmcl_fold {
 int64_t rmcl_ln_fold_elems(const rmcl_dims* d, int which);   /* which = 0: elements of wf (bf16), 1: elements of sc (f32) */
 int rmcl_ln_fold(const rmcl_dims* d, const float* params32, void* wf, float* sc, void* stream);
 
+/* Transposed bf16 shadows of qkv / proj / fc1 / fc2 of every layer (same offsets as params_lp, each matrix stored
+ * [in][out]): optional operand of rmcl_encoder_backward - the data-gradient GEMMs then read k-contiguous rows.  Re-run after
+ * every change of params_lp.                                                                                         */
+int rmcl_weight_transpose_bf16(const rmcl_dims* d, const void* params_lp, void* params_lpT, void* stream);
+
 /* Element offsets into a parameter arena.  Names follow the reference state dict. */
 typedef struct rmcl_layout {
   int64_t word, pos, btype, eln_w, eln_b;      /* text_embeddings.{word,position,token_type}_embeddings, LayerNorm */
@@ -162,12 +167,13 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
  * (the PGD data gradient, attack/pgd_attack_vilt.py:160-162).  dtext (optional) receives d loss/d
  * word-embedding output [B*L, D] f32 (the text-attack saliency, greedy_attack_vilt.py:414-452).
  * grads32 (mode FULL): gradient
- * arena, accumulated into (+=), same layout as the parameter arena.                              */
+ * arena, accumulated into (+=), same layout as the parameter arena.  params_lpT (optional, bf16 mode): transposed
+ * weight shadows from rmcl_weight_transpose_bf16.                                                 */
 int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp,
                           const int64_t* text_ids, const void* patches, const int32_t* co_mask,
                           void* stash, void* workspace, const float* dxn, int cls_only,
                           void* dpatches, float* dtext, float* grads32, uint32_t drop_seed, float drop_p,
-                          const rmcl_ragged* ragged, void* stream);
+                          const rmcl_ragged* ragged, const void* params_lpT, void* stream);
 
 /* Pooler + MoCo head + L2 normalise (vilt/modules/heads.py:10-20,129-143; objectives.py:264-269).
  * pool32: arena that owns the pooler (always the query arena); head32: arena that owns the

@@ -226,6 +226,15 @@ int rmcl_ln_fold(const rmcl_dims* d, const float* params32, void* wf, float* sc,
   return rmcl_ln_fold_launch(params32, y.layer0, y.layer_stride, d->layers, y.ln1_w, y.ln1_b, y.qkv_w, y.qkv_b, y.ln2_w, y.ln2_b, y.fc1_w,
                              y.fc1_b, d->D, d->mlp, (unsigned short*)wf, sc, (hipStream_t)stream);
 }
+int rmcl_weight_transpose_bf16(const rmcl_dims* d, const void* params_lp, void* params_lpT, void* stream) {
+  RMCL_REQUIRE(d && params_lp && params_lpT, "weight_transpose: NULL argument");
+  rmcl_layout y;
+  rmcl_param_layout(d, &y);
+  const long offs[4] = {y.qkv_w, y.proj_w, y.fc1_w, y.fc2_w};
+  const int rows[4] = {3 * d->D, d->D, d->mlp, d->D}, cols[4] = {d->D, d->D, d->D, d->mlp};
+  return rmcl_weight_transpose((const unsigned short*)params_lp, (unsigned short*)params_lpT, y.layer0, y.layer_stride, d->layers, offs, rows, cols,
+                               (hipStream_t)stream);
+}
 int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, int32_t* sel, int32_t* counts, int32_t* hw, void* stream) {
   RMCL_REQUIRE(img && sel && counts && hw, "patch_select: NULL argument");
   return rmcl_patch_select(img, B, C, Hh, Ww, ps, sel, counts, hw, (hipStream_t)stream);

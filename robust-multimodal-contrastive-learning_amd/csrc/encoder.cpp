@@ -468,7 +468,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, const void* params_lp, const int64_t* text_ids,
                           const void* patches, const int32_t* co_mask, void* stash, void* workspace, const float* dxn,
                           int cls_only, void* dpatches, float* dtext, float* G, uint32_t drop_seed, float drop_p,
-                          const rmcl_ragged* ragged, void* stream) {
+                          const rmcl_ragged* ragged, const void* params_lpT, void* stream) {
   RMCL_TRY(check_dims(d));
   RMCL_REQUIRE(!ragged || mode != RMCL_MODE_FULL || ragged->dpos_tok, "encoder_backward: rmcl_ragged.dpos_tok needed in FULL mode");
   RMCL_REQUIRE(mode == RMCL_MODE_DATA || mode == RMCL_MODE_FULL, "encoder_backward: mode must be DATA or FULL");
@@ -502,6 +502,9 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   const uint32_t dth = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
   const float dinv = 1.0f / (1.0f - drop_p);
   const bool lpm = dt != RMCL_F32 || dth != 0;      // a (masked) copy of dx in the GEMM operand type is needed
+  // transposed bf16 weight shadows: dX = dY W as [rows][K] x [cols][K] (W^T stored [in][out], k = out contiguous)
+  const bool WT = params_lpT != nullptr && dt == RMCL_BF16 && !d->exact;
+  auto WTp = [&](int64_t off) { return (const void*)((const bf16_t*)params_lpT + off); };
   // GROUPED weight gradients (bf16 fast path at the step's shapes): ONE launch per layer computes the four dW, the four bias
   // gradients and finishes the layer's LayerNorm dgamma/dbeta (gemm_dw_group_kernel); otherwise four split-K GEMMs + slab
   // reduces + column sums per layer.
@@ -536,10 +539,10 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     const void* dxT = lpm ? T[ia] : (const void*)w.dx;
     if (use_side && !grouped && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(1, l + 2), 0));   // du buffer free again
     {
-      GemmArgs g = gemm_args(dxT, c.W(c.L(l, y.fc2_w)), du, M, mlp, D, D, mlp, mlp);       // du = (dx W2) * gelu'(u)
+      GemmArgs g = gemm_args(dxT, WT ? WTp(c.L(l, y.fc2_w)) : c.W(c.L(l, y.fc2_w)), du, M, mlp, D, D, WT ? D : mlp, mlp);   // du = (dx W2) * gelu'(u)
       g.epi = EPI_DGELU; g.aux = ls.u; g.ld_aux = mlp; g.tag = GEMM_TAG_DX;
       if (dth) { g.epi |= EPI_DROP_BWD; g.drop_seed = rmcl_site_seed(drop_seed, l, DROP_SITE_HIDDEN); g.drop_thresh = dth; g.drop_inv_keep = dinv; }
-      RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
+      RMCL_TRY(gemm(c, g, dt, dt, 1, WT ? 1 : 0));
     }
     if (full && !grouped) {
       if (use_side) { HIP_TRY(hipEventRecord(EV(0, 2 * l), s)); HIP_TRY(hipStreamWaitEvent(cs.s, EV(0, 2 * l), 0)); }
@@ -550,9 +553,9 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       if (use_side) HIP_TRY(hipEventRecord(EV(1, l), cs.s));
     }
     {
-      GemmArgs g = gemm_args(du, c.W(c.L(l, y.fc1_w)), w.dln, M, D, mlp, mlp, D, D);        // dln2 = du W1
+      GemmArgs g = gemm_args(du, WT ? WTp(c.L(l, y.fc1_w)) : c.W(c.L(l, y.fc1_w)), w.dln, M, D, mlp, mlp, WT ? mlp : D, D);   // dln2 = du W1
       g.tag = GEMM_TAG_DX;
-      RMCL_TRY(gemm(c, g, dt, dln_dt, 1, 0));
+      RMCL_TRY(gemm(c, g, dt, dln_dt, 1, WT ? 1 : 0));
     }
     if (use_side && l + 1 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 1), 0));           // T[ib] free again (grouped: layer l+1's whole
                                                                                            // weight-gradient launch has finished)
@@ -562,9 +565,9 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     // ---- attention ----
     const void* dxT_b = lpm ? T[ib] : (const void*)w.dx;
     {
-      GemmArgs g = gemm_args(dxT_b, c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);        // dao = dx Wproj
+      GemmArgs g = gemm_args(dxT_b, WT ? WTp(c.L(l, y.proj_w)) : c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);   // dao = dx Wproj
       g.tag = GEMM_TAG_DX;
-      RMCL_TRY(gemm(c, g, dt, dt, 1, 0));
+      RMCL_TRY(gemm(c, g, dt, dt, 1, WT ? 1 : 0));
     }
     if (use_side && !grouped && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 2), 0));   // dqkv buffer free again
     RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, co_mask, ls.probs, w.dao, ls.ao, dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
@@ -577,9 +580,9 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       if (use_side) HIP_TRY(hipEventRecord(EV(2, l), cs.s));
     }
     {
-      GemmArgs g = gemm_args(dqkv, c.W(c.L(l, y.qkv_w)), w.dln, M, D, 3 * D, 3 * D, D, D);  // dln1 = dqkv Wqkv
+      GemmArgs g = gemm_args(dqkv, WT ? WTp(c.L(l, y.qkv_w)) : c.W(c.L(l, y.qkv_w)), w.dln, M, D, 3 * D, 3 * D, WT ? 3 * D : D, D);   // dln1 = dqkv Wqkv
       g.tag = GEMM_TAG_DX;
-      RMCL_TRY(gemm(c, g, dt, dln_dt, 1, 0));
+      RMCL_TRY(gemm(c, g, dt, dln_dt, 1, WT ? 1 : 0));
     }
     if (use_side && !grouped) HIP_TRY(hipStreamWaitEvent(s, EV(1, l), 0));                 // T[ic] free again
     RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, dln_dt, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,

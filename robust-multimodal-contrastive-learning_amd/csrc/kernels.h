@@ -64,6 +64,8 @@ int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos,
                             int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, int pos_per_sample, hipStream_t s);
 int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,
                             int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, float* dpos_tok, hipStream_t s);
+int rmcl_weight_transpose(const unsigned short* src, unsigned short* dst, long layer0, long stride, int layers, const long* offs, const int* rows,
+                          const int* cols, hipStream_t s);
 int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, int* sel, int* counts, int* hw, hipStream_t s);
 int rmcl_im2patch_sel(float* img, float* pat, const int* sel, const int* counts, int sel_ld, int B, int n, int C, int Hh, int Ww, int ps,
                       int to_image, hipStream_t s);

@@ -427,40 +427,49 @@ int rmcl_colsum(const void* X, long ld, int dt, float* out, int M, int N, hipStr
 // One workgroup per output row n of one (layer, matrix) pair; wf: [layers][3D + mlp][D] bf16 (qkv rows, then fc1 rows),
 // sc: [layers][2][3D + mlp] f32 (s, then c).  Runs after every change of the fp32 masters (optimizer step, momentum update).
 // ---------------------------------------------------------------------------------------------
+// one wave per output row (16 rows per workgroup), float4 loads, 8-byte bf16 stores
 __global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ p32, long layer0, long stride, long ln1_w, long ln1_b, long qkv_w,
-                                                      long qkv_b, long ln2_w, long ln2_b, long fc1_w, long fc1_b, int D, int mlp,
+                                                      long qkv_b, long ln2_w, long ln2_b, long fc1_w, long fc1_b, int D, int mlp, int total_rows,
                                                       bf16_t* __restrict__ wf, float* __restrict__ sc) {
-  __shared__ float red[2][4];
-  const int rows = 3 * D + mlp, l = blockIdx.x / rows, r = blockIdx.x % rows;
-  const float* base = p32 + layer0 + (long)l * stride;
-  const bool is_qkv = r < 3 * D;
-  const int n = is_qkv ? r : r - 3 * D;
-  const float* W = base + (is_qkv ? qkv_w : fc1_w) + (long)n * D;
-  const float* gam = base + (is_qkv ? ln1_w : ln2_w);
-  const float* bet = base + (is_qkv ? ln1_b : ln2_b);
-  const float bias = base[(is_qkv ? qkv_b : fc1_b) + n];
-  bf16_t* o = wf + ((long)l * rows + r) * D;
-  float ssum = 0.f, csum = 0.f;
-  for (int k = threadIdx.x; k < D; k += 256) {
-    const float w = W[k];
-    const bf16_t q = f2bf(w * gam[k]);
-    o[k] = q;
-    ssum += bf2f(q);
-    csum += w * bet[k];
-  }
-  ssum = wave_sum(ssum);
-  csum = wave_sum(csum);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ssum; red[1][threadIdx.x >> 6] = csum; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    sc[(long)l * 2 * rows + r] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    sc[(long)l * 2 * rows + rows + r] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + bias;
+  const int rows = 3 * D + mlp, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int gr = blockIdx.x * 16 + wave * 4 + i;
+    if (gr >= total_rows) return;
+    const int l = gr / rows, r = gr - l * rows;
+    const float* base = p32 + layer0 + (long)l * stride;
+    const bool is_qkv = r < 3 * D;
+    const int n = is_qkv ? r : r - 3 * D;
+    const float* W = base + (is_qkv ? qkv_w : fc1_w) + (long)n * D;
+    const float* gam = base + (is_qkv ? ln1_w : ln2_w);
+    const float* bet = base + (is_qkv ? ln1_b : ln2_b);
+    bf16_t* o = wf + ((long)l * rows + r) * D;
+    float ssum = 0.f, csum = 0.f;
+    for (int k = lane * 4; k < D; k += 256) {
+      const float4 w = *reinterpret_cast<const float4*>(W + k), g4 = *reinterpret_cast<const float4*>(gam + k),
+                   b4 = *reinterpret_cast<const float4*>(bet + k);
+      const bf16_t q0 = f2bf(w.x * g4.x), q1 = f2bf(w.y * g4.y), q2 = f2bf(w.z * g4.z), q3 = f2bf(w.w * g4.w);
+      uint2 pk;
+      pk.x = (uint32_t)q0 | ((uint32_t)q1 << 16);
+      pk.y = (uint32_t)q2 | ((uint32_t)q3 << 16);
+      *reinterpret_cast<uint2*>(o + k) = pk;
+      ssum += (bf2f(q0) + bf2f(q1)) + (bf2f(q2) + bf2f(q3));
+      csum += (w.x * b4.x + w.y * b4.y) + (w.z * b4.z + w.w * b4.w);
+    }
+    ssum = wave_sum(ssum);
+    csum = wave_sum(csum);
+    if (lane == 0) {
+      sc[(long)l * 2 * rows + r] = ssum;
+      sc[(long)l * 2 * rows + rows + r] = csum + base[(is_qkv ? qkv_b : fc1_b) + n];
+    }
   }
 }
 int rmcl_ln_fold_launch(const float* p32, long layer0, long stride, int layers, long ln1_w, long ln1_b, long qkv_w, long qkv_b, long ln2_w,
                         long ln2_b, long fc1_w, long fc1_b, int D, int mlp, unsigned short* wf, float* sc, hipStream_t s) {
-  RMCL_LAUNCH(ln_fold_kernel, dim3(layers * (3 * D + mlp)), dim3(256), 0, s, p32, layer0, stride, ln1_w, ln1_b, qkv_w, qkv_b, ln2_w, ln2_b, fc1_w,
-              fc1_b, D, mlp, wf, sc);
+  RMCL_REQUIRE(D % 4 == 0, "ln_fold: D%4");
+  const int total = layers * (3 * D + mlp);
+  RMCL_LAUNCH(ln_fold_kernel, dim3(cdiv(total, 16)), dim3(256), 0, s, p32, layer0, stride, ln1_w, ln1_b, qkv_w, qkv_b, ln2_w, ln2_b, fc1_w,
+              fc1_b, D, mlp, total, wf, sc);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

@@ -169,6 +169,9 @@ class Engine:
             for a in ("q", "k"):
                 wf, sc = z(nw, torch.bfloat16), z(ns)
                 self.fold[a] = (wf, sc, L.Fold(wf=wf.data_ptr(), sc=sc.data_ptr()))
+        # transposed bf16 shadows of the layer weights for the data-gradient GEMMs (include/rmcl.h rmcl_weight_transpose_bf16)
+        self.q_lpT = z(lay.total, torch.bfloat16) if (self.dtype == L.BF16 and os.environ.get("RMCL_NO_WT", "0") != "1") else None
+        self.lpT_stale = True
         self.specs = param_specs(cfg, lay)
         self._bufs: Dict[tuple, PassBuffers] = {}
         self.lp_stale = True
@@ -244,6 +247,19 @@ class Engine:
             check(lib.rmcl_cast_f32(P(self.k32), P(self.k_lp), L.BF16, I64(self.k32.numel()), stream_ptr()), "cast")
         self.lp_stale = False
         self.fold_stale = {"q": True, "k": True}
+        self.lpT_stale = True
+
+    def weights_T(self):
+        """transposed bf16 weight shadows of the query arena (None: the backward reads the weights as stored)"""
+        if self.q_lpT is None:
+            return None
+        if self.lp_stale:
+            self.refresh_shadows()
+        if self.lpT_stale:
+            d0 = self.dims(1)
+            check(lib.rmcl_weight_transpose_bf16(C.byref(d0), P(self.q_lp), P(self.q_lpT), stream_ptr()), "weight_transpose")
+            self.lpT_stale = False
+        return self.q_lpT
 
     def fold_of(self, key: bool):
         """rmcl_fold of the arena a pass reads (None: separate LayerNorm kernels), refreshed if its masters changed."""
@@ -394,8 +410,8 @@ class Engine:
         seed, p = pb.drop[mode]
         check(lib.rmcl_encoder_backward(C.byref(pb.d), mode, P(self.q32), P(self.q_lp), P(pb.text_ids), P(patchesT),
                                         P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), int(cls_only), P(dpatches), P(dtext),
-                                        P(self.g32 if mode == L.MODE_FULL else None), C.c_uint32(seed), F(p), self._rg(pb), stream_ptr()),
-              "encoder_backward")
+                                        P(self.g32 if mode == L.MODE_FULL else None), C.c_uint32(seed), F(p), self._rg(pb),
+                                        P(self.weights_T() if pb.dtype == L.BF16 else None), stream_ptr()), "encoder_backward")
 
     def pgd_step(self, pb: PassBuffers, lr: float, eps: float):
         per = pb.d.P * pb.d.patch_k

@@ -74,6 +74,7 @@ class FusedAdamW:
                                  F(self.betas[1]), F(self.eps), self.t, F(self.grad_scale), I64(e.q32.numel()), stream_ptr()),
               "adamw")
         e.fold_stale["q"] = True
+        e.lpT_stale = True
 
 
 class PolySchedule:

@@ -549,7 +549,7 @@ def test_grouped_weight_gradients_match_per_gemm_path_bs64():
             losses.append(float(loss))
     finally:
         lib.rmcl_tune_set(3, 1)
-    assert losses[0] == losses[1] == losses[2]
+    assert max(losses) - min(losses) < 1e-4          # (the batch mean is 64 float atomics: last-bit differences run to run)
     params = dict(m.named_parameters())
     lay = m.engine.layout
     worst = 0.0
