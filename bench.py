@@ -201,7 +201,8 @@ def main():
     B, K = args.batch, args.adv_steps
     clean = args.config == "itm_clean"
     cfg = task_moco(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=args.drop_rate, image_view=not clean,
-                    text_view=False, clean_view=clean, max_steps=100000)
+                    text_view=False, clean_view=clean, max_steps=100000,
+                    dense_images=True)         # synthetic full-size 384x384 images: skip the per-batch padded-image check
     if clean:
         cfg["loss_names"]["itm"] = 1
     torch.manual_seed(0)
