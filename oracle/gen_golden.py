@@ -19,7 +19,7 @@ vilt_module.py:275-351) pointed at the q-modules, resp. k-modules + q-pooler (:4
 Weights: ``oracle.rmcl_oracle.init_params(cfg, seed)`` loaded into the reference modules via
 their state-dict names, so a fixture is reproducible from (cfg, seed) without the reference.
 
-Usage:  python oracle/gen_golden.py [moco itm moco2 cleanitm txtatk sched]   (writes tests/golden/*.npz, ~2 min)
+Usage:  python oracle/gen_golden.py [moco itm moco2 cleanitm txtatk sched ragged pipeline]   (writes tests/golden/*.npz, ~2 min)
 """
 from __future__ import annotations
 
@@ -72,7 +72,7 @@ def _install_standins():
     mod("timm.models.resnetv2", ResNetV2=None)
     mod("timm.models.registry", register_model=lambda f: f)
     tv = mod("torchvision")
-    tv.transforms = mod("torchvision.transforms", Compose=lambda x: x)
+    tv.transforms = mod("torchvision.transforms", Compose=lambda x: x, Normalize=lambda **kw: ("normalize", kw), ToTensor=lambda: "to_tensor")
     pl = mod("pytorch_lightning", LightningModule=nn.Module)
     pl.metrics = mod("pytorch_lightning.metrics", Metric=object)
     mod("TSNE_vizualisation", TSNE_projection=None)
@@ -486,6 +486,68 @@ def run_text_attack(tag, cfg, B, seed_w, seed_k, seed_b, ragged, n_cand):
     print(tag, "text attack loss", out["loss"], "best idx", out["cand_best_idx"], "bytes", os.path.getsize(path))
 
 
+def run_pipeline():
+    """Input-pipeline pieces (row f3) from the reference's own MinMaxResize (vilt/transforms/utils.py:5-26) and
+    BaseDataset.collate (vilt/datasets/base_dataset.py:167-245; an unbound call - the method never touches self)."""
+    import importlib.util
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("ref_transforms_utils", os.path.join(REF, "vilt", "transforms", "utils.py"))
+    tu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+    rng = np.random.RandomState(5)
+    sizes = [(640, 480), (480, 640), (500, 375), (333, 500), (1024, 200), (200, 1024), (384, 384), (50, 60), (799, 801), (2000, 1500)]
+    sizes += [(int(rng.randint(200, 1500)), int(rng.randint(200, 1500))) for _ in range(40)]
+    out = {"sizes_in": np.array(sizes)}
+    for shorter, longer in ((384, 640), (800, 1333), (224, 373)):
+        r = tu.MinMaxResize(shorter=shorter, longer=longer)
+        res = []
+        for w, h in sizes:
+            img = Image.new("RGB", (w, h))
+            res.append(r(img).size)                             # (new_w, new_h)
+        out[f"sizes_out_{shorter}_{longer}"] = np.array(res)
+    # pixels: one synthetic image through MinMaxResize(384, 640) -> ToTensor -> Normalize(.5, .5)
+    src = (rng.rand(300, 451, 3) * 255).astype(np.uint8)
+    img = tu.MinMaxResize(shorter=384, longer=640)(Image.fromarray(src))
+    t = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).float().div(255.0)
+    t = (t - 0.5) / 0.5                                         # transforms.Normalize(mean .5, std .5) (pixelbert.py:9-17)
+    out["pix_src"] = src
+    out["pix_out_shape"] = np.array(t.shape)
+    out["pix_out_digest"] = tensor_digest(t)
+    out["pix_out_sub"] = t[:, ::16, ::16].numpy()
+    # collate
+    sys.modules["vilt.transforms"] = types.ModuleType("vilt.transforms")
+    sys.modules["vilt.transforms"].keys_to_transforms = lambda keys, size=224: []
+    spec = importlib.util.spec_from_file_location("ref_base_dataset", os.path.join(REF, "vilt", "datasets", "base_dataset.py"))
+    bd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bd)
+    g = torch.Generator().manual_seed(9)
+    shapes = [(3, 384, 352), (3, 320, 384), (3, 224, 288)]
+    lens = [7, 40, 13]
+    batch = []
+    for (c, h, w), n in zip(shapes, lens):
+        ids = torch.randint(1000, 30000, (n,), generator=g).tolist()
+        batch.append({"image": [torch.rand(c, h, w, generator=g) * 2 - 1], "false_image_0": [torch.rand(c, h, w, generator=g) * 2 - 1],
+                      "text": ("caption %d" % n, {"input_ids": ids, "attention_mask": [1] * n}), "img_index": n, "cap_index": 0, "raw_index": n})
+
+    def stub_collator(encodings):                               # stands in for DataCollatorForLanguageModeling (no masking)
+        ids = torch.zeros(len(encodings), 40, dtype=torch.int64)
+        for i, e in enumerate(encodings):
+            ids[i, : len(e["input_ids"])] = torch.tensor(e["input_ids"])
+        return {"input_ids": ids, "labels": torch.full_like(ids, -100)}
+
+    d = bd.BaseDataset.collate(None, batch, stub_collator)
+    out["collate_image"] = d["image"][0].numpy()[:, :, ::8, ::8]
+    out["collate_image_digest"] = tensor_digest(d["image"][0])
+    out["collate_false_image_digest"] = tensor_digest(d["false_image_0"][0])
+    out["collate_text_ids"] = d["text_ids"].numpy()
+    out["collate_text_masks"] = d["text_masks"].numpy()
+    out["collate_text_labels"] = d["text_labels"].numpy()
+    out["collate_keys"] = np.array(sorted(d.keys()))
+    path = os.path.join(ROOT, "tests", "golden", "pipeline.npz")
+    np.savez_compressed(path, **out)
+    print("pipeline fixture", os.path.getsize(path), "bytes;", out["sizes_out_384_640"][:4].tolist())
+
+
 def run_schedules():
     """LR curves from transformers.optimization (the functions vilt_utils.py:404-432 calls; importable here).
     HF AdamW itself (vilt_utils.py:395-398, transformers==4.2.1) no longer exists in the installed transformers:
@@ -546,3 +608,5 @@ if __name__ == "__main__":
         run_text_attack("L2_B4_ragged", small, 4, 11, 31, 21, True, 5)
     if want("sched"):
         run_schedules()
+    if want("pipeline"):
+        run_pipeline()

@@ -229,3 +229,43 @@ def test_lr_schedules_match_transformers():
         base, warm, total = g[name + "_args"]
         mine = [cosine_lr(i, base, int(warm), int(total)) for i in range(len(g[name]))]
         np.testing.assert_allclose(mine, g[name], rtol=1e-12, atol=1e-18)
+
+
+# ---- row f3: input pipeline pieces against the reference's own MinMaxResize and BaseDataset.collate ----------------
+
+def test_min_max_resize_and_pixelbert_match_reference():
+    import rmcl_pkg  # noqa: F401
+    from PIL import Image
+    from rmcl_amd.vilt.transforms import min_max_resize_size, pixelbert_transform
+    g = load("pipeline.npz")
+    for shorter, longer in ((384, 640), (800, 1333), (224, 373)):
+        mine = [min_max_resize_size(int(w), int(h), shorter, longer) for w, h in g["sizes_in"]]
+        np.testing.assert_array_equal(np.array(mine), g[f"sizes_out_{shorter}_{longer}"])
+        assert all(a % 32 == 0 and b % 32 == 0 for a, b in mine)
+    t = pixelbert_transform(size=384)(Image.fromarray(g["pix_src"]))
+    assert tuple(t.shape) == tuple(int(v) for v in g["pix_out_shape"])
+    np.testing.assert_allclose(t[:, ::16, ::16].numpy(), g["pix_out_sub"], atol=1e-6)
+    np.testing.assert_allclose(digest(t), g["pix_out_digest"], rtol=1e-6, atol=1e-5)
+
+
+def test_collate_matches_reference():
+    import rmcl_pkg  # noqa: F401
+    from rmcl_amd.vilt.datasets import collate
+    g = load("pipeline.npz")
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(3, 384, 352), (3, 320, 384), (3, 224, 288)]
+    lens = [7, 40, 13]
+    batch = []
+    for (c, h, w), n in zip(shapes, lens):
+        ids = torch.randint(1000, 30000, (n,), generator=gen).tolist()
+        batch.append({"image": [torch.rand(c, h, w, generator=gen) * 2 - 1], "false_image_0": [torch.rand(c, h, w, generator=gen) * 2 - 1],
+                      "text": ("caption %d" % n, {"input_ids": ids, "attention_mask": [1] * n}), "img_index": n, "cap_index": 0, "raw_index": n})
+    d = collate(batch)                                          # default collator: pad to 40, no masking
+    assert sorted(d.keys()) == [str(k) for k in g["collate_keys"]]
+    assert tuple(d["image"][0].shape) == (3, 3, 384, 384)
+    np.testing.assert_array_equal(d["image"][0].numpy()[:, :, ::8, ::8], g["collate_image"])
+    np.testing.assert_allclose(digest(d["image"][0]), g["collate_image_digest"], rtol=1e-7)
+    np.testing.assert_allclose(digest(d["false_image_0"][0]), g["collate_false_image_digest"], rtol=1e-7)
+    np.testing.assert_array_equal(d["text_ids"].numpy(), g["collate_text_ids"])
+    np.testing.assert_array_equal(d["text_masks"].numpy(), g["collate_text_masks"])
+    np.testing.assert_array_equal(d["text_labels"].numpy(), g["collate_text_labels"])

@@ -435,3 +435,22 @@ def test_layernorm_fold_matches_separate_layernorm_bs64():
     assert e["fold_cls_vs_oracle"] < max(2e-2, 2.0 * e["separate_cls_vs_oracle"]), e
     assert e["fold_text_vs_oracle"] < max(6e-2, 2.0 * e["separate_text_vs_oracle"]), e
     assert e["fold_vs_separate_cls"] < 2e-2 and e["delta_same_saturation_frac"] > 0.95, e
+
+
+def test_collated_mixed_size_batch_runs_the_step():
+    """row f3 end to end: per-sample dicts with images of different sizes -> collate (zero-pad) -> training_step on the GPU."""
+    from rmcl_amd.vilt.datasets import collate
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=3, adv_steps_img=2)
+    m, p = make_module(ocfg, 4, "bf16")
+    gen = torch.Generator().manual_seed(2)
+    samples = []
+    for (h, w), n in zip([(384, 352), (320, 384), (224, 288)], [9, 40, 17]):
+        ids = [101] + torch.randint(1000, 30000, (n - 2,), generator=gen).tolist() + [102]
+        samples.append({"image": [torch.rand(3, h, w, generator=gen) * 2 - 1],
+                        "text": ("caption", {"input_ids": ids, "attention_mask": [1] * n})})
+    batch = dev_batch(collate(samples))
+    loss = m.training_step(batch, 0)
+    loss.backward()
+    assert torch.isfinite(loss) and float(m.engine.g32.norm()) > 0
+    pb = m.engine.bufs(3, "moco", P=132)
+    assert pb.geom is not None and pb.geom.n == 132 and pb.geom.counts.tolist() == [132, 120, 63]
