@@ -106,12 +106,28 @@ class GradSync:
     on that layer's gradient-ready events (rmcl_grad_ready_wait), so RCCL runs while the layers below are still in
     their backward.  ``wait()`` makes the current stream wait for all of them (call before the optimizer step)."""
 
-    def __init__(self, flat: torch.Tensor, buckets, comm_stream, gate, prescaled: bool = False):
+    def __init__(self, flat: torch.Tensor, buckets, comm_stream, gate, prescaled: bool = False, compress: str = None):
+        """compress="bf16": every bucket travels as bf16 (half the bytes over the xGMI links: 224 instead of 449 MB per step
+        for ViLT-B/32) - cast, SUM all-reduce, cast back into the fp32 arena; the sum itself is then rounded to bf16 (the
+        usual mixed-precision DDP trade; default None keeps fp32 buckets = the reference's DDP arithmetic)."""
         self.works = []
+        self.unpack = []                       # (bf16 buffer, fp32 destination) pairs copied back in wait()
+        self.comm_stream = comm_stream if flat.is_cuda else None
         if not (dist.is_available() and dist.is_initialized()):
             return
         ws = world_size()
         main = torch.cuda.current_stream() if flat.is_cuda else None
+
+        def reduce(chunk):
+            if not prescaled:
+                chunk.div_(ws)
+            if compress == "bf16":
+                buf = chunk.to(torch.bfloat16)
+                self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+                self.unpack.append((buf, chunk))
+            else:
+                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+
         for layer, s, e in buckets:
             chunk = flat[s:e]
             if flat.is_cuda:
@@ -120,18 +136,17 @@ class GradSync:
                 else:
                     comm_stream.wait_stream(main)
                 with torch.cuda.stream(comm_stream):
-                    if not prescaled:
-                        chunk.div_(ws)
-                    self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+                    reduce(chunk)
             else:
-                if not prescaled:
-                    chunk.div_(ws)
-                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+                reduce(chunk)
 
     def wait(self):
         for w in self.works:
             w.wait()
         self.works = []
+        for buf, dst in self.unpack:
+            dst.copy_(buf)
+        self.unpack = []
 
 
 class StepGradSync:

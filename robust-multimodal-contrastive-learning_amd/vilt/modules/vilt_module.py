@@ -178,7 +178,8 @@ class ViLTransformerSS(nn.Module):
             def factory():
                 buckets = dist_utils.grad_buckets(int(lay.layer0), int(lay.layer_stride), int(self.hparams.config["num_layers"]),
                                                   int(e.g32.numel()))
-                return dist_utils.GradSync(e.g32, buckets, e.comm_stream, gate, prescaled=True)
+                return dist_utils.GradSync(e.g32, buckets, e.comm_stream, gate, prescaled=True,
+                                           compress=self.hparams.config.get("grad_allreduce_dtype"))
 
         self.step_sync.closure_done(e.g32, enabled=self.sync_grads, overlap=factory)
 

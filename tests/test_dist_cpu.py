@@ -92,6 +92,12 @@ def _worker_step_sync(rank, world, initfile, out_dir):
         assert torch.allclose(run(["itm", "moco"]), mean_of("itm") + mean_of("moco"), rtol=1e-6)
         # one closure: the overlapped per-layer path (prescaled=True)
         assert torch.allclose(run(["moco"], overlap=True), mean_of("moco"), rtol=1e-6)
+        # bf16-compressed buckets (config grad_allreduce_dtype="bf16"): same mean within bf16 rounding of the bucket values
+        arena = contrib["moco"] * (1.0 / world)
+        sync = dist_utils.GradSync(arena, dist_utils.grad_buckets(37, 50, 4, n), None, None, prescaled=True, compress="bf16")
+        sync.wait()
+        assert torch.allclose(arena, mean_of("moco"), rtol=2e-2), "bf16 buckets"
+        assert not torch.equal(arena, mean_of("moco"))                           # (it really went through bf16)
         # gradient accumulation over 3 micro-steps, reduced only on the last: mean over ranks of the SUM over micro-steps
         assert torch.allclose(run(["moco"], accumulate_micro=3), 3 * mean_of("moco"), rtol=1e-6)
         assert torch.allclose(run(["itm", "moco"], accumulate_micro=2), 2 * (mean_of("itm") + mean_of("moco")), rtol=1e-6)
