@@ -568,3 +568,46 @@ def test_grouped_weight_gradients_match_per_gemm_path_bs64():
         base = lay.layer0 + l * lay.layer_stride
         for off, n in ((lay.qkv_w, 3 * 768 * 768), (lay.proj_w, 768 * 768), (lay.fc1_w, 3072 * 768), (lay.fc2_w, 3072 * 768)):
             assert torch.equal(grads[0][base + off: base + off + n], grads[2][base + off: base + off + n]), (l, off)
+
+
+def test_two_closure_step_reduces_once_on_one_rank():
+    """itm + clean-InfoNCE in one training_step = TWO deferred backwards into one arena, under a 1-rank RCCL group: the arena
+    must be reduced exactly once, after the second closure (blocking path, no per-layer overlap), and - averaging over one
+    rank being the identity - equal the unsynchronised run."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        B = 8
+        cfg = task_moco(num_layers=2, num_negative=1024, per_gpu_batchsize=B, drop_rate=0.0, image_view=False, text_view=False,
+                        clean_view=True, num_gpus=1, num_nodes=1)
+        cfg["loss_names"]["itm"] = 1
+        ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=B)
+        m = ViLTransformerSS(cfg, device=DEV, compute_dtype="bf16")
+        m.load_state_dict({n: t.to(DEV) for n, t in O.init_params(ocfg, 5, k_seed=6).items()}, strict=False)
+        m.train()
+        m.itm_labels_override = (torch.arange(B) % 2)
+        batch = dev_batch(O.synthetic_batch(ocfg, B, 9, ragged_text=True))
+        outs = []
+        k0, q0 = m.engine.k32.clone(), m.proj_queue.clone()
+        for sync in (False, True):
+            m.sync_grads = sync
+            m.zero_grad()
+            m.queue_ptr = 0
+            m.engine.k32.copy_(k0)                                 # same momentum weights and queue for both runs
+            m.engine.lp_stale = True
+            m.proj_queue.copy_(q0)
+            loss = m.training_step(batch, 0)
+            assert m.step_sync.created == 2 and m.step_sync.open == 2
+            loss.backward()
+            assert m.step_sync.open == 0 and m.step_sync.handle is None      # two closures: one blocking pass, no overlap handle
+            torch.cuda.synchronize()
+            outs.append(m.engine.g32.clone())
+        assert float((outs[0] - outs[1]).abs().max()) <= 1e-4 * float(outs[1].abs().max())
+    finally:
+        if created:
+            dist.destroy_process_group()
