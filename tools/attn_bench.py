@@ -34,7 +34,7 @@ fwd = lambda: check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(out), P(probs), P(
 b2 = lambda: check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), None, P(dqkv), P(scores), P(dS), B, N, H, L.BF16, 0, stream()))
 b1 = lambda: check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), P(out), P(dqkv), P(scores), P(dS), B, N, H, L.BF16, 0, stream()))
 print(f"fwd {t(fwd):.1f} us   bwd two kernels {t(b2):.1f} us   bwd one kernel {t(b1):.1f} us")
-for wv in (4, 6, 8, 12, 24, 26):
+for wv in (4, 6, 8, 12):
     lib.rmcl_tune_set(4, wv)
     print(f"fwd with {wv} waves per workgroup: {t(fwd):.1f} us")
 lib.rmcl_tune_set(4, 8)
