@@ -145,6 +145,185 @@ __global__ __launch_bounds__(256) void infonce_partial_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 2: the same pass with 256 queue columns per workgroup as FOUR 64-column sub-slices folded on the fly (running
+// max / sum / dq with the usual rescaling), so half as many per-workgroup partials reach the combine kernel, the query
+// block lives in registers (A operand of the logit MFMA), and the next sub-slice's 32 KB are in flight (global -> registers
+// -> the other LDS buffer) while the current one is computed.  One workgroup per CU at Kq = 65 536 (256 workgroups).
+// ---------------------------------------------------------------------------------------------------------------------
+#define SL2 64       // columns per sub-slice
+#define NS2 4        // sub-slices per workgroup
+#define ILD2 65
+
+__global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __restrict__ q, const float* __restrict__ queue, long Kq,
+                                                               int B, float invT, float* __restrict__ part, float* __restrict__ dq_part,
+                                                               int Bpad) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  auto Qbuf = [&](int i) { return sm + i * (PD * ILD2); };   // two [PD][ILD2] buffers: Qs[c][j]
+  float* Ps = sm + 2 * PD * ILD2;        // [RT][ILD2]
+  float* c2 = Ps + RT * ILD2;            // [SL2]
+  float* q2 = c2 + SL2;                  // [RT]
+  float* fo = q2 + RT;                   // [RT] rescale of the running sums for this sub-slice
+  float* fs = fo + RT;                   // [RT] weight of this sub-slice
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wg = blockIdx.x, r0 = blockIdx.y * RT;
+  const long j00 = (long)wg * (SL2 * NS2);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- query block -> LDS (Qb[1] as scratch, pitch 129) -> registers: areg[i] = q[32 wm + lane%32][2 i + lane/32]
+  {
+    float* qs = Qbuf(1);
+    for (int i = 0; i < 8; ++i) {
+      const int v = t + 256 * i, r = v >> 5, cq = (v & 31) * 4;
+      float4 x = make_float4(0, 0, 0, 0);
+      if (r0 + r < B) x = *reinterpret_cast<const float4*>(q + (long)(r0 + r) * PD + cq);
+      float* d = qs + r * 129 + cq;
+      d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+    }
+  }
+  float4 pre[8];                                               // one sub-slice in flight: 32 floats per thread
+  auto fetch = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int v = t + 256 * i, c = v >> 4, jq = (v & 15) * 4;
+      pre[i] = *reinterpret_cast<const float4*>(queue + (long)c * Kq + j00 + (long)s * SL2 + jq);
+    }
+  };
+  auto deposit = [&](float* Qs) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int v = t + 256 * i, c = v >> 4, jq = (v & 15) * 4;
+      float* d = Qs + c * ILD2 + jq;
+      d[0] = pre[i].x; d[1] = pre[i].y; d[2] = pre[i].z; d[3] = pre[i].w;
+    }
+  };
+  fetch(0);
+  __syncthreads();
+  float areg[PD / 2];
+  {
+    const float* ap = Qbuf(1) + (32 * wm + (lane & 31)) * 129 + (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < PD / 2; ++i) areg[i] = ap[2 * i];
+  }
+  if (t < RT) {
+    float s = 0.f;
+    for (int c = 0; c < PD; ++c) { const float v = Qbuf(1)[t * 129 + c]; s += v * v; }
+    q2[t] = s;
+  }
+  deposit(Qbuf(0));
+  __syncthreads();                                             // (Qb[1] is free from here: q lives in registers)
+
+  f32x16 d0, d1;                                               // running dq: rows 32 wm .., columns 64 wn + {0..31, 32..63}
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+  // per-row running scalars (the 4 threads of a row keep identical copies)
+  const int row = t >> 2, sub = t & 3;
+  float m_run = -INFINITY, z_run = 0.f, best = -INFINITY, sd = 0.f, sc = 0.f, so = 0.f;
+  int bi = 0;
+  const float qq = q2[row];
+
+  for (int s = 0; s < NS2; ++s) {
+    float* Qs = Qbuf(s & 1);
+    if (s + 1 < NS2) fetch(s + 1);
+    if (t < SL2) {
+      float a = 0.f;
+      for (int c = 0; c < PD; ++c) { const float v = Qs[c * ILD2 + t]; a += v * v; }
+      c2[t] = a;
+    }
+    {  // step 1: S[64 x 64] = q @ Qs: one 32x32 tile per wave
+      f32x16 a0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a0[r] = 0.f;
+      const float* bp = Qs + (lane >> 5) * ILD2 + 32 * wn + (lane & 31);
+#pragma unroll 8
+      for (int i = 0; i < PD / 2; ++i) a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i], bp[2 * i * ILD2], a0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Ps[rr * ILD2 + 32 * wn + (lane & 31)] = a0[r];
+      }
+    }
+    __syncthreads();
+    {  // step 2: block softmax of this sub-slice + metrics, merged into the running values
+      float sbest = -INFINITY;
+      int sbi = 0;
+      for (int i = 0; i < SL2 / 4; ++i) {
+        const int col = 4 * i + sub;
+        const float dot = Ps[row * ILD2 + col];
+        if (dot > sbest) { sbest = dot; sbi = col; }
+        const float cc = c2[col];
+        sd += sqrtf(fmaxf(qq + cc - 2.f * dot, 0.f));
+        sc += dot / fmaxf(sqrtf(qq) * sqrtf(cc), 1e-6f);
+        so += dot;
+      }
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) {
+        const float ob = __shfl_xor(sbest, o, 64);
+        const int oi = __shfl_xor(sbi, o, 64);
+        if (ob > sbest || (ob == sbest && oi < sbi)) { sbest = ob; sbi = oi; }
+      }
+      const float ms = sbest * invT;
+      float z = 0.f;
+      for (int i = 0; i < SL2 / 4; ++i) {
+        const int col = 4 * i + sub;
+        const float p = __expf(Ps[row * ILD2 + col] * invT - ms);
+        Ps[row * ILD2 + col] = p;
+        z += p;
+      }
+      z += __shfl_xor(z, 1, 64);
+      z += __shfl_xor(z, 2, 64);
+      const float mn = fmaxf(m_run, ms), f_old = __expf(m_run - mn), f_s = __expf(ms - mn);   // (m_run = -inf first: f_old = 0)
+      z_run = z_run * f_old + z * f_s;
+      m_run = mn;
+      if (sbest > best) { best = sbest; bi = s * SL2 + sbi; }                                   // (earlier sub-slice wins ties: smaller index)
+      if (sub == 0) { fo[row] = f_old; fs[row] = f_s; }
+    }
+    __syncthreads();
+    {  // step 3: dq = dq * f_old + (f_s * P) @ Qs^T
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float f = fo[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+        d0[r] *= f;
+        d1[r] *= f;
+      }
+      const float fsr = fs[32 * wm + (lane & 31)];
+      const float* ap = Ps + (32 * wm + (lane & 31)) * ILD2 + (lane >> 5);
+      const float* bp0 = Qs + (64 * wn + (lane & 31)) * ILD2 + (lane >> 5);
+      const float* bp1 = bp0 + 32 * ILD2;
+#pragma unroll 8
+      for (int k = 0; k < SL2; k += 2) {
+        const float a = ap[k] * fsr;
+        d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[k], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[k], d1, 0, 0, 0);
+      }
+    }
+    if (s + 1 < NS2) deposit(Qbuf((s + 1) & 1));                 // the other buffer: its last readers passed the barrier above one
+    __syncthreads();                                           // sub-slice ago; also fences Ps / fo / fs for the next round
+  }
+  // metric sums across the 4 threads of a row
+#pragma unroll
+  for (int o = 1; o <= 2; o <<= 1) {
+    sd += __shfl_xor(sd, o, 64);
+    sc += __shfl_xor(sc, o, 64);
+    so += __shfl_xor(so, o, 64);
+  }
+  if (sub == 0 && r0 + row < B) {
+    float* o = part + ((long)wg * Bpad + r0 + row) * NPART;
+    o[0] = m_run; o[1] = z_run; o[2] = best; o[3] = __int_as_float((int)(j00 + bi));
+    o[4] = sd; o[5] = sc; o[6] = so; o[7] = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rr = r0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = 64 * wn + (lane & 31);
+    if (rr < B) {
+      float* o = dq_part + ((long)wg * Bpad + rr) * PD;
+      o[col] = d0[r];
+      o[col + 32] = d1[r];
+    }
+  }
+}
+
 // One workgroup per query row: merge slice partials, add the positive pair.  1024 threads = 8 groups of PD: group 0 does the
 // scalar bookkeeping, all eight split the slices of the Z / dq merge (the serial 512-slice loop was latency-bound).
 // rows_out[i, 0..9] = loss_i, pred_i (argmax of the logits incl. the positive at index 0),
@@ -233,6 +412,8 @@ __global__ __launch_bounds__(CMB_G * PD) void infonce_combine_kernel(const float
   (void)sh;
 }
 
+bool g_infonce_fold = true;          // rmcl_tune_set key 5: 0 selects the one-slice-per-workgroup kernel
+
 long rmcl_infonce_workspace_bytes(int B, long Kq) {
   const long Bpad = (B + RT - 1) / RT * RT, ns = Kq / SLICE;
   return ns * Bpad * (NPART + PD) * (long)sizeof(float);
@@ -252,9 +433,21 @@ int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int 
     hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  RMCL_LAUNCH(infonce_partial_kernel, dim3(ns, Bpad / RT), dim3(256), lds, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
+  int nparts = ns;
+  if (Kq % (SL2 * NS2) == 0 && g_infonce_fold) {               // 256 columns per workgroup, four folded 64-column sub-slices
+    nparts = (int)(Kq / (SL2 * NS2));
+    const size_t lds2 = (2 * PD * ILD2 + RT * ILD2 + SL2 + 3 * RT) * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      attr2 = true;
+    }
+    RMCL_LAUNCH(infonce_partial2_kernel, dim3(nparts, Bpad / RT), dim3(256), lds2, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
+  } else {
+    RMCL_LAUNCH(infonce_partial_kernel, dim3(ns, Bpad / RT), dim3(256), lds, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
+  }
   RMCL_CHECK_LAUNCH();
-  RMCL_LAUNCH(infonce_combine_kernel, dim3(B), dim3(CMB_G * PD), 0, s, q, k, part, dq_part, ns, B, Bpad, Kq, 1.0f / T, gscale, dq,
+  RMCL_LAUNCH(infonce_combine_kernel, dim3(B), dim3(CMB_G * PD), 0, s, q, k, part, dq_part, nparts, B, Bpad, Kq, 1.0f / T, gscale, dq,
                      rows_out, loss_sum);
   RMCL_CHECK_LAUNCH();
   return 0;

@@ -1,0 +1,36 @@
+"""Times the fused InfoNCE (forward + dq + metrics) at the step's shape (B=64, 128-d, queue 65536), both partial kernels."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.gpu_util import L, lib, check, P, I64, F, stream, DEV
+
+B, Kq = 64, 65536
+g = torch.Generator().manual_seed(0)
+q = torch.nn.functional.normalize(torch.randn(B, 128, generator=g), dim=1).to(DEV)
+k = torch.nn.functional.normalize(torch.randn(B, 128, generator=g), dim=1).to(DEV)
+queue = torch.randn(128, Kq, generator=g).to(DEV)
+dq, rows, loss = torch.empty(B, 128, device=DEV), torch.empty(B, 10, device=DEV), torch.zeros(1, device=DEV)
+lib.rmcl_infonce_ws_bytes.restype = __import__("ctypes").c_int64
+ws = torch.empty(lib.rmcl_infonce_ws_bytes(B, I64(Kq)), dtype=torch.uint8, device=DEV)
+run = lambda: check(lib.rmcl_infonce_f32(P(q), P(k), P(queue), B, 128, I64(Kq), F(0.07), F(1.0 / B), P(dq), P(rows), P(loss), P(ws), stream()))
+
+
+def t(n=50):
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+res = {}
+for fold in (0, 1):
+    lib.rmcl_tune_set(5, fold)
+    loss.zero_()
+    run()
+    res[fold] = (dq.clone(), rows.clone(), float(loss))
+    print(f"fold={fold}: {t():.1f} us per call (partial + combine); queue 33.5 MB -> {33.5e6 / (t() * 1e-6) / 1e12:.2f} TB/s effective")
+print("max |dq diff|", float((res[0][0] - res[1][0]).abs().max()), " rows diff", float((res[0][1] - res[1][1]).abs().max()), res[0][2], res[1][2])
