@@ -454,3 +454,46 @@ def test_collated_mixed_size_batch_runs_the_step():
     assert torch.isfinite(loss) and float(m.engine.g32.norm()) > 0
     pb = m.engine.bufs(3, "moco", P=132)
     assert pb.geom is not None and pb.geom.n == 132 and pb.geom.counts.tolist() == [132, 120, 63]
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# protocol edges: validation mode (the reference attacks and evaluates but does not enqueue), state-dict round trip
+# -------------------------------------------------------------------------------------------------------------------
+
+def test_validation_step_matches_oracle_and_leaves_the_queue_alone():
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=4, adv_steps_img=2, momentum=0.9)
+    m, p = make_module(ocfg, 7, "f32", k_seed=8)
+    batch = O.synthetic_batch(ocfg, 4, 3, ragged_text=True)
+    queue = O.init_queue(ocfg, 0)
+    m.eval()
+    m.queue_ptr = 8
+    q_before = m.proj_queue.clone()
+    out = m.validation_step(dev_batch(batch), 0)
+    ref = O.compute_moco_contrastive(p, ocfg, batch, queue, 8, training=False)     # the EMA still runs in validation (objectives.py:257-260)
+    assert abs(float(out["moco_loss"]) - float(ref["moco_loss"])) < 1e-3
+    assert not out["moco_loss"].requires_grad
+    assert m.queue_ptr == 8 and torch.equal(m.proj_queue, q_before) and ref["ptr"] == 8
+    np.testing.assert_allclose(out["k"].cpu().numpy(), ref["k"].numpy(), atol=1e-4)
+    sd = m.state_dict()
+    np.testing.assert_allclose(sd["k_transformer.blocks.1.mlp.fc1.weight"].cpu().numpy(), p["k_transformer.blocks.1.mlp.fc1.weight"].numpy(), atol=1e-6)
+
+
+def test_state_dict_round_trip_reproduces_the_module():
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=4, adv_steps_img=1)
+    m, p = make_module(ocfg, 7, "bf16", k_seed=8)
+    batch = dev_batch(O.synthetic_batch(ocfg, 4, 3, ragged_text=True))
+    m.queue_ptr = 12
+    loss = m.training_step(batch, 0)          # moves the momentum weights, the queue and its pointer
+    loss.backward()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    mine = {k for k in p.keys() if not k.startswith("itm_score")}        # (no ITM head without the itm task, like the reference)
+    assert mine <= set(sd.keys()) and "proj_queue" in sd and int(sd["proj_queue_ptr"]) == 16
+    m2, _ = make_module(ocfg, 99, "bf16", k_seed=98)                 # different weights, then the checkpoint
+    missing, unexpected = m2.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert m2.queue_ptr == 16
+    m.zero_grad()
+    a = m.training_step(batch, 1)
+    b = m2.training_step(batch, 1)
+    assert abs(float(a) - float(b)) < 1e-5
+    assert torch.equal(m.engine.k32, m2.engine.k32) and torch.equal(m.proj_queue, m2.proj_queue)
