@@ -199,7 +199,6 @@ def compute_moco_contrastive(pl_module, batch):
     phase = "train" if pl_module.training else "val"
     ret = {}
 
-    eng.ema(pl_module.momentum)                                            # :257-260
     pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], batch["image"][0])
     B = pb.B
 
@@ -210,6 +209,11 @@ def compute_moco_contrastive(pl_module, batch):
     pk.text_ids, pk.text_mask = pb.text_ids, pb.text_mask
     main = torch.cuda.current_stream()
     side = eng.side_stream
+    if eng.lp_stale:                       # (after a checkpoint load / manual weight edit) refresh the bf16 shadows on the MAIN
+        eng.refresh_shadows()              # stream before forking: both streams read them
+    # momentum update (:257-260).  (Moving the 1.6 GB sweep onto the key encoder's stream, beside the query encoder's first
+    # forward, measured no gain: 37.5 vs 37.6 ms per step - both are HBM-bound there.)
+    eng.ema(pl_module.momentum)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op)
