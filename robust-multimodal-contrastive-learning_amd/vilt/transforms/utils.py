@@ -1,7 +1,7 @@
-"""Image side of the input pipeline: ``MinMaxResize`` (vilt/transforms/utils.py:5-26) and the
-``pixelbert`` transform (vilt/transforms/pixelbert.py:9-17: MinMaxResize -> ToTensor -> Normalize(mean .5, std .5)), host
-side, PIL + torch only (torchvision is not required).  Every side comes out a multiple of 32, which is what the on-device
-ragged ``visual_embed`` path expects of a zero-padded batch."""
+"""Image side of the input pipeline, host side, PIL + torch only (torchvision is not required):
+``MinMaxResize`` (behaviour of vilt/transforms/utils.py:5-26) and the ``pixelbert`` transform (resize -> [0,1] tensor ->
+(x - 0.5) / 0.5, vilt/transforms/pixelbert.py:9-17).  Every output side is a multiple of 32 - what the on-device ragged
+``visual_embed`` expects of a zero-padded batch."""
 from __future__ import annotations
 
 import numpy as np
@@ -10,48 +10,42 @@ from PIL import Image
 
 
 def min_max_resize_size(w: int, h: int, shorter: int = 800, longer: int = 1333):
-    """(new_w, new_h) of MinMaxResize for a (w, h) image - the arithmetic of transforms/utils.py:11-24."""
-    scale = shorter / min(w, h)
-    if h < w:
-        newh, neww = shorter, scale * w
-    else:
-        newh, neww = scale * h, shorter
-    if max(newh, neww) > longer:
-        scale = longer / max(newh, neww)
-        newh = newh * scale
-        neww = neww * scale
-    newh, neww = int(newh + 0.5), int(neww + 0.5)
-    newh, neww = newh // 32 * 32, neww // 32 * 32
-    return neww, newh
+    """Target (width, height): the short side goes to `shorter`, then both shrink if the long side would pass `longer`,
+    then round half up and floor to multiples of 32.  Float arithmetic in the reference's order of operations (the rounding
+    of int(x + 0.5) depends on it)."""
+    k = shorter / min(w, h)
+    tw, th = (k * w, shorter) if h < w else (shorter, k * h)
+    big = max(th, tw)
+    if big > longer:
+        k2 = longer / big
+        th, tw = th * k2, tw * k2
+    snap = lambda v: int(v + 0.5) // 32 * 32
+    return snap(tw), snap(th)
 
 
 class MinMaxResize:
+    """callable(PIL image) -> PIL image, bicubic."""
+
     def __init__(self, shorter=800, longer=1333):
-        self.min = shorter
-        self.max = longer
+        self.min, self.max = shorter, longer
 
     def __call__(self, x: Image.Image) -> Image.Image:
-        w, h = x.size
-        neww, newh = min_max_resize_size(w, h, self.min, self.max)
-        return x.resize((neww, newh), resample=Image.BICUBIC)
+        return x.resize(min_max_resize_size(x.size[0], x.size[1], self.min, self.max), resample=Image.BICUBIC)
 
 
 def to_normalized_tensor(img: Image.Image) -> torch.Tensor:
-    """transforms.ToTensor() followed by inception_normalize (mean 0.5, std 0.5): uint8 HWC -> float32 CHW in [-1, 1]."""
-    a = np.asarray(img.convert("RGB"), dtype=np.uint8)
-    t = torch.from_numpy(a.copy()).permute(2, 0, 1).to(torch.float32).div_(255.0)
-    return t.sub_(0.5).div_(0.5)
+    """uint8 HWC -> float32 CHW in [-1, 1]  (ToTensor followed by Normalize(mean 0.5, std 0.5))."""
+    chw = torch.from_numpy(np.array(img.convert("RGB"), dtype=np.uint8)).permute(2, 0, 1)
+    return chw.to(torch.float32).div_(255.0).sub_(0.5).div_(0.5)
 
 
 def pixelbert_transform(size=800):
-    longer = int((1333 / 800) * size)
-    resize = MinMaxResize(shorter=size, longer=longer)
+    resize = MinMaxResize(shorter=size, longer=int((1333 / 800) * size))
     return lambda img: to_normalized_tensor(resize(img))
 
 
-_transforms = {"pixelbert": pixelbert_transform}
+_transforms = {"pixelbert": pixelbert_transform}       # (the RandAugment variant is a training-time augmentation, out of scope)
 
 
 def keys_to_transforms(keys: list, size=224):
-    """vilt/transforms/__init__.py:13-14 (the RandAugment variant is a training-time augmentation outside the hot path)."""
     return [_transforms[key](size=size) for key in keys]
