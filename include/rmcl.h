@@ -81,6 +81,17 @@ int rmcl_ln_fold(const rmcl_dims* d, const float* params32, void* wf, float* sc,
  * every change of params_lp.                                                                                         */
 int rmcl_weight_transpose_bf16(const rmcl_dims* d, const void* params_lp, void* params_lpT, void* stream);
 
+/* The two GEMM forms of the fold as single operators (the encoder pass uses them internally; exported for tests / reuse).
+ * rmcl_linear_rowstat: out[M,N] f32 = A[M,K] W[N,K]^T + bias + residual, plus out_bf16 (same values) and, per row, 4 partial
+ *   (sum, sum of squares) per 192 output columns: part[M][4*N/192][2].  N % 192 == 0; 192-row-tile shapes only.
+ * rmcl_linear_lnfold: out[M,N] bf16 = act( rstd_m * (xb[M,K] wf[N,K]^T - mean_m * s_n) + c_n ), mean / rstd from `part`
+ *   ([M][nparts][2], sums over K_ln = 768... columns); preact (optional, bf16) receives the value before the GELU.
+ * Both return an error when the shape would not run on the 192-row tile kernels (no fallback).                      */
+int rmcl_linear_rowstat(const void* A, const void* W, const float* bias, const float* residual, float* out, void* out_bf16, float* part,
+                        int M, int N, int K, void* stream);
+int rmcl_linear_lnfold(const void* xb, const void* wf, const float* s, const float* c, const float* part, int nparts, void* out,
+                       void* preact, int M, int N, int K, int gelu, float eps, float* mean, float* rstd, void* stream);
+
 /* Element offsets into a parameter arena.  Names follow the reference state dict. */
 typedef struct rmcl_layout {
   int64_t word, pos, btype, eln_w, eln_b;      /* text_embeddings.{word,position,token_type}_embeddings, LayerNorm */

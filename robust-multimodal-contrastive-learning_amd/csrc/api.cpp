@@ -237,6 +237,25 @@ int rmcl_weight_transpose_bf16(const rmcl_dims* d, const void* params_lp, void* 
   return rmcl_weight_transpose((const unsigned short*)params_lp, (unsigned short*)params_lpT, y.layer0, y.layer_stride, d->layers, offs, rows, cols,
                                (hipStream_t)stream);
 }
+int rmcl_linear_rowstat(const void* A, const void* W, const float* bias, const float* residual, float* out, void* out_bf16, float* part,
+                        int M, int N, int K, void* stream) {
+  RMCL_REQUIRE(A && W && bias && residual && out && out_bf16 && part, "linear_rowstat: NULL argument");
+  GemmArgs g = ga(A, W, out, M, N, K, K, K, N);
+  g.epi = EPI_BIAS | EPI_RESIDUAL | EPI_ROWSTAT; g.bias = bias; g.aux = residual; g.ld_aux = N; g.C2 = out_bf16;
+  g.ln_part = part; g.ln_nparts = 4 * (N / 192);
+  RMCL_REQUIRE(N % 192 == 0 && rmcl_gemm_routes_to_tile192(g, 1, 1), "linear_rowstat: shape does not run on the 192-row tile kernels");
+  return rmcl_launch_gemm(g, RMCL_BF16, RMCL_F32, 1, 1, 0, (hipStream_t)stream);
+}
+int rmcl_linear_lnfold(const void* xb, const void* wf, const float* s, const float* c, const float* part, int nparts, void* out,
+                       void* preact, int M, int N, int K, int gelu, float eps, float* mean, float* rstd, void* stream) {
+  RMCL_REQUIRE(xb && wf && s && c && part && out, "linear_lnfold: NULL argument");
+  GemmArgs g = ga(xb, wf, out, M, N, K, K, K, N);
+  g.epi = EPI_LNFOLD | (gelu ? EPI_GELU : 0) | (preact ? EPI_SAVE_PREACT : 0); g.C2 = preact;
+  g.ln_s = s; g.ln_c = c; g.ln_part = const_cast<float*>(part); g.ln_nparts = nparts; g.ln_cols = K; g.ln_eps = eps;
+  g.ln_mean = mean; g.ln_rstd = rstd;
+  RMCL_REQUIRE(rmcl_gemm_routes_to_tile192(g, 1, 1), "linear_lnfold: shape does not run on the 192-row tile kernels");
+  return rmcl_launch_gemm(g, RMCL_BF16, RMCL_BF16, 1, 1, 0, (hipStream_t)stream);
+}
 int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, int32_t* sel, int32_t* counts, int32_t* hw, void* stream) {
   RMCL_REQUIRE(img && sel && counts && hw, "patch_select: NULL argument");
   return rmcl_patch_select(img, B, C, Hh, Ww, ps, sel, counts, hw, (hipStream_t)stream);

@@ -316,7 +316,15 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       const long m = min(T.m0 + row, g.M - 1);
       const float4* pp = reinterpret_cast<const float4*>(g.ln_part + m * (long)(g.ln_nparts * 2));
       float s1 = 0.f, s2 = 0.f;
-      for (int q = 0; q < g.ln_nparts / 2; ++q) { const float4 v = pp[q]; s1 += v.x + v.z; s2 += v.y + v.w; }
+      if (g.ln_nparts == 16) {                                 // (the step's shape: all 8 loads in flight together, not 8 L2 round trips)
+        float4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = pp[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1 += v[q].x + v[q].z; s2 += v[q].y + v[q].w; }
+      } else {
+        for (int q = 0; q < g.ln_nparts / 2; ++q) { const float4 v = pp[q]; s1 += v.x + v.z; s2 += v.y + v.w; }
+      }
       const float inv = 1.0f / (float)g.ln_cols, mean = s1 * inv;
       const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + g.ln_eps);
       rowstat[2 * row] = mean;
@@ -326,6 +334,11 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();                              // the other group's last reads of this stage have retired
+  float2 rs[LNF == 1 ? 6 : 1];
+  if constexpr (LNF == 1) {                                    // mean / rstd of this lane's six rows, read once
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rs[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
+  }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     float4 res[AUX == ST_AUX_RES ? RI : 1][3];
@@ -345,10 +358,7 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       const int m = mb + i * 16;
       const bool live = m < T.m_end;
       float mean_m = 0.f, rstd_m = 1.f, ps1 = 0.f, ps2 = 0.f;
-      if constexpr (LNF == 1) {
-        const float2 ms = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
-        mean_m = ms.x; rstd_m = ms.y;
-      }
+      if constexpr (LNF == 1) { mean_m = rs[i].x; rstd_m = rs[i].y; }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float v[4] = {g.alpha * acc[i][j][0] + bias[j].x, g.alpha * acc[i][j][1] + bias[j].y, g.alpha * acc[i][j][2] + bias[j].z,

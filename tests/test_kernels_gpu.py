@@ -3,6 +3,7 @@ references of the same op.  Tolerances: exact-f32 kernels 1e-5 relative (fp32 su
 bf16-storage variants 2^-8 relative to the row scale."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -419,3 +420,47 @@ def test_gemm_skinny_heads_shapes():
         base = rnd(M, N, seed=5)
         out = gemm(X, W.t().contiguous(), M, N, K, 1, 0, L.F32, L.F32, epi=64, C_init=base)
         assert rel_err(out, X.double() @ W.double().t() + base.double()) < 2e-5
+
+
+# ------------------------------------------------------------------------- LayerNorm folded into the consuming GEMM
+@pytest.mark.parametrize("N2,gelu", [(2304, 0), (3072, 1)])
+def test_layernorm_fold_gemm_pair_matches_layernorm_then_linear(N2, gelu):
+    """Producer (fp32 output + residual, bf16 copy, per-row partial sums) and consumer (rstd * (xb W'^T - mean * s) + c) of
+    the LayerNorm fold at the step's shapes, against  LN(y) W2^T + b2  (then GELU) computed in fp64 from the producer's
+    own fp32 output."""
+    M, D, K1 = 11840, 768, 768
+    A = rnd(M, K1, seed=1).to(torch.bfloat16)
+    W1 = rnd(D, K1, seed=2, scale=0.05).to(torch.bfloat16)
+    b1 = rnd(D, seed=3)
+    res = rnd(M, D, seed=4, scale=2.0)
+    out = torch.empty(M, D, device=DEV)
+    outb = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    nparts = 4 * (D // 192)
+    part = torch.zeros(M, nparts, 2, device=DEV)
+    check(lib.rmcl_linear_rowstat(P(A), P(W1), P(b1), P(res), P(out), P(outb), P(part), M, D, K1, stream()))
+    y_ref = A.double() @ W1.double().t() + b1.double() + res.double()
+    assert rel_err(out, y_ref) < 2e-5
+    assert torch.equal(outb, out.to(torch.bfloat16))
+    np.testing.assert_allclose(part[:, :, 0].sum(1).cpu().numpy(), out.double().sum(1).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(part[:, :, 1].sum(1).cpu().numpy(), (out.double() ** 2).sum(1).cpu().numpy(), rtol=1e-5)
+    # consumer
+    gamma, beta = 1.0 + rnd(D, seed=5, scale=0.1), rnd(D, seed=6, scale=0.1)
+    W2, b2 = rnd(N2, D, seed=7, scale=0.05), rnd(N2, seed=8, scale=0.1)
+    wf = (W2 * gamma).to(torch.bfloat16)
+    s = wf.float().sum(1)
+    c = W2 @ beta + b2
+    o2 = torch.empty(M, N2, dtype=torch.bfloat16, device=DEV)
+    pre = torch.empty(M, N2, dtype=torch.bfloat16, device=DEV) if gelu else None
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    check(lib.rmcl_linear_lnfold(P(outb), P(wf), P(s), P(c), P(part), nparts, P(o2), P(pre), M, N2, D, gelu, F(1e-6), P(mean), P(rstd),
+                                 stream()))
+    yd = out.double()
+    mu, var = yd.mean(1, keepdim=True), yd.var(1, unbiased=False, keepdim=True)
+    ln = (yd - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()
+    z = ln @ W2.double().t() + b2.double()
+    np.testing.assert_allclose(mean.cpu().numpy(), mu[:, 0].cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(rstd.cpu().numpy(), (1 / torch.sqrt(var + 1e-6))[:, 0].cpu().numpy(), rtol=1e-4)
+    if gelu:
+        assert rel_err(pre, z) < 1.2e-2
+        z = torch.nn.functional.gelu(z)
+    assert rel_err(o2, z) < 1.2e-2          # bf16 operands and output (the separate LayerNorm -> bf16 -> GEMM path has the same class)

@@ -1,0 +1,40 @@
+"""qkv / fc1 forward GEMM at the step's shape: plain (A = LayerNorm output, bias epilogue) vs LayerNorm-folded consumer."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.gpu_util import L, lib, check, P, I64, F, stream, DEV
+
+M, D = 11840, 768
+g = torch.Generator().manual_seed(0)
+xb = torch.randn(M, D, generator=g).to(DEV).to(torch.bfloat16)
+part = torch.rand(M, 16, 2, generator=g).to(DEV) + 1.0
+mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+
+
+def t(fn, n=300):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+for name, N, gelu in (("qkv", 2304, 0), ("fc1", 3072, 1)):
+    W = (torch.randn(N, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    b, s, c = torch.zeros(N, device=DEV), torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if gelu else None
+    epi = 1 | (2 | 4 if gelu else 0)
+    plain = lambda: check(lib.rmcl_gemm(P(xb), P(W), P(out), P(pre), P(b), None, M, N, D, I64(D), I64(D), N, 0, F(1.0), epi, 1, L.BF16, L.BF16,
+                                        1, 1, 0, stream()))
+    fold = lambda: check(lib.rmcl_linear_lnfold(P(xb), P(W), P(s), P(c), P(part), 16, P(out), P(pre), M, N, D, gelu, F(1e-6), P(mean), P(rstd),
+                                                stream()))
+    line = f"{name}: plain {t(plain):.1f} us   LayerNorm-folded {t(fold):.1f} us"
+    for dbg in (1 << 20, 1 << 21, (1 << 20) | (1 << 21)):
+        lib.rmcl_tune_set(9, dbg)
+        line += f"   dbg{dbg >> 20}: {t(fold):.1f}"
+    lib.rmcl_tune_set(9, 0)
+    print(line)
