@@ -33,8 +33,4 @@ for name, N, gelu in (("qkv", 2304, 0), ("fc1", 3072, 1)):
     fold = lambda: check(lib.rmcl_linear_lnfold(P(xb), P(W), P(s), P(c), P(part), 16, P(out), P(pre), M, N, D, gelu, F(1e-6), P(mean), P(rstd),
                                                 stream()))
     line = f"{name}: plain {t(plain):.1f} us   LayerNorm-folded {t(fold):.1f} us"
-    for dbg in (1 << 20, 1 << 21, (1 << 20) | (1 << 21)):
-        lib.rmcl_tune_set(9, dbg)
-        line += f"   dbg{dbg >> 20}: {t(fold):.1f}"
-    lib.rmcl_tune_set(9, 0)
     print(line)
