@@ -339,19 +339,27 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
 #pragma unroll
     for (int i = 0; i < 6; ++i) rs[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
   }
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    float4 res[AUX == ST_AUX_RES ? RI : 1][3];
-    uint2 pre[AUX == ST_AUX_DGELU ? RI : 1][3];
+  // aux operand (fp32 residual / bf16 pre-activation) of chunk ch + 1 is fetched while chunk ch is converted and stored: the
+  // residual stream is HBM-cold here, and a load -> wait -> compute sequence per chunk put its latency on every chunk
+  float4 resb[2][AUX == ST_AUX_RES ? RI : 1][3];
+  uint2 preb[2][AUX == ST_AUX_DGELU ? RI : 1][3];
+  auto aux_fetch = [&](int ch, int buf) {
 #pragma unroll
     for (int il = 0; il < RI; ++il) {
       const long mr = min(mb + (ch * RI + il) * 16, g.M - 1);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        if (AUX == ST_AUX_RES) res[il][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + mr * g.ld_aux + nb + j * 16);
-        if (AUX == ST_AUX_DGELU) pre[il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+        if (AUX == ST_AUX_RES) resb[buf][il][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+        if (AUX == ST_AUX_DGELU) preb[buf][il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
       }
     }
+  };
+  if constexpr (AUX != ST_AUX_NONE) aux_fetch(0, 0);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if constexpr (AUX != ST_AUX_NONE) { if (ch + 1 < NCH) aux_fetch(ch + 1, (ch + 1) & 1); }
+    auto& res = resb[ch & 1];
+    auto& pre = preb[ch & 1];
 #pragma unroll
     for (int il = 0; il < RI; ++il) {
       const int i = ch * RI + il;

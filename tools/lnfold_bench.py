@@ -34,3 +34,15 @@ for name, N, gelu in (("qkv", 2304, 0), ("fc1", 3072, 1)):
                                                 stream()))
     line = f"{name}: plain {t(plain):.1f} us   LayerNorm-folded {t(fold):.1f} us"
     print(line)
+
+# producer side: fp32 output + residual, plain vs with the bf16 copy + per-row partial sums
+for name, K in (("proj", 768), ("fc2", 3072)):
+    A = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    W = (torch.randn(D, K, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    b, res = torch.zeros(D, device=DEV), torch.randn(M, D, generator=g).to(DEV)
+    out, outb = torch.empty(M, D, device=DEV), torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    prt = torch.empty(M, 16, 2, device=DEV)
+    plain = lambda: check(lib.rmcl_gemm(P(A), P(W), P(out), None, P(b), P(res), M, D, K, I64(K), I64(K), D, D, F(1.0), 1 | 8, 1, L.BF16, L.F32,
+                                        1, 1, 0, stream()))
+    prod = lambda: check(lib.rmcl_linear_rowstat(P(A), P(W), P(b), P(res), P(out), P(outb), P(prt), M, D, K, stream()))
+    print(f"{name}: plain {t(plain):.1f} us   with bf16 copy + row partials {t(prod):.1f} us")
