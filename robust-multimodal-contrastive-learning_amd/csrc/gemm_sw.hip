@@ -306,21 +306,43 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
+    // per-column vectors of both column halves and (LNF) the statistics of this lane's six rows: fetched ONCE, ahead of the chunk
+    // loop (inside it every (chunk, half) paid an L2 / LDS round trip before its first FMA)
+    // (the GELU' form carries no bias - fc2-dX - and has no registers to spare: its zero "bias" stays a constant)
+    constexpr bool HOIST = AUX != SW_AUX_DGELU;
+    float4 bias2[HOIST ? 2 : 1][3], lns2[2][LNF == 1 ? 3 : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int nbh = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if constexpr (LNF == 1) {
+            bias2[hb][j] = *reinterpret_cast<const float4*>(g.ln_c + nbh + j * 16);
+            lns2[hb][j] = *reinterpret_cast<const float4*>(g.ln_s + nbh + j * 16);
+          } else {
+            bias2[hb][j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nbh + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+    }
+    float2 rs6[LNF == 1 ? 6 : 1];
+    if constexpr (LNF == 1) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) rs6[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
+    }
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
-        float4 bias[3], lns[LNF == 1 ? 3 : 1];
+        float4 bias_l[3];
+        if constexpr (!HOIST) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          if constexpr (LNF == 1) {
-            bias[j] = *reinterpret_cast<const float4*>(g.ln_c + nb + j * 16);
-            lns[j] = *reinterpret_cast<const float4*>(g.ln_s + nb + j * 16);
-          } else {
-            bias[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
+          for (int j = 0; j < 3; ++j) bias_l[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        auto& bias = HOIST ? bias2[HOIST ? hb : 0] : bias_l;
+        auto& lns = lns2[hb];
         uint2 pre[AUX == SW_AUX_DGELU ? 3 : 1][3];
 #pragma unroll
         for (int il = 0; il < 3; ++il) {
@@ -341,10 +363,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
           const int i = ch * 3 + il;
           const int row = il * 16 + (lane & 15);
           float mean_m = 0.f, rstd_m = 1.f;
-          if constexpr (LNF == 1) {
-            const float2 ms = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
-            mean_m = ms.x; rstd_m = ms.y;
-          }
+          if constexpr (LNF == 1) { mean_m = rs6[i].x; rstd_m = rs6[i].y; }
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const f32x4 av = acc[i][hb * 3 + j];
