@@ -168,8 +168,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--drop-rate", type=float, default=0.0,
                     help="0 = the parity configuration (headline); 0.1 = the reference's training default (config.py:57)")
-    ap.add_argument("--config", default="rmcl_pgd", choices=["rmcl_pgd", "itm_clean"],
-                    help="rmcl_pgd = BASELINE configs[2]/[3] (the metric); itm_clean = BASELINE configs[1]")
+    ap.add_argument("--config", default="rmcl_pgd", choices=["rmcl_pgd", "itm_clean", "full_rmcl"],
+                    help="rmcl_pgd = BASELINE configs[2]/[3] (the metric); itm_clean = BASELINE configs[1]; full_rmcl = configs[4] "
+                         "(PGD K=5 + greedy text attack with synthetic candidates + the three views)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -200,8 +201,11 @@ def main():
         L.check(L.lib.rmcl_tune_set(1, 8), "tune_set")     # leave 8 CUs to RCCL's channels (include/rmcl.h)
     B, K = args.batch, args.adv_steps
     clean = args.config == "itm_clean"
+    full = args.config == "full_rmcl"
+    if full:
+        K = 5
     cfg = task_moco(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=args.drop_rate, image_view=not clean,
-                    text_view=False, clean_view=clean, max_steps=100000,
+                    text_view=full, clean_view=clean, max_steps=100000, max_loops=10, n_candidates=5,
                     dense_images=True)         # synthetic full-size 384x384 images: skip the per-batch padded-image check
     if clean:
         cfg["loss_names"]["itm"] = 1
@@ -259,6 +263,13 @@ def main():
             workload = (f"clean ITM + contrastive step: ITM + word-patch alignment (IPOT) + CE on the clean InfoNCE logits (queue 65536) "
                         f"+ full backward + AdamW, ViLT-B/32, bs={B}/GPU, 384x384 img + 40 tok (BASELINE configs[1])")
             metric = "image-text pairs/sec, ViLT-B/32 clean ITM+contrastive step"
+        if full:
+            # SURVEY 8d Config 5: 11F (key, clean, three attacked views fwd+bwd) + 2K F (PGD) + the text attack: per loop 2F
+            # (saliency fwd + data backward) + 5F (five candidate sentences per sample) = 70F for 10 loops; K = 5
+            step_flops = (11 + 2 * K + 10 * (2 + 5)) * F_PER_PAIR * B
+            workload = (f"full RMCL step: PGD K={K} image attack + greedy text attack (10 loops x 5 synthetic candidates per sample) + text / "
+                        f"image / both views + MoCo InfoNCE (queue 65536) + full backward + AdamW, ViLT-B/32, bs={B}/GPU (BASELINE configs[4])")
+            metric = f"image-text pairs/sec, ViLT-B/32 full RMCL step (PGD K={K} + text attack)"
         kern_tf = kern_fl / (kern_ms * 1e-3) / 1e12 if kern_n else 0.0
         traffic = traffic_record("mlp_fwd_pair") if args.dtype == "bf16" and B == 64 else None
         out = {

@@ -497,3 +497,39 @@ def test_state_dict_round_trip_reproduces_the_module():
     b = m2.training_step(batch, 1)
     assert abs(float(a) - float(b)) < 1e-5
     assert torch.equal(m.engine.k32, m2.engine.k32) and torch.equal(m.proj_queue, m2.proj_queue)
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] at its own size: PGD K = 5 image attack + greedy text attack (synthetic candidates) + MoCo queue,
+# 12 layers, bs = 64, bf16 - size-independent properties of the three-view step
+# -------------------------------------------------------------------------------------------------------------------
+
+def test_full_rmcl_three_views_bs64_bf16():
+    B, loops = 64, 2
+    ocfg = O.default_config(per_gpu_batchsize=B, adv_steps_img=5, text_view=True, image_view=True, max_loops=loops, n_candidates=5)
+    m, p = make_module(ocfg, 7, "bf16", k_seed=9, max_loops=loops, n_candidates=5, seed=0)
+    batch = O.synthetic_batch(ocfg, B, 5, ragged_text=True)
+    dev = dev_batch(batch)
+    q0 = m.proj_queue.clone()
+    m.zero_grad()
+    loss = m.training_step(dev, 0)
+    assert m.step_sync.created == 3                                    # text, image and both views: three deferred backwards
+    assert torch.isfinite(loss) and 20.0 < float(loss) < 80.0
+    lg = m.logged
+    views = [float(lg[f"moco_loss/attacked_{v}_loss"]) for v in ("txt", "img", "both")]
+    assert abs(float(loss) - sum(views) / 3) < 1e-3                     # moco_loss = mean of the three view losses (:397)
+    assert 0.0 <= float(lg["moco_attack/train/num_changes"]) <= loops and 0.0 <= float(lg["moco_attack/train/change_rate"]) <= 0.2 + 1e-6
+    loss.backward()
+    assert m.step_sync.open == 0
+    g = m.engine.g32
+    assert torch.isfinite(g).all() and float(g.norm()) > 0
+    pb = m.engine.bufs(B)
+    assert float(pb.delta.abs().max()) <= ocfg["adv_max_norm_img"] + 1e-9
+    assert m.queue_ptr == B and torch.equal(m.proj_queue[:, B:], q0[:, B:])       # one enqueue per step, whatever the views
+    # the attacked text differs from the input only inside the valid, non-special positions; masks untouched
+    pt = m.engine.bufs(B, "moco_txt")
+    changed = (pt.text_ids.cpu() != batch["text_ids"])
+    assert bool((pt.text_mask.cpu() == batch["text_masks"]).all())
+    assert not bool(changed[:, 0].any()) and not bool((changed & (batch["text_masks"] == 0)).any())
+    assert int(changed.sum(1).max()) <= loops
+    record("full_rmcl_bs64", loss=float(loss), txt=views[0], img=views[1], both=views[2], num_changes=float(lg["moco_attack/train/num_changes"]))
