@@ -171,6 +171,10 @@ def main():
     ap.add_argument("--config", default="rmcl_pgd", choices=["rmcl_pgd", "itm_clean", "full_rmcl"],
                     help="rmcl_pgd = BASELINE configs[2]/[3] (the metric); itm_clean = BASELINE configs[1]; full_rmcl = configs[4] "
                          "(PGD K=5 + greedy text attack with synthetic candidates + the three views)")
+    ap.add_argument("--grad-sync", default="ring", choices=["ring", "direct"],
+                    help="N > 1 gradient reduction: ring = RCCL all-reduce per layer bucket; direct = one-hop reduce-scatter "
+                         "(all-to-all + owner sum) + all-gather over the xGMI mesh (dist_utils.DirectReduce)")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="transport type of the gradient buckets")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -209,6 +213,8 @@ def main():
                     dense_images=True)         # synthetic full-size 384x384 images: skip the per-batch padded-image check
     if clean:
         cfg["loss_names"]["itm"] = 1
+    cfg["grad_allreduce_algo"] = args.grad_sync
+    cfg["grad_allreduce_dtype"] = "bf16" if args.grad_dtype == "bf16" else None
     torch.manual_seed(0)
     model = ViLTransformerSS(cfg, device=device, compute_dtype=args.dtype)
     model.train()
@@ -278,7 +284,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "world_size": dist.get_world_size() if use_dist else 1,
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}", "drop_rate": args.drop_rate,
-                       "final_loss": round(final_loss, 4)},
+                       "grad_sync": f"{args.grad_sync}/{args.grad_dtype}", "final_loss": round(final_loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(kern_tf, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(kern_tf * 1e12 / PEAK_BF16, 4),
                          "traffic": traffic["bytes_per_launch"] if traffic else None,

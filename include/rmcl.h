@@ -156,6 +156,12 @@ int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, in
 int rmcl_im2patch_sel(float* img, float* patches, const int32_t* sel, const int32_t* counts, int sel_ld, int B, int n, int C, int Hh,
                       int Ww, int ps, int to_image, void* stream);
 
+/* Owner-side sum of a direct reduce-scatter over the xGMI links (replaces the reduction DDP's all-reduce performs inside the
+ * collective, run.py:96): pieces [n_pieces][piece_elems] of `dtype` (F32 or BF16), this rank's slice as every rank sent
+ * it; out32 = their sum (fp32 accumulation, rank order); out_wire (may be NULL) = the sum rounded to `dtype`, the operand
+ * of the all-gather that follows.  piece_elems % 4 == 0.                                                            */
+int rmcl_shard_sum(const void* pieces, int dtype, int n_pieces, int64_t piece_elems, float* out32, void* out_wire, void* stream);
+
 /* out[dtype] = a + d1 + d2 (d1/d2 may be NULL): `img_init + img_delta` (attack/pgd_attack_vilt.py:144)
  * and the attacked view of objectives.py:176, fused with the cast to the GEMM operand type.      */
 int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* out, int dtype, int64_t n, void* stream);

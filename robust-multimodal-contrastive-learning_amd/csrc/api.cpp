@@ -265,6 +265,11 @@ int rmcl_im2patch_sel(float* img, float* patches, const int32_t* sel, const int3
   RMCL_REQUIRE(img && patches && sel && counts && n > 0, "im2patch_sel: NULL argument");
   return rmcl_im2patch_sel(img, patches, sel, counts, sel_ld, B, n, C, Hh, Ww, ps, to_image, (hipStream_t)stream);
 }
+int rmcl_shard_sum(const void* pieces, int dtype, int n_pieces, int64_t piece_elems, float* out32, void* out_wire, void* stream) {
+  RMCL_REQUIRE(pieces && (out32 || out_wire), "shard_sum: NULL argument");
+  RMCL_REQUIRE(dtype == RMCL_F32 || dtype == RMCL_BF16, "shard_sum: dtype");
+  return rmcl_k_shard_sum(pieces, dtype, n_pieces, piece_elems, out32, out_wire, (hipStream_t)stream);
+}
 int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* out, int dtype, int64_t n, void* stream) {
   RMCL_REQUIRE(a && out, "add_cast: NULL argument");
   return rmcl_k_add_cast(a, d1, d2, out, dtype, n, (hipStream_t)stream);

@@ -412,6 +412,45 @@ int rmcl_k_add_cast(const float* a, const float* d1, const float* d2, void* out,
   return 0;
 }
 
+// Owner-side sum of the direct reduce-scatter (dist_utils.DirectReduce): pieces [W][n] holds this rank's slice as every
+// rank sent it (rank-major); out32[n] = sum over W in rank order, fp32 accumulation; out_wire (optional) = the same sum in
+// the wire type, the operand of the all-gather that follows.
+template <typename T>
+__global__ __launch_bounds__(256) void shard_sum_kernel(const T* __restrict__ pieces, int W, long n4, float* __restrict__ out32,
+                                                        T* __restrict__ out_wire) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < W; ++w) {
+      if constexpr (sizeof(T) == 4) {
+        const float4 v = reinterpret_cast<const float4*>(pieces)[(long)w * n4 + i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      } else {
+        const uint2 v = reinterpret_cast<const uint2*>(pieces)[(long)w * n4 + i];
+        acc.x += bf2f((bf16_t)(v.x & 0xffffu)); acc.y += bf2f((bf16_t)(v.x >> 16));
+        acc.z += bf2f((bf16_t)(v.y & 0xffffu)); acc.w += bf2f((bf16_t)(v.y >> 16));
+      }
+    }
+    if (out32) reinterpret_cast<float4*>(out32)[i] = acc;
+    if (out_wire) {
+      if constexpr (sizeof(T) == 4) reinterpret_cast<float4*>(out_wire)[i] = acc;
+      else {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(acc.x) | ((uint32_t)f2bf(acc.y) << 16);
+        pk.y = (uint32_t)f2bf(acc.z) | ((uint32_t)f2bf(acc.w) << 16);
+        reinterpret_cast<uint2*>(out_wire)[i] = pk;
+      }
+    }
+  }
+}
+int rmcl_k_shard_sum(const void* pieces, int dt, int W, long n, float* out32, void* out_wire, hipStream_t s) {
+  RMCL_REQUIRE(n % 4 == 0 && W >= 1, "shard_sum: n%4 / W");
+  const int grid = (int)std::min<long>(cdiv(n / 4, 256), 8192);
+  if (dt == RMCL_F32) RMCL_LAUNCH(shard_sum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)pieces, W, n / 4, out32, (float*)out_wire);
+  else RMCL_LAUNCH(shard_sum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)pieces, W, n / 4, out32, (bf16_t*)out_wire);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
 // co_mask[b, 0:L] = text_mask[b,:] != 0; co_mask[b, L] = 1; co_mask[b, L+1+p] = (sum_c patch[b*P+p][c*ps*ps] != 0)
 // (pixel mask sampled at every patch's top-left pixel: vision_transformer.py:564-565,672; vilt_module.py:324)
 template <typename T>

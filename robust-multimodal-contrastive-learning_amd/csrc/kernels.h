@@ -75,6 +75,7 @@ int rmcl_pos_resize_bwd(const float* dtok, const int* sel, const int* counts, co
                         float* dtable, hipStream_t s);
 int rmcl_im2patch(const float* img, float* pat, int B, int C, int Hh, int Ww, int ps, int to_image, hipStream_t s);
 int rmcl_k_add_cast(const float* a, const float* d1, const float* d2, void* out, int dt, long n, hipStream_t s);
+int rmcl_k_shard_sum(const void* pieces, int dt, int W, long n, float* out32, void* out_wire, hipStream_t s);
 int rmcl_cast(const float* in, void* out, int dt, long n, hipStream_t s);
 int rmcl_co_mask(const long* text_mask, const void* pat, int dt, int* co, int B, int L, int P, int C, int pp, hipStream_t s);
 int rmcl_pgd_update(const void* g, int dt, float* delta, unsigned* amax_bits, int B, long per_sample, float lr, float eps, hipStream_t s);

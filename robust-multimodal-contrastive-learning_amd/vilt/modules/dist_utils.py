@@ -56,6 +56,62 @@ def queue_advance(ptr: int, n_keys: int, num_negative: int, per_step_bs: int) ->
     return True, (ptr + n_keys) % num_negative
 
 
+class DirectReduce:
+    """SUM over ranks of one flat fp32 chunk as a ONE-HOP reduce-scatter + all-gather (replaces
+    the ring all-reduce inside DDP, run.py:96).  MI355X xGMI is a full mesh of point-to-point links (7 per GPU): a ring
+    moves 2(W-1)/W of the bytes through W-1 hops, this form sends slice j straight to its owner j over the direct link
+    (``all_to_all_single``: W-1 concurrent sends per rank), the owner adds the W pieces (``rmcl_shard_sum``: fp32
+    accumulation in rank order, so the result does not depend on arrival order) and the finished slices return with one
+    ``all_gather_into_tensor``.  Same bytes per rank as the ring, one hop each way, every link busy at once.
+
+    ``wire``: torch.bfloat16 sends both legs in bf16 (half the bytes; the pieces are rounded once before the sum and the
+    sum once after it); default fp32 is exact up to the summation order.  Slices are padded to a multiple of 256 elements.
+    On a CUDA chunk everything is enqueued on the CURRENT stream (the collectives' completion is a stream dependency,
+    not a host wait); ``finish()`` waits for the all-gather and writes the chunk back."""
+
+    def __init__(self, chunk: torch.Tensor, wire: Optional[torch.dtype] = None):
+        ws = world_size()
+        n = chunk.numel()
+        s = -(-n // ws)
+        s = (s + 255) // 256 * 256
+        wire = wire or chunk.dtype
+        self.chunk, self.n = chunk, n
+        if ws * s == n and wire == chunk.dtype:
+            send = chunk
+        else:
+            send = torch.zeros(ws * s, dtype=wire, device=chunk.device)
+            send[:n].copy_(chunk)
+        recv = torch.empty(ws * s, dtype=wire, device=chunk.device)
+        dist.all_to_all_single(recv, send)
+        mine = self._owner_sum(recv, ws, s)
+        self.gathered = chunk if send is chunk else torch.empty(ws * s, dtype=wire, device=chunk.device)
+        self.work = dist.all_gather_into_tensor(self.gathered, mine, async_op=True)
+        self._keep = (send, recv, mine)                     # alive until the collectives have run
+
+    @staticmethod
+    def _owner_sum(recv: torch.Tensor, ws: int, s: int) -> torch.Tensor:
+        if recv.is_cuda:
+            from ... import _lib as L                       # the HIP library: loud failure when it is missing
+            mine = torch.empty(s, dtype=recv.dtype, device=recv.device)
+            L.check(L.lib.rmcl_shard_sum(L.C.c_void_p(recv.data_ptr()), L.BF16 if recv.dtype == torch.bfloat16 else L.F32, ws, s, None,
+                                         L.C.c_void_p(mine.data_ptr()), L.C.c_void_p(torch.cuda.current_stream().cuda_stream)), "shard_sum")
+            return mine
+        acc = recv[:s].float().clone()                      # CPU ranks of the gloo tests: same rank-order fp32 sum
+        for w in range(1, ws):
+            acc += recv[w * s:(w + 1) * s].float()
+        return acc.to(recv.dtype)
+
+    def finish(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+            if self.gathered is not self.chunk:
+                self.chunk.copy_(self.gathered[:self.n])
+            self._keep = None
+
+    wait = finish
+
+
 def allreduce_mean_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, async_op: bool = False):
     """Gradient averaging over a flat fp32 arena in a few large buckets (xGMI is point-to-point:
     few, large collectives).  Returns the list of work handles when async_op."""
@@ -73,14 +129,25 @@ def allreduce_mean_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, as
     return works
 
 
-def allreduce_sum_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, force: bool = False):
+def allreduce_sum_(flat: torch.Tensor, bucket_elems: int = 32 * 1024 * 1024, force: bool = False, algo: str = "ring",
+                   wire: Optional[torch.dtype] = None):
     """Blocking bucketed SUM over the flat gradient arena (the 1/world_size is applied to the loss gradient beforehand).
-    ``force``: issue the collectives even in a 1-rank group (single-GPU rehearsal of the communication path)."""
+    ``force``: issue the collectives even in a 1-rank group (single-GPU rehearsal of the communication path).
+    ``algo``: "ring" = RCCL all-reduce per bucket; "direct" = DirectReduce per bucket (wire: its transport dtype)."""
     if world_size() == 1 and not force:
         return
     n = flat.numel()
+    pending = []
     for s in range(0, n, bucket_elems):
-        dist.all_reduce(flat[s:min(n, s + bucket_elems)], op=dist.ReduceOp.SUM)
+        chunk = flat[s:min(n, s + bucket_elems)]
+        if algo == "direct":
+            pending.append(DirectReduce(chunk, wire))
+        elif algo == "ring":
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+        else:
+            raise ValueError(f"grad_allreduce_algo must be 'ring' or 'direct', got {algo!r}")
+    for p in pending:
+        p.finish()
 
 
 def grad_buckets(layer0: int, layer_stride: int, layers: int, total: int):
@@ -106,10 +173,15 @@ class GradSync:
     on that layer's gradient-ready events (rmcl_grad_ready_wait), so RCCL runs while the layers below are still in
     their backward.  ``wait()`` makes the current stream wait for all of them (call before the optimizer step)."""
 
-    def __init__(self, flat: torch.Tensor, buckets, comm_stream, gate, prescaled: bool = False, compress: str = None):
+    def __init__(self, flat: torch.Tensor, buckets, comm_stream, gate, prescaled: bool = False, compress: str = None,
+                 algo: str = "ring"):
         """compress="bf16": every bucket travels as bf16 (half the bytes over the xGMI links: 224 instead of 449 MB per step
         for ViLT-B/32) - cast, SUM all-reduce, cast back into the fp32 arena; the sum itself is then rounded to bf16 (the
-        usual mixed-precision DDP trade; default None keeps fp32 buckets = the reference's DDP arithmetic)."""
+        usual mixed-precision DDP trade; default None keeps fp32 buckets = the reference's DDP arithmetic).
+        algo="direct": every bucket goes through DirectReduce (one-hop reduce-scatter + all-gather) instead of RCCL's
+        all-reduce; with compress="bf16" both of its legs travel as bf16."""
+        if algo not in ("ring", "direct"):
+            raise ValueError(f"grad_allreduce_algo must be 'ring' or 'direct', got {algo!r}")
         self.works = []
         self.unpack = []                       # (bf16 buffer, fp32 destination) pairs copied back in wait()
         self.comm_stream = comm_stream if flat.is_cuda else None
@@ -121,7 +193,9 @@ class GradSync:
         def reduce(chunk):
             if not prescaled:
                 chunk.div_(ws)
-            if compress == "bf16":
+            if algo == "direct":
+                self.works.append(DirectReduce(chunk, torch.bfloat16 if compress == "bf16" else None))
+            elif compress == "bf16":
                 buf = chunk.to(torch.bfloat16)
                 self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
                 self.unpack.append((buf, chunk))
@@ -162,10 +236,14 @@ class StepGradSync:
     ``overlap``: a factory returning a ``GradSync`` (per-layer buckets gated on the backward's events); used only when the
     step has a single closure, because the per-layer events belong to ONE backward."""
 
-    def __init__(self):
+    def __init__(self, algo: str = "ring", compress: Optional[str] = None):
+        """algo / compress: config["grad_allreduce_algo"] ("ring" | "direct") and config["grad_allreduce_dtype"] (None |
+        "bf16", honoured by the direct form and by the overlapped per-layer buckets) for the blocking pass."""
         self.open = 0
         self.created = 0
         self.handle = None
+        self.algo = algo
+        self.compress = compress
 
     def begin_step(self):
         self.open = 0
@@ -187,7 +265,8 @@ class StepGradSync:
         if overlap is not None and self.created == 1:
             self.handle = overlap()
         else:
-            allreduce_sum_(flat, force=True)
+            allreduce_sum_(flat, force=True, algo=self.algo,
+                           wire=torch.bfloat16 if (self.algo == "direct" and self.compress == "bf16") else None)
 
     def wait(self):
         if self.handle is not None:

@@ -82,7 +82,7 @@ class ViLTransformerSS(nn.Module):
                 self.greedy_attacker = GreedyAttack_moco(config)
         self.grad_anchor = torch.zeros((), device=eng.device, requires_grad=True)
         self.sync_grads = True                     # False on the early micro-steps of gradient accumulation (DDP no_sync)
-        self.step_sync = dist_utils.StepGradSync()
+        self.step_sync = dist_utils.StepGradSync(algo=config.get("grad_allreduce_algo", "ring"), compress=config.get("grad_allreduce_dtype"))
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._after_load())
         # downstream checkpoint (vilt_module.py:134-160, test_only twin :252-268): loaded AFTER the momentum copies were
         # shadowed, strict=False, like the reference - so k_* keys absent from the file keep their pre-load values
@@ -179,7 +179,8 @@ class ViLTransformerSS(nn.Module):
                 buckets = dist_utils.grad_buckets(int(lay.layer0), int(lay.layer_stride), int(self.hparams.config["num_layers"]),
                                                   int(e.g32.numel()))
                 return dist_utils.GradSync(e.g32, buckets, e.comm_stream, gate, prescaled=True,
-                                           compress=self.hparams.config.get("grad_allreduce_dtype"))
+                                           compress=self.hparams.config.get("grad_allreduce_dtype"),
+                                           algo=self.hparams.config.get("grad_allreduce_algo", "ring"))
 
         self.step_sync.closure_done(e.g32, enabled=self.sync_grads, overlap=factory)
 

@@ -105,6 +105,62 @@ def _worker_step_sync(rank, world, initfile, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_direct(rank, world, initfile, outdir):
+    import rmcl_pkg  # noqa: F401
+    from rmcl_amd.vilt.modules import dist_utils
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(1234)
+        for n in (1000, 256 * world, 7):                                        # padded, exactly sliceable, shorter than a slice
+            parts = [torch.randn(n, generator=g) for _ in range(world)]         # every rank draws all contributions
+            want = parts[0].clone()
+            for r in range(1, world):
+                want += parts[r]                                                 # rank-order fp32 sum = what the owner computes
+            mine = parts[rank].clone()
+            ref = parts[rank].clone()
+            dist.all_reduce(ref)
+            red = dist_utils.DirectReduce(mine)
+            red.finish()
+            assert torch.equal(mine, want), f"direct reduce n={n}"
+            assert torch.allclose(mine, ref, rtol=1e-5, atol=1e-6)               # and the ring all-reduce up to summation order
+            # bf16 wire: pieces rounded once, sum rounded once
+            mine16 = parts[rank].clone()
+            dist_utils.DirectReduce(mine16, torch.bfloat16).finish()
+            want16 = parts[0].bfloat16().float()
+            for r in range(1, world):
+                want16 += parts[r].bfloat16().float()
+            assert torch.equal(mine16, want16.bfloat16().float()), f"bf16 wire n={n}"
+        # through the step reducer: 2 closures, blocking pass, direct form; and the overlapped per-layer buckets
+        n = 300
+        base = torch.arange(n, dtype=torch.float32)
+        sync = dist_utils.StepGradSync(algo="direct")
+        sync.begin_step()
+        sc = [sync.register(), sync.register()]
+        arena = torch.zeros(n)
+        for i, s_ in enumerate(sc):
+            arena += base * (rank + 1 + i) * s_
+            sync.closure_done(arena, enabled=True)
+        sync.wait()
+        want = sum(base * (r + 1) + base * (r + 2) for r in range(world)) / world
+        assert torch.allclose(arena, want, rtol=1e-6)
+        arena = base * (rank + 1) / world
+        h = dist_utils.GradSync(arena, dist_utils.grad_buckets(37, 50, 4, n), None, None, prescaled=True, algo="direct")
+        h.wait()
+        assert torch.allclose(arena, sum(base * (r + 1) for r in range(world)) / world, rtol=1e-6)
+        # every rank ends with the SAME bits (the owner computes each slice once)
+        torch.save(arena, os.path.join(outdir, f"d{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_reduce_scatter_all_gather_matches_allreduce(world):
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_direct, args=(world, os.path.join(d, "init"), d), nprocs=world, join=True)
+        outs = [torch.load(os.path.join(d, f"d{r}.pt")) for r in range(world)]
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
 def test_two_rank_step_grad_sync_reduces_once():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_step_sync, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)

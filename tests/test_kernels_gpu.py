@@ -464,3 +464,22 @@ def test_layernorm_fold_gemm_pair_matches_layernorm_then_linear(N2, gelu):
         assert rel_err(pre, z) < 1.2e-2
         z = torch.nn.functional.gelu(z)
     assert rel_err(o2, z) < 1.2e-2          # bf16 operands and output (the separate LayerNorm -> bf16 -> GEMM path has the same class)
+
+
+@pytest.mark.parametrize("wire", ["f32", "bf16"])
+def test_shard_sum_is_the_rank_order_sum(wire):
+    """rmcl_shard_sum (owner side of the direct reduce-scatter): W pieces of one slice -> fp32 sum in rank order, and the
+    sum in the wire type."""
+    W, n = 8, 256 * 37
+    g = torch.Generator().manual_seed(3)
+    pieces = torch.randn(W, n, generator=g).to(DEV)
+    if wire == "bf16":
+        pieces = pieces.to(torch.bfloat16)
+    out32 = torch.empty(n, device=DEV)
+    outw = torch.empty(n, dtype=pieces.dtype, device=DEV)
+    check(lib.rmcl_shard_sum(P(pieces), L.BF16 if wire == "bf16" else L.F32, W, n, P(out32), P(outw), stream()))
+    want = pieces[0].float().clone()
+    for w in range(1, W):
+        want += pieces[w].float()
+    assert torch.equal(out32, want)
+    assert torch.equal(outw, want.to(pieces.dtype))

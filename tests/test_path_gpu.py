@@ -358,8 +358,9 @@ def test_overlapped_gradient_sync_is_exact_on_one_rank():
         batch = dev_batch(O.synthetic_batch(ocfg, 64, 9))
         q0 = m.engine.q32.clone()
         outs = []
-        for sync in (False, True):
+        for sync, algo in ((False, "ring"), (True, "ring"), (True, "direct")):
             m.sync_grads = sync
+            m.hparams.config["grad_allreduce_algo"] = algo     # "direct": every per-layer bucket through DirectReduce
             m.engine.q32.copy_(q0)
             m.engine.lp_stale = True
             opt.m.zero_(); opt.v.zero_(); opt.t = 0
@@ -377,10 +378,12 @@ def test_overlapped_gradient_sync_is_exact_on_one_rank():
         for l in range(3):                                     # weight-matrix gradients: ordered slab reduce -> bitwise
             base = lay.layer0 + l * lay.layer_stride
             for off, n in ((lay.qkv_w, 3 * 768 * 768), (lay.proj_w, 768 * 768), (lay.fc1_w, 3072 * 768), (lay.fc2_w, 3072 * 768)):
-                assert torch.equal(outs[0][0][base + off: base + off + n], outs[1][0][base + off: base + off + n]), (l, off)
+                for other in (1, 2):
+                    assert torch.equal(outs[0][0][base + off: base + off + n], outs[other][0][base + off: base + off + n]), (l, off, other)
         # bias / LayerNorm gradients use float atomics (summation order varies run to run)
-        assert float((outs[0][0] - outs[1][0]).abs().max()) <= 1e-4 * float(outs[1][0].abs().max())
-        assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2.1 * float(opt.param_groups[0]["lr"]) * 10
+        for other in (1, 2):
+            assert float((outs[0][0] - outs[other][0]).abs().max()) <= 1e-4 * float(outs[other][0].abs().max())
+            assert float((outs[0][1] - outs[other][1]).abs().max()) <= 2.1 * float(opt.param_groups[0]["lr"]) * 10
     finally:
         m.sync_grads = True
         if created:
@@ -594,11 +597,12 @@ def test_two_closure_step_reduces_once_on_one_rank():
         batch = dev_batch(O.synthetic_batch(ocfg, B, 9, ragged_text=True))
         outs = []
         k0, q0 = m.engine.k32.clone(), m.proj_queue.clone()
-        for sync in (False, True):
+        for sync, algo in ((False, "ring"), (True, "ring"), (True, "direct")):
             m.sync_grads = sync
+            m.step_sync.algo = algo                                # "direct": one-hop reduce-scatter + all-gather (DirectReduce)
             m.zero_grad()
             m.queue_ptr = 0
-            m.engine.k32.copy_(k0)                                 # same momentum weights and queue for both runs
+            m.engine.k32.copy_(k0)                                 # same momentum weights and queue for every run
             m.engine.lp_stale = True
             m.proj_queue.copy_(q0)
             loss = m.training_step(batch, 0)
@@ -608,6 +612,8 @@ def test_two_closure_step_reduces_once_on_one_rank():
             torch.cuda.synchronize()
             outs.append(m.engine.g32.clone())
         assert float((outs[0] - outs[1]).abs().max()) <= 1e-4 * float(outs[1].abs().max())
+        assert float((outs[0] - outs[2]).abs().max()) <= 1e-4 * float(outs[2].abs().max())
     finally:
+        m.step_sync.algo = "ring"
         if created:
             dist.destroy_process_group()
