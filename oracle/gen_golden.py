@@ -486,6 +486,167 @@ def run_text_attack(tag, cfg, B, seed_w, seed_k, seed_b, ragged, n_cand):
     print(tag, "text attack loss", out["loss"], "best idx", out["cand_best_idx"], "bytes", os.path.getsize(path))
 
 
+TOY_GROUPS = [
+    "dog puppy hound canine pooch dogs", "cat kitten feline kitty tabby cats", "man guy gentleman fellow male men",
+    "woman lady female gal madam women", "child kid toddler youngster infant children", "house home cottage dwelling cabin houses",
+    "street road avenue lane boulevard streets", "car automobile vehicle sedan auto cars", "boat ship vessel yacht canoe boats",
+    "field meadow pasture lawn prairie fields", "ball sphere orb globe football balls", "table desk counter bench stand tables",
+    "big large huge giant enormous bigger", "small little tiny petite miniature smaller", "red crimson scarlet ruby maroon reddish",
+    "green emerald olive lime jade greenish", "run jog sprint dash race running", "walk stroll hike march wander walking",
+    "sit rest perch lounge squat sitting", "eat dine chew munch devour eating", "jump leap hop bound spring jumping",
+    "hold grasp grip clutch carry holding", "look gaze stare glance peer looking", "play frolic romp sport game playing",
+]
+TOY_FUNCTION = "a an the on in at with of and is are near by to from under over two three some his her its".split()
+TOY_STOP = "near two three some".split()                      # stands in for nltk's English stop words (not in the built-in list)
+TOY_PIECES = "##s ##ing ##ed ##er ##ly".split()
+
+
+def write_toy_resources():
+    """Small WordPiece vocabulary (special ids where bert-base-uncased has them), synonym groups with counter-fitted-style
+    vectors, stop words: the offline stand-ins for the resources the reference loads by name
+    (greedy_attack_vilt.py:51,53,66-67).  Original data of this repo, written next to the fixtures."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    toks = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [f"[unused{i}]" for i in range(99, 995)]
+    assert len(toks) == 1000
+    words = [w for grp in TOY_GROUPS for w in grp.split()[:5]]               # the 6th word of a group is an inflection built from pieces
+    toks += TOY_FUNCTION + words + TOY_PIECES
+    with open(os.path.join(gold, "toy_vocab.txt"), "w") as f:
+        f.write("\n".join(toks) + "\n")
+    with open(os.path.join(gold, "toy_stopwords.txt"), "w") as f:
+        f.write("\n".join(TOY_STOP) + "\n")
+    rng = np.random.RandomState(7)
+    lines = []
+    for gi, grp in enumerate(TOY_GROUPS):
+        base = rng.randn(24)
+        for wi, w in enumerate(grp.split()):
+            v = base + (0.35 + 0.25 * wi) * rng.randn(24)                    # later words of a group drift out of the 0.5 threshold
+            lines.append(w + " " + " ".join(f"{x:.5f}" for x in v))
+    lines.append(lines[3])                                                   # one duplicated line: row numbering vs word numbering (:86-88)
+    for w in ("the", "near", "is"):
+        lines.append(w + " " + " ".join(f"{x:.5f}" for x in rng.randn(24)))
+    with open(os.path.join(gold, "toy_counter_fitted.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return gold
+
+
+TOY_SENTENCES = [
+    "a big dog and a small cat run on the green field near the house",
+    "the man and the woman walk on the street with a child holding a red ball",
+    "two dogs jump over a table in the house",
+    "a lady is sitting in a boat looking at the kid playing with some puppy near a car",
+    "the kitten eat under the desk",
+    "three men hold the large football on a lawn by the road and look at the ship",
+]
+
+
+def run_text_attack_words(tag, cfg, B, seed_w, seed_k, seed_b, max_loops, n_cand):
+    """The WHOLE greedy text attack (host + tensor side) from the reference's own GreedyAttack_moco.adv_attack_samples
+    (attack/greedy_attack_vilt.py:494-599) on toy resources.  The object is made with __new__ and given the attributes
+    __init__ (:48-74) would set; init_matrix (:76-111) is the reference's.  Only adaptation: the installed transformers
+    5.x tokenizer has no `_convert_token_to_id` (the reference calls it at :285; transformers 4.2.1 had it) - a subclass
+    forwards it to convert_tokens_to_ids.  Run with PYTHONHASHSEED=0: the reference keeps candidates in Python sets."""
+    import tempfile
+    from transformers import BertTokenizer
+    from torch.nn import CosineSimilarity
+
+    class Tok(BertTokenizer):
+        def _convert_token_to_id(self, token):
+            return self.convert_tokens_to_ids(token)
+
+    gold = write_toy_resources()
+    with open(os.path.join(gold, "toy_vocab.txt")) as f:
+        vocab = {line.rstrip("\n"): i for i, line in enumerate(f)}
+    tok = Tok(vocab=vocab, do_lower_case=True)
+    torch.manual_seed(99)
+    cfg = dict(cfg, per_gpu_batchsize=B, max_loops=max_loops, n_candidates=n_cand)
+    p = O.init_params(cfg, seed_w, k_seed=seed_k)
+    h = Holder(cfg)
+    h.load_oracle_params(p)
+    h.proj_queue.copy_(O.init_queue(cfg, 0))
+    h.train()
+    batch = O.synthetic_batch(cfg, B, seed_b)
+    sentences = TOY_SENTENCES[:B]
+    enc = tok(sentences, truncation=True, padding="max_length", max_length=cfg["max_text_len"], return_special_tokens_mask=True)
+    batch["text"] = list(sentences)
+    batch["text_ids"] = torch.tensor(enc["input_ids"])
+    batch["text_masks"] = torch.tensor(enc["attention_mask"])
+    with torch.no_grad():
+        rk = h.infer_k(deepcopy(batch))
+        k = nn.functional.normalize(h.k_moco_head(rk["cls_feats"]), dim=1)
+
+    g = GreedyAttack_moco.__new__(GreedyAttack_moco)
+    g.pl_module, g.contrastive_framework = None, "moco"
+    g.stopwords = set(TOY_STOP)
+    g.cosine_similarity = CosineSimilarity(dim=1, eps=1e-6)
+    g.tokenizer = tok
+    g.device, g.words_to_sub_words = None, None
+    g.max_length, g.n_candidates, g.max_loops, g.sim_thred = cfg["max_text_len"], n_cand, max_loops, 0.5
+    g.word2id = tok.get_vocab()
+    g.id2word = {v: kk for kk, v in g.word2id.items()}
+    g.cos_sim = g.sim_word2id = g.sim_id2word = g.cos_sim_dict = None
+    g.synonym = "cos_sim"
+    g.max_image_len = cfg["max_image_len"]
+    g.moco_head = None
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:                       # init_matrix saves its cosine matrix into the cwd (:97)
+        os.chdir(tmp)
+        try:
+            g.init_matrix(os.path.join(gold, "toy_counter_fitted.txt"), os.path.join(tmp, "absent.npy"))
+        finally:
+            os.chdir(cwd)
+
+    trace = {"replace_idx": [], "all_new_text": [], "all_num": [], "best_idx": [], "cand_loss": [], "grads": [], "ids": []}
+    cwi, cns, spf, gg = g.compute_word_importance, g.construct_new_samples, g.split_forward, g.get_grad
+
+    def w_gg(*a, **kw):
+        out = gg(*a, **kw)
+        trace["grads"].append(np.array(out[1], dtype=np.float32))
+        trace["ids"].append(a[0].numpy().copy())
+        return out
+
+    def w_cwi(**kw):
+        out = cwi(**kw)
+        trace["replace_idx"].append([-1 if x is None else int(x) for x in out[0]])
+        return out
+
+    def w_cns(**kw):
+        out = cns(**kw)
+        trace["all_new_text"].append(list(out[0]))
+        trace["all_num"].append(list(out[1]))
+        return out
+
+    def w_spf(*a, **kw):
+        out = spf(*a, **kw)
+        trace["best_idx"].append([int(j) for _, j in out])
+        trace["cand_loss"].append([float(x) for cl, _ in out for x in cl])
+        return out
+
+    g.get_grad, g.compute_word_importance, g.construct_new_samples, g.split_forward = w_gg, w_cwi, w_cns, w_spf
+    ids_in, masks_in = batch["text_ids"].numpy().copy(), batch["text_masks"].numpy().copy()     # (get_grad rebinds the batch's entries)
+    res = g.adv_attack_samples(h, batch, k)
+    words = sorted(g.sim_word2id, key=g.sim_word2id.get)
+    out = {
+        "k": k.numpy(), "text_in": np.array(sentences), "text_ids_in": ids_in, "text_masks_in": masks_in,
+        "text_out": np.array(res["text"]), "text_ids_out": res["txt_input_ids"].numpy(), "text_masks_out": res["text_masks"].numpy(),
+        "num_changes": np.float64(res["num_changes"]), "change_rate": np.float64(res["change_rate"]),
+        "problem": np.array(bool(res["Problem"])), "changes_verification": np.array(res["changes_verification"]),
+        "replace_idx": np.array(trace["replace_idx"]), "best_idx": np.array(trace["best_idx"]),
+        "grads_loop0": trace["grads"][0], "ids_loops": np.stack(trace["ids"]),
+        "syn_words": np.array(words),
+        # the reference's candidate sets in ITS iteration order (a set: depends on the hash seed), '|'-joined per word
+        "syn_cands": np.array(["|".join(g.cos_sim_dict[g.sim_word2id[w]]) for w in words]),
+        "meta": np.array([B, seed_w, seed_b, cfg["num_layers"], cfg["num_negative"], seed_k, n_cand, max_loops]),
+    }
+    for li in range(max_loops):
+        out[f"new_text_{li}"] = np.array(trace["all_new_text"][li])
+        out[f"all_num_{li}"] = np.array(trace["all_num"][li])
+        out[f"cand_loss_{li}"] = np.array(trace["cand_loss"][li])
+    path = os.path.join(ROOT, "tests", "golden", f"txtatk_words_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(tag, "word attack", res["text"], "changes", res["num_changes"], res["changes_verification"], "replace", trace["replace_idx"],
+          "best", trace["best_idx"], "bytes", os.path.getsize(path))
+
+
 def run_pipeline():
     """Input-pipeline pieces (row f3) from the reference's own MinMaxResize (vilt/transforms/utils.py:5-26) and
     BaseDataset.collate (vilt/datasets/base_dataset.py:167-245; an unbound call - the method never touches self)."""
@@ -606,6 +767,10 @@ if __name__ == "__main__":
         run_clean_itm("L12_B2", dict(full, momentum=0.95), 2, 12, 32, 22, False)
     if want("txtatk"):
         run_text_attack("L2_B4_ragged", small, 4, 11, 31, 21, True, 5)
+    if want("txtwords"):
+        if os.environ.get("PYTHONHASHSEED") != "0":
+            sys.exit("txtwords: run with PYTHONHASHSEED=0 (the reference iterates Python sets of candidate words)")
+        run_text_attack_words("L2_B4", small, 4, 11, 31, 21, 4, 5)
     if want("sched"):
         run_schedules()
     if want("pipeline"):

@@ -34,6 +34,9 @@ def task_moco(**over):
         batch_size=128, max_epoch=1, max_image_len=200, test_only=False,
         adv_steps_img=5, adv_lr_img=0.05, adv_max_norm_img=0.005,
         n_candidates=5, max_loops=10, sim_thred=0.5, cos_sim=True, synonym="cos_sim",
+        # reference config.py:161-162; the word-level text attack is active when `tokenizer` is a LOCAL vocab path (or an
+        # object) and embedding_path exists - with the hub name "bert-base-uncased" it runs at token level
+        embedding_path="../attack/counter-fitted-vectors.txt", sim_path="../attack/cos_sim_counter_fitting.npy", stopwords=None,
         TSNE_vizualisation=False, img_save_path="",
     )
     cfg.update(over)

@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/rmcl_oracle.py) against the golden vectors produced by the
 reference's own code (oracle/gen_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -8,6 +10,7 @@ from oracle import rmcl_oracle as O
 from tests.golden_util import cfg_from_meta, digest, load
 
 torch.set_num_threads(8)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.fixture(scope="module", params=["L2_B4_ragged", "L12_B2", "L2_B4_raggedimg", "L2_B3_raggedimg2"])
@@ -269,3 +272,82 @@ def test_collate_matches_reference():
     np.testing.assert_array_equal(d["text_ids"].numpy(), g["collate_text_ids"])
     np.testing.assert_array_equal(d["text_masks"].numpy(), g["collate_text_masks"])
     np.testing.assert_array_equal(d["text_labels"].numpy(), g["collate_text_labels"])
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# f4: linguistic host side of the greedy text attack against the reference's own run on toy resources
+# (oracle/gen_golden.py run_text_attack_words; fixture txtatk_words_L2_B4.npz + toy_vocab / toy_counter_fitted / toy_stopwords)
+# -------------------------------------------------------------------------------------------------------------------
+
+def _word_attack_host(reference_order=False):
+    import rmcl_pkg  # noqa: F401
+    from rmcl_amd.attack import word_substitution as WS
+    g = np.load(os.path.join(GOLD, "txtatk_words_L2_B4.npz"))
+    tok = WS.load_tokenizer(os.path.join(GOLD, "toy_vocab.txt"))
+    table = WS.SynonymTable(os.path.join(GOLD, "toy_counter_fitted.txt"), n_candidates=5, sim_thred=0.5)
+    return g, tok, table, WS
+
+
+def test_synonym_table_matches_reference_candidate_sets():
+    g, tok, table, WS = _word_attack_host()
+    words = [str(w) for w in g["syn_words"]]
+    assert words == sorted(table.word2id, key=table.word2id.get)            # same numbering incl. the duplicated line
+    n_multi = 0
+    for w, cands in zip(words, g["syn_cands"]):
+        ref = str(cands).split("|")
+        assert set(table(w)) == set(ref), (w, table(w), ref)                   # the reference keeps a set: order is hash-seed dependent
+        n_multi += len(ref) > 1
+    assert n_multi > 20                                                       # the table is not trivially "every word maps to itself"
+    assert table("zebra") == ["zebra"] and "zebra" not in table
+
+
+def test_word_filter_and_subword_map():
+    g, tok, table, WS = _word_attack_host()
+    flt = WS.WordFilter(WS.load_stopwords(os.path.join(GOLD, "toy_stopwords.txt")))
+    for w in ("the", "a", "near", "some", "[SEP]", "[MASK]", ".", "", "..", "with"):
+        assert flt(w), w
+    for w in ("dog", "boat", "red", "jade"):
+        assert not flt(w), w
+    ids = torch.from_numpy(g["text_ids_in"])
+    words = WS.decode_words(tok, ids[2])
+    assert words == "two dogs jump over a table in the house".split()
+    m = WS.words_to_sub_words(tok, words, 40)
+    assert m[0].tolist() == [0] and m[1].tolist() == [1, 2] and m[2].tolist() == [3]      # "dogs" = dog ##s
+    assert len(WS.words_to_sub_words(tok, ["dogs"] * 30, 40)) == 19                        # cut where position + n would reach max_length
+    ids2, masks2 = WS.encode_sentences(tok, [str(t) for t in g["text_in"]], 40)
+    assert torch.equal(ids2, ids) and torch.equal(masks2, torch.from_numpy(g["text_masks_in"]))
+
+
+def test_word_importance_and_candidates_match_reference_first_loop():
+    """compute_word_importance + construct_new_samples on the reference's loop-0 saliency gradients: the same word per
+    sentence, and - with the reference's candidate order - the same candidate sentences in the same order."""
+    g, tok, table, WS = _word_attack_host()
+    from rmcl_amd.attack.greedy_attack_vilt import GreedyAttack_moco
+    cfg = dict(max_text_len=40, n_candidates=5, max_loops=4, sim_thred=0.5, max_image_len=200, vocab_size=30522, synonym="cos_sim")
+    ref_order = {str(w): str(c).split("|") for w, c in zip(g["syn_words"], g["syn_cands"])}
+
+    class RefOrder:
+        word2id = table.word2id
+        __contains__ = lambda self, w: w in table.word2id
+        __call__ = lambda self, w: ref_order.get(w, [w])
+
+    for syn, exact in ((RefOrder(), True), (table, False)):
+        att = GreedyAttack_moco(cfg, tokenizer=tok, stopwords=os.path.join(GOLD, "toy_stopwords.txt"), synonyms=syn)
+        ids = torch.from_numpy(g["text_ids_in"])
+        B = ids.shape[0]
+        words = [WS.decode_words(tok, ids[b]) for b in range(B)]
+        att.calc_words_to_sub_words(words, B)
+        att.replace_history = [set() for _ in range(B)]
+        att.changes_verification = [0] * B
+        pick = att.compute_word_importance(words, ids, g["grads_loop0"], B)
+        assert [-1 if x is None else x for x in pick] == g["replace_idx"][0].tolist()
+        new_text, all_num, changed = att.construct_new_samples(pick, words, B)
+        assert all_num == g["all_num_0"].tolist()
+        want = [str(t) for t in g["new_text_0"]]
+        if exact:
+            assert new_text == want
+        else:
+            s0 = 0
+            for n in all_num:
+                assert set(new_text[s0:s0 + n]) == set(want[s0:s0 + n])
+                s0 += n

@@ -334,6 +334,50 @@ def test_text_attack_tensor_side_matches_reference_golden():
     assert [j for _, j in picks] == g["cand_best_idx"].tolist()
 
 
+def test_word_level_text_attack_matches_reference_end_to_end():
+    """f4: the whole greedy text attack - linguistic host side (attack/word_substitution.py) + HIP tensor side - against
+    the reference's own adv_attack_samples (greedy_attack_vilt.py:494-599) on the toy vocabulary / synonym vectors: the
+    word attacked per loop, the candidate chosen, the final sentences, ids, masks and change statistics.  Candidates are
+    fed in the reference's recorded iteration order (it keeps them in a Python set); the table itself is compared as sets in
+    the CPU suite."""
+    from rmcl_amd.attack import word_substitution as WS
+    g = load("txtatk_words_L2_B4.npz")
+    B, sw, sb, L_, Kq, seed_k, n_cand, loops = [int(x) for x in g["meta"]]
+    ocfg = O.default_config(num_layers=L_, num_negative=Kq, per_gpu_batchsize=B)
+    m, p = make_module(ocfg, sw, "f32", k_seed=seed_k)
+    gold = os.path.join(ROOT, "tests", "golden")
+    tok = WS.load_tokenizer(os.path.join(gold, "toy_vocab.txt"))
+    table = WS.SynonymTable(os.path.join(gold, "toy_counter_fitted.txt"), n_candidates=n_cand, sim_thred=0.5)
+    ref_order = {str(w): str(c).split("|") for w, c in zip(g["syn_words"], g["syn_cands"])}
+
+    class RefOrder:
+        word2id = table.word2id
+        __contains__ = lambda self, w: w in table.word2id
+        __call__ = lambda self, w: ref_order.get(w, [w])
+
+    cfg = dict(m.config, max_loops=loops, n_candidates=n_cand)
+    att = GreedyAttack_moco(cfg, tokenizer=tok, stopwords=os.path.join(gold, "toy_stopwords.txt"), synonyms=RefOrder())
+    batch = dev_batch(O.synthetic_batch(ocfg, B, sb))
+    batch["text"] = [str(t) for t in g["text_in"]]
+    batch["text_ids"] = torch.from_numpy(g["text_ids_in"]).to(DEV)
+    batch["text_masks"] = torch.from_numpy(g["text_masks_in"]).to(DEV)
+    res = att.adv_attack_samples(m, batch, torch.from_numpy(g["k"]).to(DEV))
+    for li, (replace_idx, new_text, all_num, best) in enumerate(att.trace):
+        assert [-1 if x is None else x for x in replace_idx] == g["replace_idx"][li].tolist(), li
+        assert new_text == [str(t) for t in g[f"new_text_{li}"]], li
+        assert best == g["best_idx"][li].tolist(), li
+    assert res["text"] == [str(t) for t in g["text_out"]]
+    assert torch.equal(res["txt_input_ids"].cpu(), torch.from_numpy(g["text_ids_out"]))
+    assert torch.equal(res["text_masks"].cpu(), torch.from_numpy(g["text_masks_out"]))
+    assert res["changes_verification"] == g["changes_verification"].tolist()
+    assert abs(res["num_changes"] - float(g["num_changes"])) < 1e-12 and abs(res["change_rate"] - float(g["change_rate"])) < 1e-12
+    assert bool(res["Problem"]) == bool(g["problem"])
+    # and through the objective's entry point with the table in ITS OWN (similarity) order: runs, changes words, keeps shapes
+    att2 = GreedyAttack_moco(cfg, tokenizer=tok, stopwords=os.path.join(gold, "toy_stopwords.txt"), synonyms=table)
+    res2 = att2.adv_attack_samples(m, batch, torch.from_numpy(g["k"]).to(DEV))
+    assert res2["txt_input_ids"].shape == batch["text_ids"].shape and res2["num_changes"] > 0
+
+
 # -------------------------------------------------------------------------------------------------------------------
 # f1: the Adam part of the fused AdamW against torch.optim.AdamW (weight_decay = 0, where HF's AdamW and torch's
 # coincide).  HF 4.2.1's decay ordering (after the update) is restated from its source: parity unpinned, see DESIGN 5.
