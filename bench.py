@@ -168,9 +168,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--drop-rate", type=float, default=0.0,
                     help="0 = the parity configuration (headline); 0.1 = the reference's training default (config.py:57)")
-    ap.add_argument("--config", default="rmcl_pgd", choices=["rmcl_pgd", "itm_clean", "full_rmcl"],
+    ap.add_argument("--config", default="rmcl_pgd", choices=["rmcl_pgd", "itm_clean", "full_rmcl", "barlowtwins"],
                     help="rmcl_pgd = BASELINE configs[2]/[3] (the metric); itm_clean = BASELINE configs[1]; full_rmcl = configs[4] "
-                         "(PGD K=5 + greedy text attack with synthetic candidates + the three views)")
+                         "(PGD K=5 + greedy text attack with synthetic candidates + the three views); barlowtwins = the Barlow-Twins "
+                         "variant of the step (8192-wide head, cross-correlation loss, image view)")
     ap.add_argument("--grad-sync", default="ring", choices=["ring", "direct"],
                     help="N > 1 gradient reduction: ring = RCCL all-reduce per layer bucket; direct = one-hop reduce-scatter "
                          "(all-to-all + owner sum) + all-gather over the xGMI mesh (dist_utils.DirectReduce)")
@@ -198,7 +199,7 @@ def main():
 
     import rmcl_pkg  # noqa: F401
     from rmcl_amd import _lib as L
-    from rmcl_amd.vilt.config import task_moco
+    from rmcl_amd.vilt.config import task_moco, task_barlowtwins
     from rmcl_amd.vilt.modules import ViLTransformerSS
 
     if world > 1:
@@ -213,6 +214,10 @@ def main():
                     dense_images=True)         # synthetic full-size 384x384 images: skip the per-batch padded-image check
     if clean:
         cfg["loss_names"]["itm"] = 1
+    barlow = args.config == "barlowtwins"
+    if barlow:
+        cfg = task_barlowtwins(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=args.drop_rate, image_view=True,
+                               text_view=False, max_steps=100000, dense_images=True)
     cfg["grad_allreduce_algo"] = args.grad_sync
     cfg["grad_allreduce_dtype"] = "bf16" if args.grad_dtype == "bf16" else None
     torch.manual_seed(0)
@@ -276,6 +281,13 @@ def main():
             workload = (f"full RMCL step: PGD K={K} image attack + greedy text attack (10 loops x 5 synthetic candidates per sample) + text / "
                         f"image / both views + MoCo InfoNCE (queue 65536) + full backward + AdamW, ViLT-B/32, bs={B}/GPU (BASELINE configs[4])")
             metric = f"image-text pairs/sec, ViLT-B/32 full RMCL step (PGD K={K} + text attack)"
+        if barlow:
+            # clean forward 1F + K PGD steps 2F each + attacked forward/backward 3F; the head adds 3 x 2 x B x 8192^2-ish FLOPs per
+            # pass (weight-streaming, HBM-bound) and the 8192 x 8192 x B correlation - not counted in F
+            step_flops = (4 + 2 * K) * F_PER_PAIR * B
+            workload = (f"Barlow-Twins variant of the RMCL step: clean projection + PGD K={K} on the cross-correlation loss + attacked view + "
+                        f"full backward + AdamW (ViLT-B/32 + 768-8192-8192-8192 BatchNorm head), bs={B}/GPU (objectives.py:449-602)")
+            metric = f"image-text pairs/sec, ViLT-B/32 Barlow-Twins step (PGD K={K})"
         kern_tf = kern_fl / (kern_ms * 1e-3) / 1e12 if kern_n else 0.0
         traffic = traffic_record("mlp_fwd_pair") if args.dtype == "bf16" and B == 64 else None
         out = {

@@ -166,6 +166,38 @@ int rmcl_shard_sum(const void* pieces, int dtype, int n_pieces, int64_t piece_el
  * and the attacked view of objectives.py:176, fused with the cast to the GEMM operand type.      */
 int rmcl_add_cast_f32(const float* a, const float* d1, const float* d2, void* out, int dtype, int64_t n, void* stream);
 
+/* ---- Barlow-Twins variant ---------------------------------------------------------------------------
+ * BarlowTwinsHead (vilt/modules/heads.py:88-107; built with [8192, 8192], 8192 at vilt_module.py:115): Linear(D,H1) -
+ * BatchNorm1d - ReLU - Linear(H1,H2) - BatchNorm1d - ReLU - Linear(H2,H3) (no biases), then BatchNorm1d(H3, affine=False).
+ * w1..w3, g1/b1, g2/b2: element offsets of the weights and the BatchNorm gamma/beta in ONE fp32 arena (parameters and, at
+ * the same offsets, gradients).  All head arithmetic is fp32.                                                          */
+typedef struct rmcl_bt_head {
+  int32_t D, H1, H2, H3;
+  int64_t w1, g1, b1, w2, g2, b2, w3;
+} rmcl_bt_head;
+int64_t rmcl_bt_stash_floats(const rmcl_bt_head* h, int B);
+/* z [B,H3] = head(cls_feats [B,D]).  training != 0: batch statistics (and, when `running` is given, the running estimates
+ * [mean1,var1,mean2,var2,mean3,var3] are updated with `momentum`, unbiased variance - nn.BatchNorm1d); training == 0:
+ * normalise with `running`.  `stash` (rmcl_bt_stash_floats) keeps what rmcl_bt_head_backward needs.                  */
+int rmcl_bt_head_forward(const rmcl_bt_head* h, const float* params, const float* cls_feats, int B, int training, float* running,
+                         float momentum, float* stash, float* z, void* stream);
+/* dcls [B,D] = d loss / d cls_feats given dz [B,H3]; G != NULL: weight / gamma / beta gradients are ACCUMULATED into G at the
+ * head's offsets (NULL: data gradient only - the PGD inner loop, attack/pgd_attack_vilt.py:205-222).                     */
+int rmcl_bt_head_backward(const rmcl_bt_head* h, const float* params, float* stash, const float* dz, int B, int training, float* G,
+                          float* dcls, void* stream);
+/* Cross-correlation loss of compute_barlowtwins_contrastive (vilt/modules/objectives.py:476-484, PGD form
+ * attack/pgd_attack_vilt.py:219-224), in three steps so the caller can all-reduce c between the first two (:480):
+ *   rmcl_bt_corr: c [N,N] = zq^T zk * inv_bs;
+ *   rmcl_bt_loss: loss2 = (sum_i (c_ii - 1)^2, sum_{i != j} c_ij^2) and, IN PLACE, c <- grad_scale * d(on + lambda off)/dc;
+ *                 ws: rmcl_bt_loss_ws_floats(N) floats;
+ *   rmcl_bt_dz:   dzq [B,N] = zk G^T * inv_bs with G the matrix rmcl_bt_loss left in c.                                */
+int rmcl_bt_corr(const float* zq, const float* zk, int B, int N, float inv_bs, float* c, void* stream);
+int64_t rmcl_bt_loss_ws_floats(int N);
+int rmcl_bt_loss(float* c, int N, float lambda, float grad_scale, float* ws, float* loss2, void* stream);
+int rmcl_bt_dz(const float* zk, const float* G, int B, int N, float inv_bs, float* dzq, void* stream);
+/* rows [B,3] = (||q_b - k_b||, cosine(q_b, k_b) eps 1e-6, q_b . k_b): the distance logs of objectives.py:496-498 */
+int rmcl_bt_pair_metrics(const float* q, const float* k, int B, int N, float* rows, void* stream);
+
 /* One joint text+image encoder forward up to transformer.norm: replaces ViLTransformerSS.infer /
  * infer_k (vilt_module.py:275-418) minus the pooler.  params32: fp32 arena; params_lp: bf16
  * shadow arena (NULL when dtype is F32).  text_ids/text_mask [B,L] int64; patches [B*P,patch_k]

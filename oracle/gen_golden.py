@@ -90,7 +90,7 @@ _install_standins()
 import vilt.modules.vision_transformer as vit  # noqa: E402  (reference, unmodified)
 import vilt.modules.heads as heads  # noqa: E402
 import vilt.modules.objectives as objectives  # noqa: E402
-from attack.pgd_attack_vilt import PGDAttack, PGDAttack_moco  # noqa: E402
+from attack.pgd_attack_vilt import PGDAttack, PGDAttack_moco, PGDAttack_bartlowtwins  # noqa: E402
 from attack.greedy_attack_vilt import GreedyAttack_moco  # noqa: E402
 from transformers.models.bert.modeling_bert import BertConfig, BertEmbeddings  # noqa: E402
 
@@ -647,6 +647,76 @@ def run_text_attack_words(tag, cfg, B, seed_w, seed_k, seed_b, max_loops, n_cand
           "best", trace["best_idx"], "bytes", os.path.getsize(path))
 
 
+def run_barlow(tag, cfg, B, seed_w, seed_h, seed_b, ragged, dims):
+    """One Barlow-Twins image-view step from the reference's own compute_barlowtwins_contrastive (objectives.py:449-602),
+    PGDAttack_bartlowtwins (pgd_attack_vilt.py:178-236) and heads.BarlowTwinsHead (heads.py:88-107), built with widths
+    `dims` (vilt_module.py:115 hard-codes 8192: the class itself takes them as arguments), then backward.  The clean
+    projection k, the attacked projection, the PGD delta (what pgd_attack returns) and BatchNorm's running statistics are
+    recorded through forward hooks / a wrapper around the attacker - nothing in the reference is edited."""
+    torch.manual_seed(777)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+    cfg = dict(cfg, per_gpu_batchsize=B, barlowtwins_dims=tuple(dims), image_view=True, text_view=False)
+    p = O.init_params(cfg, seed_w)
+    hp = O.bt_init_params(cfg, seed_h)
+    h = Holder(cfg)
+    h.barlowtwins_head = heads.BarlowTwinsHead(cfg["hidden_size"], [dims[0], dims[1]], dims[2])
+    h.adv_lr = cfg["adv_lr"]
+    h.pgd_attacker = PGDAttack_bartlowtwins(cfg)
+    for name in ("train", "val"):
+        for met in ("barlowtwins_loss", "barlowtwins_loss_invariance_img", "barlowtwins_loss_redundancy_img"):
+            setattr(h, f"{name}_{met}", lambda x: x)
+    h.load_oracle_params(dict(p, **hp))
+    h.train()
+    batch = O.synthetic_batch(cfg, B, seed_b, ragged_text=ragged)
+    seen, deltas = [], []
+    h.barlowtwins_head.register_forward_hook(lambda mod, inp, out_: seen.append((mod is h.barlowtwins_head, out_.detach().clone())))
+    attack = h.pgd_attacker.pgd_attack
+
+    def recording_attack(*a, **kw):
+        d = attack(*a, **kw)
+        deltas.append(d.detach().clone())
+        return d
+
+    h.pgd_attacker.pgd_attack = recording_attack
+    h.zero_grad()
+    ret = objectives.compute_barlowtwins_contrastive(h, deepcopy(batch))
+    # vilt_module.py:475 sums EVERY returned value whose key contains "loss": barlowtwins_loss AND the two logged components
+    # barlowtwins_loss_invariance_img / _redundancy_img, which are live graph tensors - the step optimises 2x the loss
+    loss = sum(v for kk, v in ret.items() if "loss" in kk)
+    loss.backward()
+    own = [t for is_own, t in seen if is_own]                                # the module's own head: clean k, then the attacked view
+    assert len(own) == 2 and len(deltas) == 1
+    out = {"barlowtwins_loss": np.float64(ret["barlowtwins_loss"].item()), "total_loss": np.float64(loss.item()), "k": own[0].numpy(), "q_image": own[1].numpy(),
+           "delta_sub": deltas[0][:, :, ::8, ::8].contiguous().numpy(), "delta_digest": tensor_digest(deltas[0]),
+           "delta_patch00": deltas[0][:, :, :32, :32].contiguous().numpy()}
+    for kk, v in ret.items():
+        if kk != "barlowtwins_loss":
+            out["ret_" + kk] = np.float64(float(v))
+    for kk, v in h.logged.items():
+        out["log_" + kk.replace("/", "__")] = np.float64(v)
+    gnames, gd = [], []
+    for n, prm in h.named_parameters():
+        if not n.startswith("k_") and prm.grad is not None:
+            gnames.append(n)
+            gd.append(tensor_digest(prm.grad))
+    out["grad_names"] = np.array(gnames)
+    out["grad_digest"] = np.stack(gd)
+    out["grad_bt_w1"] = h.barlowtwins_head.projector[0].weight.grad[:8, :64].numpy().copy()
+    out["grad_bt_w3"] = h.barlowtwins_head.projector[6].weight.grad[:8, :64].numpy().copy()
+    out["grad_bt_g2"] = h.barlowtwins_head.projector[4].weight.grad[:64].numpy().copy()
+    out["grad_pooler_w"] = h.pooler.dense.weight.grad[:8, :64].numpy().copy()
+    out["grad_qkv0_w"] = h.transformer.blocks[0].attn.qkv.weight.grad[:8, :64].numpy().copy()
+    for n, buf in h.barlowtwins_head.named_buffers():
+        out["buf_" + n.replace(".", "__")] = buf.detach().double().numpy() if buf.dtype != torch.int64 else np.int64(int(buf))
+    out["meta"] = np.array([B, seed_w, seed_b, int(ragged), cfg["num_layers"], cfg["adv_steps_img"], seed_h, dims[0], dims[1], dims[2]])
+    path = os.path.join(ROOT, "tests", "golden", f"barlow_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(tag, "barlowtwins_loss", out["barlowtwins_loss"], {k_: float(v) for k_, v in ret.items() if k_ != "barlowtwins_loss"},
+          "bytes", os.path.getsize(path))
+
+
 def run_pipeline():
     """Input-pipeline pieces (row f3) from the reference's own MinMaxResize (vilt/transforms/utils.py:5-26) and
     BaseDataset.collate (vilt/datasets/base_dataset.py:167-245; an unbound call - the method never touches self)."""
@@ -771,6 +841,9 @@ if __name__ == "__main__":
         if os.environ.get("PYTHONHASHSEED") != "0":
             sys.exit("txtwords: run with PYTHONHASHSEED=0 (the reference iterates Python sets of candidate words)")
         run_text_attack_words("L2_B4", small, 4, 11, 31, 21, 4, 5)
+    if want("barlow"):
+        run_barlow("L2_B4_ragged", dict(small, adv_steps_img=2), 4, 11, 41, 21, True, (512, 384, 256))
+        run_barlow("L2_B4_wide", dict(small, adv_steps_img=1), 4, 13, 42, 23, False, (8192, 8192, 8192))   # the reference's widths
     if want("sched"):
         run_schedules()
     if want("pipeline"):

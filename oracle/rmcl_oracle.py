@@ -39,7 +39,7 @@ def default_config(**over) -> dict:
         text_view=False, image_view=True, augmentation=False,
         adv_steps_img=3, adv_lr_img=0.05, adv_max_norm_img=0.005,
         num_gpus=1, num_nodes=1, per_gpu_batchsize=64, proj_dim=128, n_candidates=5, max_loops=10, seed=0,
-        loss_names={"moco": 1, "itm": 0},
+        loss_names={"moco": 1, "itm": 0}, adv_lr=0.0051,
     )
     cfg.update(over)
     return cfg
@@ -598,6 +598,148 @@ def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, p
     ret["moco_loss"] = loss / n
     ret["ptr"] = ptr
     return ret
+
+
+# --------------------------------------------------------------------------------------
+# Barlow-Twins variant
+# --------------------------------------------------------------------------------------
+BT_PREFIX = "barlowtwins_head."
+
+
+def bt_dims(cfg: dict) -> Tuple[int, int, int]:
+    """Widths of BarlowTwinsHead: the reference hard-codes [8192, 8192], 8192 (vilt_module.py:115)."""
+    return tuple(cfg.get("barlowtwins_dims", (8192, 8192, 8192)))
+
+
+def bt_param_shapes(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
+    """state-dict names of heads.BarlowTwinsHead (heads.py:88-107): projector = Sequential(Linear, BatchNorm1d, ReLU,
+    Linear, BatchNorm1d, ReLU, Linear), all linears without bias; norm = BatchNorm1d(affine=False) has buffers only."""
+    D = cfg["hidden_size"]
+    H1, H2, H3 = bt_dims(cfg)
+    n = BT_PREFIX + "projector."
+    return [(n + "0.weight", (H1, D)), (n + "1.weight", (H1,)), (n + "1.bias", (H1,)),
+            (n + "3.weight", (H2, H1)), (n + "4.weight", (H2,)), (n + "4.bias", (H2,)), (n + "6.weight", (H3, H2))]
+
+
+def bt_init_params(cfg: dict, seed: int) -> Params:
+    """Seeded head weights: linears ~ U(+-1/sqrt(fan_in)) (nn.Linear's default range - the reference never applies
+    init_weights to this head), BatchNorm gamma ~ 1 + N(0, 0.05), beta ~ N(0, 0.02) (not the (1, 0) default, which would
+    hide affine bugs)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    p: Params = {}
+    for name, shape in bt_param_shapes(cfg):
+        if len(shape) == 2:
+            p[name] = (torch.rand(shape, generator=g) * 2 - 1) / float(shape[1]) ** 0.5
+        elif name.endswith("weight"):
+            p[name] = 1.0 + 0.05 * torch.randn(shape, generator=g)
+        else:
+            p[name] = 0.02 * torch.randn(shape, generator=g)
+    return p
+
+
+def bt_running_init(cfg: dict) -> Params:
+    H1, H2, H3 = bt_dims(cfg)
+    out: Params = {}
+    for key, n in (("projector.1", H1), ("projector.4", H2), ("norm", H3)):
+        out[BT_PREFIX + key + ".running_mean"] = torch.zeros(n)
+        out[BT_PREFIX + key + ".running_var"] = torch.ones(n)
+        out[BT_PREFIX + key + ".num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    return out
+
+
+def batch_norm(x: Tensor, w: Optional[Tensor], b: Optional[Tensor], running: Optional[Params], key: str, training: bool,
+               eps: float = 1e-5, momentum: float = 0.1) -> Tensor:
+    """nn.BatchNorm1d: batch statistics (biased variance) in training, running estimates in eval; the running variance is
+    updated with the UNBIASED batch variance."""
+    if training:
+        mean = x.mean(0)
+        var = x.var(0, unbiased=False)
+        if running is not None:
+            n = x.shape[0]
+            with torch.no_grad():
+                running[key + ".running_mean"].mul_(1 - momentum).add_(momentum * mean)
+                running[key + ".running_var"].mul_(1 - momentum).add_(momentum * var * (n / (n - 1) if n > 1 else 1.0))
+                running[key + ".num_batches_tracked"] += 1
+    else:
+        mean, var = running[key + ".running_mean"], running[key + ".running_var"]
+    y = (x - mean) / torch.sqrt(var + eps)
+    if w is not None:
+        y = y * w + b
+    return y
+
+
+def barlowtwins_head(p: Params, cls: Tensor, running: Optional[Params] = None, training: bool = True) -> Tensor:
+    """BarlowTwinsHead.forward (heads.py:104-107)."""
+    n = BT_PREFIX + "projector."
+    h = cls @ p[n + "0.weight"].t()
+    h = torch.relu(batch_norm(h, p[n + "1.weight"], p[n + "1.bias"], running, n + "1", training))
+    h = h @ p[n + "3.weight"].t()
+    h = torch.relu(batch_norm(h, p[n + "4.weight"], p[n + "4.bias"], running, n + "4", training))
+    h = h @ p[n + "6.weight"].t()
+    return batch_norm(h, None, None, running, BT_PREFIX + "norm", training)
+
+
+def barlow_loss(zq: Tensor, zk: Tensor, denom: float, lam: float, gathered_c=None) -> Tuple[Tensor, Tensor, Tensor]:
+    """c = zq^T zk / denom; on_diag = sum (c_ii - 1)^2, off_diag = sum_{i != j} c_ij^2 (objectives.py:478-484).
+    ``gathered_c``: callable standing in for the all-reduce of c over ranks (:480)."""
+    c = zq.t() @ zk / denom
+    if gathered_c is not None:
+        c = gathered_c(c)
+    d = torch.diagonal(c)
+    on = ((d - 1) ** 2).sum()
+    off = (c ** 2).sum() - (d ** 2).sum()
+    return on + lam * off, on, off
+
+
+def bt_pgd_attack(p: Params, cfg: dict, batch: dict, k: Tensor, return_steps: bool = False):
+    """PGDAttack_bartlowtwins.pgd_attack (attack/pgd_attack_vilt.py:198-236): like the MoCo PGD with the loss
+    (on_diag + adv_lr * off_diag) / K on c = q^T k / B (LOCAL batch, no all-reduce); the head is a deep copy in train mode,
+    so its running statistics are not those of the module."""
+    K, lr, eps = cfg["adv_steps_img"], cfg["adv_lr_img"], cfg["adv_max_norm_img"]
+    img0 = batch["image"][0]
+    delta = torch.zeros_like(img0)
+    steps = []
+    for _ in range(K):
+        d = delta.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            out = infer(p, cfg, batch["text_ids"], batch["text_masks"], img0 + d)
+            q = barlowtwins_head(p, out["cls_feats"], None, True)
+            loss = barlow_loss(q, k, float(q.shape[0]), cfg["adv_lr"])[0] / float(K)
+            (g,) = torch.autograd.grad(loss, d)
+        den = g.abs().flatten(1).max(dim=1).values.clamp_min(1e-8).view(-1, 1, 1, 1)
+        delta = delta + lr * g / den
+        if eps > 0:
+            delta = delta.clamp(-eps, eps)
+        delta = delta.detach()
+        steps.append(delta.clone())
+    return (delta, steps) if return_steps else delta
+
+
+def compute_barlowtwins_contrastive(p: Params, cfg: dict, batch: dict, running: Optional[Params] = None, training: bool = True,
+                                    gathered_c=None) -> dict:
+    """objectives.compute_barlowtwins_contrastive (objectives.py:449-602), image view (the text view differs from MoCo's only
+    in the loss its greedy attack maximises, greedy_attack_vilt.py:602-700).  ONE encoder and ONE head (no momentum copies):
+    k = head(infer(clean)) under no_grad, q = head(infer(attacked)); BatchNorm runs in the module's mode, so in training
+    both calls use their own batch statistics and update the running estimates."""
+    if not cfg["image_view"]:
+        raise NotImplementedError("oracle: Barlow-Twins image view only")
+    ids, masks, img = batch["text_ids"], batch["text_masks"], batch["image"][0]
+    per_step_bs = cfg["num_gpus"] * cfg["num_nodes"] * cfg["per_gpu_batchsize"]
+    with torch.no_grad():
+        k = barlowtwins_head(p, infer(p, cfg, ids, masks, img)["cls_feats"], running, training)
+    pd = {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in p.items()}
+    delta, steps = bt_pgd_attack(pd, cfg, batch, k, return_steps=True)
+    prev = steps[-2] if len(steps) >= 2 else torch.zeros_like(delta)
+    attacked = img + prev + delta                                          # same in-place quirk as the MoCo path
+    out = infer(p, cfg, ids, masks, attacked)
+    q = barlowtwins_head(p, out["cls_feats"], running, training)
+    loss, on, off = barlow_loss(q, k, float(per_step_bs), cfg["adv_lr"], gathered_c)
+    cos = torch.nn.functional.cosine_similarity(q, k, dim=1, eps=1e-6)
+    return {"barlowtwins_loss": loss, "barlowtwins_loss_invariance_img": on, "barlowtwins_loss_redundancy_img": cfg["adv_lr"] * off,
+            "k": k, "q_image": q.detach(), "delta": delta, "attacked_image": attacked,
+            "pos_dist_attacked_img": (q - k).norm(dim=1).mean().detach(), "pos_cosine_attacked_img": cos.mean().detach(),
+            "pos_dot_attacked_img": (q * k).sum(1).mean().detach(), "delta_range": delta.norm(dim=1).mean()}
 
 
 # --------------------------------------------------------------------------------------

@@ -42,6 +42,13 @@ class Fold(C.Structure):
     _fields_ = [("wf", C.c_void_p), ("sc", C.c_void_p)]
 
 
+class BtHead(C.Structure):
+    """include/rmcl.h rmcl_bt_head: widths of the BarlowTwinsHead and the arena offsets of its tensors."""
+    _fields_ = [("D", C.c_int32), ("H1", C.c_int32), ("H2", C.c_int32), ("H3", C.c_int32),
+                ("w1", C.c_int64), ("g1", C.c_int64), ("b1", C.c_int64), ("w2", C.c_int64), ("g2", C.c_int64), ("b2", C.c_int64),
+                ("w3", C.c_int64)]
+
+
 class RmclError(RuntimeError):
     pass
 
@@ -54,7 +61,7 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     lib.rmcl_last_error.restype = C.c_char_p
     for name in ("rmcl_stash_bytes", "rmcl_workspace_bytes", "rmcl_heads_stash_bytes", "rmcl_infonce_ws_bytes",
-                 "rmcl_attention_scratch_elems", "rmcl_ln_fold_elems"):
+                 "rmcl_attention_scratch_elems", "rmcl_ln_fold_elems", "rmcl_bt_stash_floats", "rmcl_bt_loss_ws_floats"):
         getattr(lib, name).restype = C.c_int64
     return lib
 
@@ -70,6 +77,8 @@ EXPORTS = (
     "rmcl_wpa_cost_finish", "rmcl_wpa_distance", "rmcl_itm_fwd", "rmcl_itm_bwd",
     "rmcl_gemm", "rmcl_layernorm_fwd", "rmcl_layernorm_bwd", "rmcl_attention_scratch_elems", "rmcl_attention_fwd",
     "rmcl_attention_bwd",
+    "rmcl_bt_stash_floats", "rmcl_bt_head_forward", "rmcl_bt_head_backward", "rmcl_bt_corr", "rmcl_bt_loss_ws_floats", "rmcl_bt_loss",
+    "rmcl_bt_dz", "rmcl_bt_pair_metrics",
 )
 
 

@@ -1,7 +1,8 @@
 """PGD image attack on the MoCo objective.  Mirrors attack/pgd_attack_vilt.py:7-175 of the
 reference (class names, constructor keys, ``pgd_attack(pl_module, batch, k_modality)`` -> delta),
 but runs K x (encoder forward, InfoNCE, data-gradient backward, L-inf-normalised ascent step,
-eps-projection) as HIP kernels with no deepcopy of the encoder and no weight-gradient work."""
+eps-projection) as HIP kernels with no deepcopy of the encoder and no weight-gradient work.
+``PGDAttack_bartlowtwins`` (sic, :178-236) is the same loop on the Barlow-Twins cross-correlation loss."""
 from __future__ import annotations
 
 import torch
@@ -65,5 +66,42 @@ class PGDAttack_moco(PGDAttack):
         delta_p = self.attack_patches(pl_module, pb, k_modality)
         B = img_init.shape[0]
         # the reference leaves batch['image'][0] = img_init + delta_{K-1} behind (:144)
+        batch["image"][0] = img_init.to(eng.device) + eng.patches_to_image(pb.delta_prev, pb)
+        return eng.patches_to_image(delta_p, pb)
+
+
+class PGDAttack_bartlowtwins(PGDAttack):
+    """attack/pgd_attack_vilt.py:178-236 (the reference's spelling of the class name is kept): loss =
+    (on_diag + adv_lr * off_diag) / K on c = q^T k / B over the LOCAL batch, q = barlowtwins_head(cls_feats) with batch
+    statistics (the reference attacks a deep copy of the head in train mode, so the module's running estimates stay)."""
+
+    def __init__(self, config):
+        super().__init__(config, "barlowtwins")
+
+    def attack_patches(self, pl_module, pb, zk):
+        eng = pl_module.engine
+        K = self.adv_steps_img
+        bb = eng.bt_bufs(pb.B, "pgd")
+        pb.delta.zero_()
+        pb.delta_prev.zero_()
+        for step in range(K):
+            if step == K - 1 and K > 1:
+                pb.delta_prev.copy_(pb.delta)
+            op = eng.make_operand(pb, pb.delta)
+            eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+            eng.heads_forward(pb, key=False, want_q=False)
+            eng.bt_forward(bb, pb.cls, training=True, track=False)
+            eng.bt_loss(bb, zk, float(pb.B), pl_module.adv_lr, 1.0 / K, want_dz=True)
+            dcls = eng.bt_backward(bb, bb.dz, training=True, with_grads=False)
+            eng.heads_backward(pb, None, dcls, with_grads=False)
+            eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=pb.gpatch)
+            eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img)
+        return pb.delta
+
+    def pgd_attack(self, pl_module, batch, k_modality=None):
+        eng = pl_module.engine
+        img_init = batch["image"][0]
+        pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], img_init, tag="bt")
+        delta_p = self.attack_patches(pl_module, pb, k_modality.to(eng.device, torch.float32).contiguous())
         batch["image"][0] = img_init.to(eng.device) + eng.patches_to_image(pb.delta_prev, pb)
         return eng.patches_to_image(delta_p, pb)

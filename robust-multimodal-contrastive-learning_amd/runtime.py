@@ -79,6 +79,41 @@ def param_specs(cfg: dict, lay: L.Layout) -> List[Tuple[str, int, Tuple[int, ...
 EMA_GROUPS = ("text_embeddings", "token_type_embeddings", "transformer", "moco_head")
 
 
+def bt_layout(cfg: dict, base: int):
+    """BarlowTwinsHead (heads.py:88-107; widths [8192, 8192], 8192 at vilt_module.py:115, config key "barlowtwins_dims")
+    appended to the parameter arena at element offset `base`: returns (rmcl_bt_head struct, specs, elements used)."""
+    D = cfg["hidden_size"]
+    H1, H2, H3 = cfg.get("barlowtwins_dims", (8192, 8192, 8192))
+    off = base
+    offs = {}
+    n = "barlowtwins_head.projector."
+    shapes = [("w1", n + "0.weight", (H1, D)), ("g1", n + "1.weight", (H1,)), ("b1", n + "1.bias", (H1,)),
+              ("w2", n + "3.weight", (H2, H1)), ("g2", n + "4.weight", (H2,)), ("b2", n + "4.bias", (H2,)), ("w3", n + "6.weight", (H3, H2))]
+    specs = []
+    for key, name, shape in shapes:
+        offs[key] = off
+        specs.append((name, off, shape))
+        cnt = 1
+        for v in shape:
+            cnt *= v
+        off += (cnt + 63) // 64 * 64
+    return L.BtHead(D=D, H1=H1, H2=H2, H3=H3, **offs), specs, off - base
+
+
+class BtBuffers:
+    """Per-pass buffers of the Barlow-Twins head: its stash, the projection z, d loss / dz and the distance rows."""
+
+    def __init__(self, eng: "Engine", B: int):
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=eng.device)
+        self.B = B
+        self.stash = f32(int(lib.rmcl_bt_stash_floats(C.byref(eng.bt), B)))
+        self.z = f32(B, eng.bt.H3)
+        self.dz = f32(B, eng.bt.H3)
+        self.dcls = f32(B, eng.bt.D)
+        self.rows = f32(B, 3)
+        self.loss2 = f32(2)
+
+
 class PassBuffers:
     """Everything sized by the per-GPU batch B (allocated once, reused every step)."""
 
@@ -155,10 +190,23 @@ class Engine:
         lib.rmcl_param_layout(C.byref(d0), C.byref(self.layout))
         lay = self.layout
         z = lambda n, dt=torch.float32: torch.zeros(int(n), dtype=dt, device=self.device)
-        self.q32 = z(lay.total)
+        # optional Barlow-Twins head (loss_names["barlowtwins"] > 0): appended behind the C layout's tensors, so the optimizer,
+        # the gradient reduction and the state dict see it as part of the same arena
+        self.bt, self.bt_specs, extra = None, [], 0
+        if cfg.get("loss_names", {}).get("barlowtwins", 0) > 0:
+            self.bt, self.bt_specs, extra = bt_layout(cfg, int(lay.total))
+            H = self.bt
+            self.bt_running = torch.cat([torch.zeros(H.H1), torch.ones(H.H1), torch.zeros(H.H2), torch.ones(H.H2), torch.zeros(H.H3),
+                                         torch.ones(H.H3)]).to(self.device)      # [mean1, var1, mean2, var2, mean3, var3]
+            self.bt_tracked = torch.zeros(3, dtype=torch.int64, device=self.device)
+            self.bt_corr = torch.empty(H.H3, H.H3, dtype=torch.float32, device=self.device)
+            self.bt_ws = torch.empty(int(lib.rmcl_bt_loss_ws_floats(H.H3)), dtype=torch.float32, device=self.device)
+            self._bt_bufs = {}
+        self.total = int(lay.total) + extra
+        self.q32 = z(self.total)
         self.k32 = z(lay.ema_end)
-        self.g32 = z(lay.total)
-        self.q_lp = z(lay.total, torch.bfloat16) if self.dtype == L.BF16 else None
+        self.g32 = z(self.total)
+        self.q_lp = z(self.total, torch.bfloat16) if self.dtype == L.BF16 else None
         self.k_lp = z(lay.ema_end, torch.bfloat16) if self.dtype == L.BF16 else None
         # LayerNorm folded into the qkv / fc1 GEMMs of the passes that keep no LayerNorm output (include/rmcl.h rmcl_fold):
         # W' = W * gamma (bf16) + the s / c vectors per arena, re-derived whenever the fp32 masters change
@@ -172,7 +220,7 @@ class Engine:
         # transposed bf16 shadows of the layer weights for the data-gradient GEMMs (include/rmcl.h rmcl_weight_transpose_bf16)
         self.q_lpT = z(lay.total, torch.bfloat16) if (self.dtype == L.BF16 and os.environ.get("RMCL_NO_WT", "0") != "1") else None
         self.lpT_stale = True
-        self.specs = param_specs(cfg, lay)
+        self.specs = param_specs(cfg, lay) + self.bt_specs
         self._bufs: Dict[tuple, PassBuffers] = {}
         self.lp_stale = True
         self.drop_p = float(cfg.get("drop_rate", 0.0))
@@ -412,6 +460,43 @@ class Engine:
                                         P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), int(cls_only), P(dpatches), P(dtext),
                                         P(self.g32 if mode == L.MODE_FULL else None), C.c_uint32(seed), F(p), self._rg(pb),
                                         P(self.weights_T() if pb.dtype == L.BF16 else None), stream_ptr()), "encoder_backward")
+
+    # ---- Barlow-Twins head (include/rmcl.h rmcl_bt_*) --------------------------------------------------------------
+    def bt_bufs(self, B: int, tag: str) -> BtBuffers:
+        if (B, tag) not in self._bt_bufs:
+            self._bt_bufs[(B, tag)] = BtBuffers(self, B)
+        return self._bt_bufs[(B, tag)]
+
+    def bt_forward(self, bb: BtBuffers, cls: torch.Tensor, training: bool, track: bool):
+        """z = barlowtwins_head(cls_feats).  training: batch statistics; track: also update the module's running estimates (the
+        module's own head does, the PGD / text attack's deep copy of it does not: pgd_attack_vilt.py:189)."""
+        run = self.bt_running if (track or not training) else None
+        check(lib.rmcl_bt_head_forward(C.byref(self.bt), P(self.q32), P(cls), bb.B, int(training), P(run), F(0.1), P(bb.stash), P(bb.z),
+                                       stream_ptr()), "bt_head_forward")
+        if training and track:
+            self.bt_tracked += 1
+        return bb.z
+
+    def bt_backward(self, bb: BtBuffers, dz: torch.Tensor, training: bool, with_grads: bool):
+        check(lib.rmcl_bt_head_backward(C.byref(self.bt), P(self.q32), P(bb.stash), P(dz), bb.B, int(training),
+                                        P(self.g32 if with_grads else None), P(bb.dcls), stream_ptr()), "bt_head_backward")
+        return bb.dcls
+
+    def bt_loss(self, bb: BtBuffers, zk: torch.Tensor, denom: float, lam: float, grad_scale: float, want_dz: bool, reduce_c=None):
+        """loss2 = (on_diag, off_diag) of c = z^T zk / denom (objectives.py:478-484); dz = d(grad_scale (on + lam off))/dz.
+        reduce_c: callable run on the correlation matrix between its computation and the loss (the all-reduce of :480)."""
+        N = self.bt.H3
+        check(lib.rmcl_bt_corr(P(bb.z), P(zk), bb.B, N, F(1.0 / denom), P(self.bt_corr), stream_ptr()), "bt_corr")
+        if reduce_c is not None:
+            reduce_c(self.bt_corr)
+        check(lib.rmcl_bt_loss(P(self.bt_corr), N, F(lam), F(grad_scale), P(self.bt_ws), P(bb.loss2), stream_ptr()), "bt_loss")
+        if want_dz:
+            check(lib.rmcl_bt_dz(P(zk), P(self.bt_corr), bb.B, N, F(1.0 / denom), P(bb.dz), stream_ptr()), "bt_dz")
+        return bb.loss2
+
+    def bt_pair_metrics(self, bb: BtBuffers, zk: torch.Tensor):
+        check(lib.rmcl_bt_pair_metrics(P(bb.z), P(zk), bb.B, self.bt.H3, P(bb.rows), stream_ptr()), "bt_pair_metrics")
+        return bb.rows
 
     def pgd_step(self, pb: PassBuffers, lr: float, eps: float):
         per = pb.d.P * pb.d.patch_k

@@ -41,3 +41,18 @@ def task_moco(**over):
     )
     cfg.update(over)
     return cfg
+
+
+def task_barlowtwins(**over):
+    """reference config.py:166-199: the Barlow-Twins variant of the contrastive pre-training.
+    barlowtwins_dims: widths of BarlowTwinsHead - the reference hard-codes [8192, 8192], 8192 (vilt_module.py:115)."""
+    cfg = default_config(
+        exp_name="barlowtwins", Multimodal=True, augmentation=False, text_view=False, image_view=False,
+        loss_names=_loss_names({"barlowtwins": 1}), adv_lr=0.0051, batch_size=128, max_epoch=1, max_image_len=200, test_only=False,
+        adv_steps_img=5, adv_lr_img=0.05, adv_max_norm_img=0.005,
+        n_candidates=5, max_loops=10, sim_thred=0.5, cos_sim=True, synonym="cos_sim",
+        embedding_path="../attack/counter-fitted-vectors.txt", sim_path="../attack/cos_sim_counter_fitting.npy", stopwords=None,
+        TSNE_vizualisation=False, img_save_path="", barlowtwins_dims=(8192, 8192, 8192),
+    )
+    cfg.update(over)
+    return cfg

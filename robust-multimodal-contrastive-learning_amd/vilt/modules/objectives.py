@@ -311,3 +311,78 @@ def compute_moco_contrastive(pl_module, batch):
             pl_module.log(f"moco_dist_{phase}_{tag}/Neg_attacked_{v}", neg)
             pl_module.log(f"moco_dist_{phase}_{tag}/Neg-Pos_attacked_{v}", neg - pos)
     return ret
+
+
+def compute_barlowtwins_contrastive(pl_module, batch):
+    """objectives.py:449-602, image view: ONE encoder and one head.  k = head(infer(clean)) under no_grad,
+    q = head(infer(img + delta_{K-1} + delta_K)) after the PGD of attack/pgd_attack_vilt.py:178-236,
+    c = q^T k / per_step_bs, summed over ranks (:480), loss = sum_i (c_ii - 1)^2 + adv_lr * sum_{i != j} c_ij^2 (the reference
+    uses its `adv_lr` hyper-parameter as the redundancy weight).  The head's BatchNorms run in the module's mode and - in
+    training - update their running estimates in BOTH calls, like nn.BatchNorm1d does under no_grad too."""
+    eng = pl_module.engine
+    if pl_module.augmentation:
+        raise NotImplementedError("augmentation views are out of scope (SURVEY 2.1 #17)")
+    if pl_module.text_view:
+        raise NotImplementedError("Barlow-Twins text view (GreedyAttack_barlowtwins, greedy_attack_vilt.py:602-700) is not built; "
+                                  "image_view=True, text_view=False runs")
+    if not pl_module.image_view:
+        raise ZeroDivisionError("division by zero: loss / loss_num with both views off (objectives.py:451-452,548)")
+    phase = "train" if pl_module.training else "val"
+    training = bool(pl_module.training)
+    need_grad = torch.is_grad_enabled() and training
+    ret = {}
+    pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], batch["image"][0], tag="bt")
+    B = pb.B
+    op = eng.make_operand(pb)
+    bk = eng.bt_bufs(B, "k")
+    eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)          # :460-462
+    eng.heads_forward(pb, key=False, want_q=False)
+    zk = eng.bt_forward(bk, pb.cls, training, track=training)
+    pl_module.pgd_attacker.attack_patches(pl_module, pb, zk)                    # compute_pgd (:503)
+    check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3, pb.d.patch_k // 3, stream_ptr()),
+          "delta_norm")
+    n_pix = pb.delta.numel() // 3 if pb.geom is None else pb.B * pb.geom.shape[2] * pb.geom.shape[3]
+    pl_module.log(f"barlowtwins_attack/{phase}/delta", _scalar(pb.loss_sum / float(n_pix)))
+    op_att = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pb.patchesT_full)
+    eng.encoder_forward(pb, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op_att)
+    eng.heads_forward(pb, key=False, want_q=False)
+    bq = eng.bt_bufs(B, "q")
+    eng.bt_forward(bq, pb.cls, training, track=training)
+
+    def reduce_c(c):                                                            # torch.distributed.all_reduce(c_1) (:507)
+        if dist_utils.world_size() > 1:
+            torch.distributed.all_reduce(c)
+
+    loss2 = eng.bt_loss(bq, zk, float(pl_module.per_step_bs), pl_module.adv_lr, 1.0, want_dz=need_grad, reduce_c=reduce_c)
+    on_diag, off_diag = loss2[0].clone(), loss2[1].clone()
+    rows = eng.bt_pair_metrics(bq, zk)
+    ret["barlowtwins_loss_invariance_img"] = on_diag
+    ret["barlowtwins_loss_redundancy_img"] = pl_module.adv_lr * off_diag
+    ret["pos_dist_attacked_img"], ret["pos_cosine_attacked_img"], ret["pos_dot_attacked_img"] = rows[:, 0].mean(), rows[:, 1].mean(), rows[:, 2].mean()
+    ret["k"], ret["q_image"] = zk.clone(), bq.z.clone()
+    value = _scalar(on_diag + pl_module.adv_lr * off_diag)
+    if need_grad:
+        dz_saved = bq.dz.clone()
+
+        def backward(grad_out, pb=pb, bq=bq, dz_saved=dz_saved, op=op_att):
+            dz = dz_saved * grad_out.to(dz_saved.dtype)
+            dcls = eng.bt_backward(bq, dz, training=True, with_grads=True)
+            eng.heads_backward(pb, None, dcls, with_grads=True)
+            eng.encoder_backward(pb, L.MODE_FULL, op, pb.dcls, cls_only=True, dpatches=None)
+            pl_module.after_backward(overlap=True)
+
+        # NOTE on ranks: the reference all-reduces c WITHOUT autograd support, so each rank backpropagates d loss(c_global) / dq
+        # of its own rows and DDP then AVERAGES the gradients - the 1/world_size of that average is the prescale below
+        value = _DeferredBackward.apply(pl_module.grad_anchor, value, backward, pl_module.grad_prescale())
+        # Reference behaviour: training_step sums every returned value whose key contains "loss" (vilt_module.py:475), and
+        # the two logged components ARE live graph tensors there (:486-487) - the step optimises loss + on_diag +
+        # adv_lr * off_diag = 2 x the loss.  The components therefore carry the same deferred backward (as a zero-valued term).
+        ret["barlowtwins_loss_invariance_img"] = on_diag + (value - value.detach())
+    ret["barlowtwins_loss"] = value / 1                                         # loss / loss_num with one view (:548)
+    pl_module.log(f"barlowtwins/{phase}/loss", ret["barlowtwins_loss"].detach())
+    pl_module.log(f"barlowtwins_dist_{phase}_L2/Pos_attacked_img", ret["pos_dist_attacked_img"])
+    pl_module.log(f"barlowtwins_dist_{phase}_Cosine/Pos_attacked_img", ret["pos_cosine_attacked_img"])
+    pl_module.log(f"barlowtwins_dist_{phase}_Dot/Pos_attacked_img", ret["pos_dot_attacked_img"])
+    pl_module.log(f"barlowtwins/{phase}/barlowtwins_loss_invariance_img", on_diag)
+    pl_module.log(f"barlowtwins/{phase}/barlowtwins_loss_redundancy_img", ret["barlowtwins_loss_redundancy_img"])
+    return ret

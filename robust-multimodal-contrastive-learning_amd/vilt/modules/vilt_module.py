@@ -16,7 +16,7 @@ import torch.nn as nn
 from ... import _lib as L
 from ..._lib import lib, check
 from ...runtime import Engine, EMA_GROUPS
-from ...attack.pgd_attack_vilt import PGDAttack_moco
+from ...attack.pgd_attack_vilt import PGDAttack_moco, PGDAttack_bartlowtwins
 from ...attack.greedy_attack_vilt import GreedyAttack_moco
 from . import objectives, vilt_utils, dist_utils
 
@@ -80,6 +80,28 @@ class ViLTransformerSS(nn.Module):
                 self.pgd_attacker = PGDAttack_moco(config)
             if self.text_view and not self.augmentation:
                 self.greedy_attacker = GreedyAttack_moco(config)
+        if config["loss_names"].get("barlowtwins", 0) > 0:                 # vilt_module.py:109-131
+            self.multimodal = config.get("Multimodal", True)
+            self.per_step_bs = config["num_gpus"] * config["num_nodes"] * config["per_gpu_batchsize"]
+            self.text_view = config["text_view"]
+            self.image_view = config["image_view"]
+            self.augmentation = config["augmentation"]
+            self.adv_lr = config["adv_lr"]
+            self.loss_weight = 0.001
+            H = eng.bt
+            o = 0
+            for i, (key, n) in enumerate((("projector.1", H.H1), ("projector.4", H.H2), ("norm", H.H3))):
+                node = self                                               # nn.BatchNorm1d buffers under the reference's names
+                for part in ("barlowtwins_head." + key).split("."):
+                    if part not in node._modules:
+                        node.add_module(part, _Node())
+                    node = node._modules[part]
+                node.register_buffer("running_mean", eng.bt_running[o:o + n])
+                node.register_buffer("running_var", eng.bt_running[o + n:o + 2 * n])
+                node.register_buffer("num_batches_tracked", eng.bt_tracked[i])
+                o += 2 * n
+            if self.image_view and not self.augmentation:
+                self.pgd_attacker = PGDAttack_bartlowtwins(config)
         self.grad_anchor = torch.zeros((), device=eng.device, requires_grad=True)
         self.sync_grads = True                     # False on the early micro-steps of gradient accumulation (DDP no_sync)
         self.step_sync = dist_utils.StepGradSync(algo=config.get("grad_allreduce_algo", "ring"), compress=config.get("grad_allreduce_dtype"))
@@ -112,7 +134,13 @@ class ViLTransformerSS(nn.Module):
                 continue
             leaf = name.split(".")[-1]
             is_ln = any(t in name for t in ("LayerNorm", "norm1", "norm2", "transformer.norm", "projector.1"))
-            if is_ln:
+            if name.startswith("barlowtwins_head."):
+                # never passed through init_weights in the reference (vilt_module.py:115): nn.Linear / nn.BatchNorm1d defaults
+                if p.dim() == 2:
+                    nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+                else:
+                    p.fill_(1.0 if leaf == "weight" else 0.0)
+            elif is_ln:
                 p.fill_(1.0 if leaf == "weight" else 0.0)
             elif name.startswith("transformer.patch_embed.proj"):
                 # the reference leaves the patch projection at nn.Conv2d's default init (vision_transformer.py:397-403;
@@ -258,7 +286,9 @@ class ViLTransformerSS(nn.Module):
             ret.update(objectives.compute_itm_wpa(self, batch))
         if "moco" in self.current_tasks:
             ret.update(objectives.compute_moco_contrastive(self, batch))
-        unsupported = [t for t in self.current_tasks if t not in ("itm", "moco")]
+        if "barlowtwins" in self.current_tasks:
+            ret.update(objectives.compute_barlowtwins_contrastive(self, batch))
+        unsupported = [t for t in self.current_tasks if t not in ("itm", "moco", "barlowtwins")]
         if unsupported:
             raise NotImplementedError(f"tasks {unsupported} are outside the RMCL hot path (SURVEY 8)")
         return ret

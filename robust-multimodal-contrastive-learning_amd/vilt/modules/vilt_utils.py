@@ -49,7 +49,7 @@ class FusedAdamW:
         ends, mults, wds = [], [], []
         specs = sorted(eng.specs, key=lambda s: s[1])
         for i, (name, off, shape) in enumerate(specs):
-            end = specs[i + 1][1] if i + 1 < len(specs) else eng.layout.total
+            end = specs[i + 1][1] if i + 1 < len(specs) else eng.total
             decay = not any(nd in name for nd in NO_DECAY)
             head = any(bb in name for bb in HEAD_NAMES)
             ends.append(end)
