@@ -91,7 +91,7 @@ import vilt.modules.vision_transformer as vit  # noqa: E402  (reference, unmodif
 import vilt.modules.heads as heads  # noqa: E402
 import vilt.modules.objectives as objectives  # noqa: E402
 from attack.pgd_attack_vilt import PGDAttack, PGDAttack_moco, PGDAttack_bartlowtwins  # noqa: E402
-from attack.greedy_attack_vilt import GreedyAttack_moco  # noqa: E402
+from attack.greedy_attack_vilt import GreedyAttack_moco, GreedyAttack_barlowtwins  # noqa: E402
 from transformers.models.bert.modeling_bert import BertConfig, BertEmbeddings  # noqa: E402
 
 
@@ -717,6 +717,133 @@ def run_barlow(tag, cfg, B, seed_w, seed_h, seed_b, ragged, dims):
           "bytes", os.path.getsize(path))
 
 
+def run_barlow_views(tag, cfg, B, seed_w, seed_h, seed_b, dims, max_loops, n_cand):
+    """The three-view Barlow-Twins step (text / image / both) from the reference's compute_barlowtwins_contrastive with its
+    own GreedyAttack_barlowtwins (greedy_attack_vilt.py:602-830) on the toy linguistic resources and PGDAttack_bartlowtwins,
+    then the backward of training_step's loss sum.  The attacker object is made with __new__ (its __init__ downloads a
+    tokenizer / loads nltk) exactly like run_text_attack_words.  PYTHONHASHSEED=0 (candidate sets)."""
+    import tempfile
+    from transformers import BertTokenizer
+    from torch.nn import CosineSimilarity
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+
+    class Tok(BertTokenizer):
+        def _convert_token_to_id(self, token):
+            return self.convert_tokens_to_ids(token)
+
+    gold = write_toy_resources()
+    with open(os.path.join(gold, "toy_vocab.txt")) as f:
+        vocab = {line.rstrip("\n"): i for i, line in enumerate(f)}
+    tok = Tok(vocab=vocab, do_lower_case=True)
+    torch.manual_seed(555)
+    cfg = dict(cfg, per_gpu_batchsize=B, barlowtwins_dims=tuple(dims), image_view=True, text_view=True, max_loops=max_loops, n_candidates=n_cand)
+    p = O.init_params(cfg, seed_w)
+    hp = O.bt_init_params(cfg, seed_h)
+    h = Holder(cfg)
+    h.barlowtwins_head = heads.BarlowTwinsHead(cfg["hidden_size"], [dims[0], dims[1]], dims[2])
+    h.adv_lr = cfg["adv_lr"]
+    h.pgd_attacker = PGDAttack_bartlowtwins(cfg)
+    for name in ("train", "val"):
+        for met in ("barlowtwins_loss",) + tuple(f"barlowtwins_loss_{a}_{b}" for a in ("invariance", "redundancy") for b in ("img", "text", "both")):
+            setattr(h, f"{name}_{met}", lambda x: x)
+    h.load_oracle_params(dict(p, **hp))
+    h.train()
+    g = GreedyAttack_barlowtwins.__new__(GreedyAttack_barlowtwins)
+    g.pl_module, g.contrastive_framework = None, "barlowtwins"
+    g.stopwords = set(TOY_STOP)
+    g.cosine_similarity = CosineSimilarity(dim=1, eps=1e-6)
+    g.tokenizer = tok
+    g.device, g.words_to_sub_words = None, None
+    g.max_length, g.n_candidates, g.max_loops, g.sim_thred = cfg["max_text_len"], n_cand, max_loops, 0.5
+    g.word2id = tok.get_vocab()
+    g.id2word = {v: kk for kk, v in g.word2id.items()}
+    g.cos_sim = g.sim_word2id = g.sim_id2word = g.cos_sim_dict = None
+    g.synonym = "cos_sim"
+    g.max_image_len = cfg["max_image_len"]
+    g.barlowtwins_head = None
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            g.init_matrix(os.path.join(gold, "toy_counter_fitted.txt"), os.path.join(tmp, "absent.npy"))
+        finally:
+            os.chdir(cwd)
+    h.greedy_attacker = g
+    batch = O.synthetic_batch(cfg, B, seed_b)
+    sentences = TOY_SENTENCES[:B]
+    enc = tok(sentences, truncation=True, padding="max_length", max_length=cfg["max_text_len"], return_special_tokens_mask=True)
+    batch["text"] = list(sentences)
+    batch["text_ids"] = torch.tensor(enc["input_ids"])
+    batch["text_masks"] = torch.tensor(enc["attention_mask"])
+    # keys the reference's Barlow-Twins text attack copies per candidate (:752-760); their values never reach the arithmetic
+    batch["cap_index"] = batch["replica"] = batch["img_index"] = batch["raw_index"] = list(range(B))
+    batch["text_ids_mlm"] = batch["text_ids"].clone()
+    batch["text_labels_mlm"] = batch["text_labels"].clone()
+    ids_in, masks_in = batch["text_ids"].numpy().copy(), batch["text_masks"].numpy().copy()
+    trace = {"replace_idx": [], "best_idx": [], "all_new_text": []}
+    cwi, spf, cns = g.compute_word_importance, g.split_forward, g.construct_new_samples
+
+    def w_cwi(**kw):
+        o_ = cwi(**kw)
+        trace["replace_idx"].append([-1 if x is None else int(x) for x in o_[0]])
+        return o_
+
+    def w_spf(*a, **kw):
+        o_ = spf(*a, **kw)
+        trace["best_idx"].append([int(j) for _, j in o_])
+        return o_
+
+    def w_cns(**kw):
+        o_ = cns(**kw)
+        trace["all_new_text"].append(list(o_[0]))
+        return o_
+
+    g.compute_word_importance, g.split_forward, g.construct_new_samples = w_cwi, w_spf, w_cns
+    geo = objectives.compute_geometric
+    attacked = {}
+
+    def rec_geo(pl_module, b_, name, k_modality=None):
+        out_ = geo(pl_module, b_, name, k_modality=k_modality)
+        attacked["text"], attacked["ids"], attacked["masks"] = list(out_["text"]), out_["text_ids"].clone(), out_["text_masks"].clone()
+        return out_
+
+    objectives.compute_geometric = rec_geo
+    try:
+        h.zero_grad()
+        ret = objectives.compute_barlowtwins_contrastive(h, deepcopy(batch))
+    finally:
+        objectives.compute_geometric = geo
+    loss = sum(v for kk, v in ret.items() if "loss" in kk)                        # vilt_module.py:475
+    loss.backward()
+    words = sorted(g.sim_word2id, key=g.sim_word2id.get)
+    out = {"total_loss": np.float64(loss.item()), "text_in": np.array(sentences), "text_ids_in": ids_in, "text_masks_in": masks_in,
+           "text_out": np.array(attacked["text"]), "text_ids_out": attacked["ids"].numpy(), "text_masks_out": attacked["masks"].numpy(),
+           "replace_idx": np.array(trace["replace_idx"]), "best_idx": np.array(trace["best_idx"]),
+           "syn_words": np.array(words), "syn_cands": np.array(["|".join(g.cos_sim_dict[g.sim_word2id[w]]) for w in words])}
+    for li, t in enumerate(trace["all_new_text"]):
+        out[f"new_text_{li}"] = np.array(t)
+    for kk, v in ret.items():
+        out["ret_" + kk] = np.float64(float(v))
+    for kk, v in h.logged.items():
+        out["log_" + kk.replace("/", "__")] = np.float64(v)
+    gnames, gd = [], []
+    for n, prm in h.named_parameters():
+        if not n.startswith("k_") and prm.grad is not None:
+            gnames.append(n)
+            gd.append(tensor_digest(prm.grad))
+    out["grad_names"] = np.array(gnames)
+    out["grad_digest"] = np.stack(gd)
+    for n, buf in h.barlowtwins_head.named_buffers():
+        out["buf_" + n.replace(".", "__")] = buf.detach().double().numpy() if buf.dtype != torch.int64 else np.int64(int(buf))
+    out["meta"] = np.array([B, seed_w, seed_b, cfg["num_layers"], cfg["adv_steps_img"], seed_h, dims[0], dims[1], dims[2], max_loops, n_cand])
+    path = os.path.join(ROOT, "tests", "golden", f"barlow3_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(tag, "three views total", out["total_loss"], attacked["text"], "replace", trace["replace_idx"], "best", trace["best_idx"],
+          "bytes", os.path.getsize(path))
+
+
 def run_pipeline():
     """Input-pipeline pieces (row f3) from the reference's own MinMaxResize (vilt/transforms/utils.py:5-26) and
     BaseDataset.collate (vilt/datasets/base_dataset.py:167-245; an unbound call - the method never touches self)."""
@@ -844,6 +971,10 @@ if __name__ == "__main__":
     if want("barlow"):
         run_barlow("L2_B4_ragged", dict(small, adv_steps_img=2), 4, 11, 41, 21, True, (512, 384, 256))
         run_barlow("L2_B4_wide", dict(small, adv_steps_img=1), 4, 13, 42, 23, False, (8192, 8192, 8192))   # the reference's widths
+    if want("barlow3"):
+        if os.environ.get("PYTHONHASHSEED") != "0":
+            sys.exit("barlow3: run with PYTHONHASHSEED=0 (the reference iterates Python sets of candidate words)")
+        run_barlow_views("L2_B4", dict(small, adv_steps_img=2), 4, 11, 41, 21, (512, 384, 256), 3, 5)
     if want("sched"):
         run_schedules()
     if want("pipeline"):

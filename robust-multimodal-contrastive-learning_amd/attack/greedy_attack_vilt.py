@@ -138,57 +138,19 @@ class GreedyAttack:
             changed.append(True)
         return all_new_text, all_num, changed
 
-    def adv_attack_samples(self, pl_module, batch, k_modality):
+    # ---- framework hooks (get_grad / split_forward of the reference's subclasses) -----------------------------------
+    def bind_keys(self, pl_module, pb, k):
         raise NotImplementedError(f"adv_attack_samples of {self.contrastive_framework} isn't implemented.")
 
+    def bind_candidate_keys(self, pc, k, own):
+        pass
 
-class GreedyAttack_moco(GreedyAttack):
-    def __init__(self, config, candidate_fn: Optional[Callable] = None, tokenizer=None, stopwords=None, synonyms=None):
-        super().__init__(config, "moco", candidate_fn, tokenizer, stopwords, synonyms)
-
-    # ---- tensor side, same method names as the reference ----------------------------------------------------------
     def get_grad(self, pl_module, pb, op, de):
-        """get_grad (:406-452): forward, batch-mean InfoNCE, backward to the OUTPUT of word_embeddings (what the
-        reference's backward hook captures).  Returns (per-row CE [B], grads view [B,L,D] = `de`, q [B,128])."""
-        eng = pl_module.engine
-        Bn = pb.B
-        eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
-        eng.heads_forward(pb, key=False)
-        eng.infonce(pb, 1.0 / Bn, want_dq=True)
-        ce0 = pb.rows[:, 0].clone()
-        eng.heads_backward(pb, pb.dq, None, with_grads=False)
-        eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=None, dtext=de)
-        return ce0, de.view(Bn, pb.d.L, -1), pb.q
+        raise NotImplementedError(f"get_grad of {self.contrastive_framework} isn't implemented.")
 
-    def split_forward(self, pl_module, pc, n_real):
-        """split_forward (:454-492), device part: candidates through the encoder, per-row CE against the same keys."""
-        eng = pl_module.engine
-        eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT)
-        eng.heads_forward(pc, key=False)
-        eng.infonce(pc, 0.0, want_dq=False)
-        return pc.rows[:n_real, 0]
-
-    @staticmethod
-    def select(ce0, cec, owner, n_real, Bn):
-        """split_forward's scoring (:466-490) on per-row CE values.  The reference evaluates the BATCH-MEAN loss with row
-        i replaced by candidate j and compares it with the original batch mean.  Its `t_save = ori_z[i]` (:475) is a
-        view, so the restore at :489 is a no-op and row i keeps its LAST candidate while later samples are scored:
-            loss_ij = mean(ce0) + sum_{r<i} (ce_{r,last} - ce0_r)/B + (ce_ij - ce0_i)/B
-        Returns [(losses, best index or -1)] per sample (first maximum, strict >, like :485-486)."""
-        ori = float(sum(ce0) / Bn)
-        out, drift, start = [], 0.0, 0
-        for b in range(Bn):
-            idx = [i for i in range(start, n_real) if owner[i] == b]
-            start = idx[-1] + 1
-            best, best_j, losses = ori, -1, []
-            for j, r in enumerate(idx):
-                lj = ori + drift + (cec[r] - ce0[b]) / Bn
-                losses.append(lj)
-                if lj > best:
-                    best, best_j = lj, j
-            drift += (cec[idx[-1]] - ce0[b]) / Bn
-            out.append((losses, best_j))
-        return out
+    def score(self, pl_module, pc, ctx, owner, n_real, Bn):
+        """split_forward: [(candidate losses, index of the best candidate or -1)] per sample"""
+        raise NotImplementedError(f"split_forward of {self.contrastive_framework} isn't implemented.")
 
     def adv_attack_samples(self, pl_module, batch, k_modality):
         if self.tokenizer is not None:
@@ -216,14 +178,14 @@ class GreedyAttack_moco(GreedyAttack):
         op = eng.make_operand(pb)                                   # clean image, shared by every loop
         de = torch.empty(Bn * Lt, pb.d.D, device=dev)
         k = k_modality.to(dev, torch.float32).contiguous()
-        pb.k.copy_(k)
+        self.bind_keys(pl_module, pb, k)
         text = [" ".join(w) for w in cur_words]
         self.trace = []                                             # per loop: (replace_idx, all_new_text, all_num, picks) for tests
 
         for loop in range(self.max_loops):
             pb.text_ids = ids_host.to(dev)
             pb.text_mask = masks_host.to(dev)
-            ce0, grads, _ = self.get_grad(pl_module, pb, op, de)
+            ctx, grads, _ = self.get_grad(pl_module, pb, op, de)
             replace_idx = self.compute_word_importance(cur_words, ids_host, grads.cpu().numpy(), Bn)
             all_new_text, all_num, changed = self.construct_new_samples(replace_idx, cur_words, Bn)
             n_real = len(all_new_text)
@@ -237,9 +199,8 @@ class GreedyAttack_moco(GreedyAttack):
             pc.text_ids = torch.cat([cids, ids_host[:1].expand(pad, Lt)]).to(dev).contiguous()
             pc.text_mask = torch.cat([cmasks, masks_host[:1].expand(pad, Lt)]).to(dev).contiguous()
             torch.index_select(op.view(Bn, -1), 0, own, out=pc.patchesT.view(Bc, -1))
-            pc.k.copy_(k.index_select(0, own))
-            cec = self.split_forward(pl_module, pc, n_real).cpu().tolist()
-            picks = self.select(ce0.cpu().tolist(), cec, owner, n_real, Bn)
+            self.bind_candidate_keys(pc, k, own)
+            picks = self.score(pl_module, pc, ctx, owner, n_real, Bn)
             count = 0
             for b, (losses, best_j) in enumerate(picks):
                 if changed[b] and best_j > 0:
@@ -273,7 +234,7 @@ class GreedyAttack_moco(GreedyAttack):
         op = eng.make_operand(pb)                                   # clean image, shared by every loop
         de = torch.empty(Bn * Lt, pb.d.D, device=dev)
         k = k_modality.to(dev, torch.float32).contiguous()
-        pb.k.copy_(k)
+        self.bind_keys(pl_module, pb, k)
         orig = ids_host.clone()
         history = [set() for _ in range(Bn)]
         changes = [0] * Bn
@@ -281,7 +242,7 @@ class GreedyAttack_moco(GreedyAttack):
 
         for loop in range(self.max_loops):
             pb.text_ids = ids_host.to(dev)
-            ce0, grads, _ = self.get_grad(pl_module, pb, op, de)
+            ctx, grads, _ = self.get_grad(pl_module, pb, op, de)
             sal = grads.abs().sum(-1).cpu()                          # L1 norm of the gradient per position (:221-228)
             # ---- pick one position per sample, build the candidate sentences (host logic) -------------
             rows, owner, pos_of = [], [], []
@@ -309,9 +270,8 @@ class GreedyAttack_moco(GreedyAttack):
             pc.text_ids = torch.stack(rows).to(dev)
             pc.text_mask = masks.index_select(0, own)
             torch.index_select(op.view(Bn, -1), 0, own, out=pc.patchesT.view(Bc, -1))
-            pc.k.copy_(k.index_select(0, own))
-            cec = self.split_forward(pl_module, pc, n_real).cpu().tolist()
-            picks = self.select(ce0.cpu().tolist(), cec, owner, n_real, Bn)
+            self.bind_candidate_keys(pc, k, own)
+            picks = self.score(pl_module, pc, ctx, owner, n_real, Bn)
             # ---- selection (:562-578): a changed sample takes its best candidate when its index is > 0 ---
             start = 0
             for b, (_, best_j) in enumerate(picks):
@@ -328,3 +288,124 @@ class GreedyAttack_moco(GreedyAttack):
         return {"txt_input_ids": ids_host.to(dev), "text_masks": masks, "text": batch.get("text"),
                 "num_changes": sum(nchg) / Bn, "change_rate": sum(c / n for c, n in zip(nchg, nwords)) / Bn,
                 "Problem": any(c == 0 for c in nchg), "changes_verification": changes}
+
+
+class GreedyAttack_moco(GreedyAttack):
+    def __init__(self, config, candidate_fn: Optional[Callable] = None, tokenizer=None, stopwords=None, synonyms=None):
+        super().__init__(config, "moco", candidate_fn, tokenizer, stopwords, synonyms)
+
+    # ---- tensor side, same method names as the reference ----------------------------------------------------------
+    def get_grad(self, pl_module, pb, op, de):
+        """get_grad (:406-452): forward, batch-mean InfoNCE, backward to the OUTPUT of word_embeddings (what the
+        reference's backward hook captures).  Returns (per-row CE [B], grads view [B,L,D] = `de`, q [B,128])."""
+        eng = pl_module.engine
+        Bn = pb.B
+        eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+        eng.heads_forward(pb, key=False)
+        eng.infonce(pb, 1.0 / Bn, want_dq=True)
+        ce0 = pb.rows[:, 0].clone()
+        eng.heads_backward(pb, pb.dq, None, with_grads=False)
+        eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=None, dtext=de)
+        return ce0, de.view(Bn, pb.d.L, -1), pb.q
+
+    def split_forward(self, pl_module, pc, n_real):
+        """split_forward (:454-492), device part: candidates through the encoder, per-row CE against the same keys."""
+        eng = pl_module.engine
+        eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT)
+        eng.heads_forward(pc, key=False)
+        eng.infonce(pc, 0.0, want_dq=False)
+        return pc.rows[:n_real, 0]
+
+    def bind_keys(self, pl_module, pb, k):
+        pb.k.copy_(k)
+
+    def bind_candidate_keys(self, pc, k, own):
+        pc.k.copy_(k.index_select(0, own))
+
+    def score(self, pl_module, pc, ctx, owner, n_real, Bn):
+        cec = self.split_forward(pl_module, pc, n_real).cpu().tolist()
+        return self.select(ctx.cpu().tolist(), cec, owner, n_real, Bn)
+
+    @staticmethod
+    def select(ce0, cec, owner, n_real, Bn):
+        """split_forward's scoring (:466-490) on per-row CE values.  The reference evaluates the BATCH-MEAN loss with row
+        i replaced by candidate j and compares it with the original batch mean.  Its `t_save = ori_z[i]` (:475) is a
+        view, so the restore at :489 is a no-op and row i keeps its LAST candidate while later samples are scored:
+            loss_ij = mean(ce0) + sum_{r<i} (ce_{r,last} - ce0_r)/B + (ce_ij - ce0_i)/B
+        Returns [(losses, best index or -1)] per sample (first maximum, strict >, like :485-486)."""
+        ori = float(sum(ce0) / Bn)
+        out, drift, start = [], 0.0, 0
+        for b in range(Bn):
+            idx = [i for i in range(start, n_real) if owner[i] == b]
+            start = idx[-1] + 1
+            best, best_j, losses = ori, -1, []
+            for j, r in enumerate(idx):
+                lj = ori + drift + (cec[r] - ce0[b]) / Bn
+                losses.append(lj)
+                if lj > best:
+                    best, best_j = lj, j
+            drift += (cec[idx[-1]] - ce0[b]) / Bn
+            out.append((losses, best_j))
+        return out
+
+
+class GreedyAttack_barlowtwins(GreedyAttack):
+    """attack/greedy_attack_vilt.py:602-700: the same greedy attack maximising the Barlow-Twins loss
+    on_diag + adv_lr * off_diag of c = q^T k / B (local batch; q = barlowtwins_head(cls_feats) with BATCH statistics - the
+    reference attacks a deep copy of the head left in train mode, so a candidate batch is normalised by its own rows)."""
+
+    def __init__(self, config, candidate_fn: Optional[Callable] = None, tokenizer=None, stopwords=None, synonyms=None):
+        super().__init__(config, "barlowtwins", candidate_fn, tokenizer, stopwords, synonyms)
+        self._zk = None
+
+    def bind_keys(self, pl_module, pb, k):
+        self._zk = k
+
+    def get_grad(self, pl_module, pb, op, de):
+        """get_grad (:623-668): loss = on_diag + adv_lr * off_diag, gradient at the output of word_embeddings.
+        Returns (context for score(): the projections [B, H3], grads view [B,L,D], the projections)."""
+        eng = pl_module.engine
+        bb = eng.bt_bufs(pb.B, "txtatk")
+        eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+        eng.heads_forward(pb, key=False, want_q=False)
+        eng.bt_forward(bb, pb.cls, training=True, track=False)
+        eng.bt_loss(bb, self._zk, float(pb.B), pl_module.adv_lr, 1.0, want_dz=True)
+        dcls = eng.bt_backward(bb, bb.dz, training=True, with_grads=False)
+        eng.heads_backward(pb, None, dcls, with_grads=False)
+        eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=None, dtext=de)
+        z = bb.z.clone()
+        return z, de.view(pb.B, pb.d.L, -1), z
+
+    def score(self, pl_module, pc, ctx, owner, n_real, Bn):
+        """split_forward (:670-707).  Candidates go through encoder + head as ONE batch of n_real rows (BatchNorm statistics
+        over exactly those rows); then, sample by sample and candidate by candidate, row i of the projection matrix is
+        replaced and the loss of the whole matrix re-evaluated.  `t_save = ori_z[i]` (:691) is a view, so row i keeps its LAST
+        candidate while later samples are scored (same reference behaviour as the MoCo attack); the comparison baseline is
+        the loss of the UNMODIFIED matrix for every sample (:684-688).  All n_real + 1 losses are produced on the device
+        and read back once."""
+        eng = pl_module.engine
+        eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT)
+        eng.heads_forward(pc, key=False, want_q=False)
+        bc = eng.bt_bufs(n_real, "txtatk_cand")
+        zc = eng.bt_forward(bc, pc.cls[:n_real].contiguous(), training=True, track=False)
+        Z = ctx.clone()
+        vals = torch.empty(n_real + 1, 2, device=Z.device)
+        lam = pl_module.adv_lr
+        eng.bt_loss_of(Z, self._zk, Bn, float(Bn), lam, 1.0, vals[0])
+        for r in range(n_real):
+            Z[owner[r]].copy_(zc[r])
+            eng.bt_loss_of(Z, self._zk, Bn, float(Bn), lam, 1.0, vals[1 + r])
+        v = vals.cpu().double()
+        loss = (v[:, 0] + lam * v[:, 1]).tolist()
+        out, r = [], 0
+        for b in range(Bn):
+            best, best_j, losses = loss[0], -1, []
+            j = 0
+            while r < n_real and owner[r] == b:
+                losses.append(loss[1 + r])
+                if loss[1 + r] > best:
+                    best, best_j = loss[1 + r], j
+                r += 1
+                j += 1
+            out.append((losses, best_j))
+        return out

@@ -485,14 +485,20 @@ class Engine:
     def bt_loss(self, bb: BtBuffers, zk: torch.Tensor, denom: float, lam: float, grad_scale: float, want_dz: bool, reduce_c=None):
         """loss2 = (on_diag, off_diag) of c = z^T zk / denom (objectives.py:478-484); dz = d(grad_scale (on + lam off))/dz.
         reduce_c: callable run on the correlation matrix between its computation and the loss (the all-reduce of :480)."""
+        self.bt_loss_of(bb.z, zk, bb.B, denom, lam, grad_scale, bb.loss2, reduce_c)
+        if want_dz:
+            check(lib.rmcl_bt_dz(P(zk), P(self.bt_corr), bb.B, self.bt.H3, F(1.0 / denom), P(bb.dz), stream_ptr()), "bt_dz")
+        return bb.loss2
+
+    def bt_loss_of(self, z: torch.Tensor, zk: torch.Tensor, B: int, denom: float, lam: float, grad_scale: float, loss2: torch.Tensor,
+                   reduce_c=None):
+        """(on_diag, off_diag) of c = z^T zk / denom into `loss2` (any 2-float device view); leaves the gradient matrix in
+        self.bt_corr."""
         N = self.bt.H3
-        check(lib.rmcl_bt_corr(P(bb.z), P(zk), bb.B, N, F(1.0 / denom), P(self.bt_corr), stream_ptr()), "bt_corr")
+        check(lib.rmcl_bt_corr(P(z), P(zk), B, N, F(1.0 / denom), P(self.bt_corr), stream_ptr()), "bt_corr")
         if reduce_c is not None:
             reduce_c(self.bt_corr)
-        check(lib.rmcl_bt_loss(P(self.bt_corr), N, F(lam), F(grad_scale), P(self.bt_ws), P(bb.loss2), stream_ptr()), "bt_loss")
-        if want_dz:
-            check(lib.rmcl_bt_dz(P(zk), P(self.bt_corr), bb.B, N, F(1.0 / denom), P(bb.dz), stream_ptr()), "bt_dz")
-        return bb.loss2
+        check(lib.rmcl_bt_loss(P(self.bt_corr), N, F(lam), F(grad_scale), P(self.bt_ws), P(loss2), stream_ptr()), "bt_loss")
 
     def bt_pair_metrics(self, bb: BtBuffers, zk: torch.Tensor):
         check(lib.rmcl_bt_pair_metrics(P(bb.z), P(zk), bb.B, self.bt.H3, P(bb.rows), stream_ptr()), "bt_pair_metrics")

@@ -313,19 +313,57 @@ def compute_moco_contrastive(pl_module, batch):
     return ret
 
 
+def _bt_view(pl_module, pv, op, zk, suffix, ret, phase, need_grad, training):
+    """One Barlow-Twins loss view (objectives.py:464-498 text / :500-525 image / :527-546 both): forward of the view, the
+    head (running estimates updated in training), c = q^T k / per_step_bs summed over ranks, on/off-diagonal loss, distance
+    logs; returns (loss value with a deferred HIP backward, on_diag, adv_lr * off_diag)."""
+    eng = pl_module.engine
+    eng.encoder_forward(pv, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op)
+    eng.heads_forward(pv, key=False, want_q=False)
+    bq = eng.bt_bufs(pv.B, "q_" + suffix)
+    eng.bt_forward(bq, pv.cls, training, track=training)
+
+    def reduce_c(c):                                                            # torch.distributed.all_reduce(c) (:480,:507,:535)
+        if dist_utils.world_size() > 1:
+            torch.distributed.all_reduce(c)
+
+    loss2 = eng.bt_loss(bq, zk, float(pl_module.per_step_bs), pl_module.adv_lr, 1.0, want_dz=need_grad, reduce_c=reduce_c)
+    on_diag, red = loss2[0].clone(), pl_module.adv_lr * loss2[1]
+    rows = eng.bt_pair_metrics(bq, zk)
+    ret[f"pos_dist_attacked_{suffix}"], ret[f"pos_cosine_attacked_{suffix}"], ret[f"pos_dot_attacked_{suffix}"] = \
+        rows[:, 0].mean(), rows[:, 1].mean(), rows[:, 2].mean()
+    ret[f"q_{suffix}"] = bq.z.clone()
+    value = _scalar(on_diag + red)
+    if need_grad:
+        dz_saved = bq.dz.clone()
+
+        def backward(grad_out, pv=pv, bq=bq, dz_saved=dz_saved, op=op):
+            dz = dz_saved * grad_out.to(dz_saved.dtype)
+            dcls = eng.bt_backward(bq, dz, training=True, with_grads=True)
+            eng.heads_backward(pv, None, dcls, with_grads=True)
+            eng.encoder_backward(pv, L.MODE_FULL, op, pv.dcls, cls_only=True, dpatches=None)
+            pl_module.after_backward(overlap=True)
+
+        # NOTE on ranks: the reference all-reduces c WITHOUT autograd support, so each rank backpropagates d loss(c_global) / dq
+        # of its own rows and DDP then AVERAGES the gradients - the 1/world_size of that average is the prescale
+        value = _DeferredBackward.apply(pl_module.grad_anchor, value, backward, pl_module.grad_prescale())
+        # Reference behaviour: training_step sums every returned value whose key contains "loss" (vilt_module.py:475), and the
+        # logged components ARE live graph tensors there (:486-487) - each view is optimised with weight 1/loss_num + 1.  The
+        # invariance component therefore carries the same deferred backward (as a zero-valued term).
+        on_diag = on_diag + (value - value.detach())
+    return value, on_diag, red
+
+
 def compute_barlowtwins_contrastive(pl_module, batch):
-    """objectives.py:449-602, image view: ONE encoder and one head.  k = head(infer(clean)) under no_grad,
-    q = head(infer(img + delta_{K-1} + delta_K)) after the PGD of attack/pgd_attack_vilt.py:178-236,
-    c = q^T k / per_step_bs, summed over ranks (:480), loss = sum_i (c_ii - 1)^2 + adv_lr * sum_{i != j} c_ij^2 (the reference
-    uses its `adv_lr` hyper-parameter as the redundancy weight).  The head's BatchNorms run in the module's mode and - in
-    training - update their running estimates in BOTH calls, like nn.BatchNorm1d does under no_grad too."""
+    """objectives.py:449-602: ONE encoder and one head.  k = head(infer(clean)) under no_grad; per view
+    q = head(infer(view)), c = q^T k / per_step_bs summed over ranks, loss = sum_i (c_ii - 1)^2 + adv_lr * sum_{i != j} c_ij^2
+    (the reference uses its `adv_lr` hyper-parameter as the redundancy weight).  Views like the MoCo objective: attacked text
+    (greedy attack on this loss), attacked image (PGD on this loss; img + delta_{K-1} + delta_K), both.  The head's BatchNorms
+    run in the module's mode and - in training - update their running estimates in EVERY call, also under no_grad."""
     eng = pl_module.engine
     if pl_module.augmentation:
         raise NotImplementedError("augmentation views are out of scope (SURVEY 2.1 #17)")
-    if pl_module.text_view:
-        raise NotImplementedError("Barlow-Twins text view (GreedyAttack_barlowtwins, greedy_attack_vilt.py:602-700) is not built; "
-                                  "image_view=True, text_view=False runs")
-    if not pl_module.image_view:
+    if not (pl_module.image_view or pl_module.text_view):
         raise ZeroDivisionError("division by zero: loss / loss_num with both views off (objectives.py:451-452,548)")
     phase = "train" if pl_module.training else "val"
     training = bool(pl_module.training)
@@ -338,51 +376,43 @@ def compute_barlowtwins_contrastive(pl_module, batch):
     eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)          # :460-462
     eng.heads_forward(pb, key=False, want_q=False)
     zk = eng.bt_forward(bk, pb.cls, training, track=training)
-    pl_module.pgd_attacker.attack_patches(pl_module, pb, zk)                    # compute_pgd (:503)
-    check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3, pb.d.patch_k // 3, stream_ptr()),
-          "delta_norm")
-    n_pix = pb.delta.numel() // 3 if pb.geom is None else pb.B * pb.geom.shape[2] * pb.geom.shape[3]
-    pl_module.log(f"barlowtwins_attack/{phase}/delta", _scalar(pb.loss_sum / float(n_pix)))
-    op_att = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pb.patchesT_full)
-    eng.encoder_forward(pb, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op_att)
-    eng.heads_forward(pb, key=False, want_q=False)
-    bq = eng.bt_bufs(B, "q")
-    eng.bt_forward(bq, pb.cls, training, track=training)
-
-    def reduce_c(c):                                                            # torch.distributed.all_reduce(c_1) (:507)
-        if dist_utils.world_size() > 1:
-            torch.distributed.all_reduce(c)
-
-    loss2 = eng.bt_loss(bq, zk, float(pl_module.per_step_bs), pl_module.adv_lr, 1.0, want_dz=need_grad, reduce_c=reduce_c)
-    on_diag, off_diag = loss2[0].clone(), loss2[1].clone()
-    rows = eng.bt_pair_metrics(bq, zk)
-    ret["barlowtwins_loss_invariance_img"] = on_diag
-    ret["barlowtwins_loss_redundancy_img"] = pl_module.adv_lr * off_diag
-    ret["pos_dist_attacked_img"], ret["pos_cosine_attacked_img"], ret["pos_dot_attacked_img"] = rows[:, 0].mean(), rows[:, 1].mean(), rows[:, 2].mean()
-    ret["k"], ret["q_image"] = zk.clone(), bq.z.clone()
-    value = _scalar(on_diag + pl_module.adv_lr * off_diag)
-    if need_grad:
-        dz_saved = bq.dz.clone()
-
-        def backward(grad_out, pb=pb, bq=bq, dz_saved=dz_saved, op=op_att):
-            dz = dz_saved * grad_out.to(dz_saved.dtype)
-            dcls = eng.bt_backward(bq, dz, training=True, with_grads=True)
-            eng.heads_backward(pb, None, dcls, with_grads=True)
-            eng.encoder_backward(pb, L.MODE_FULL, op, pb.dcls, cls_only=True, dpatches=None)
-            pl_module.after_backward(overlap=True)
-
-        # NOTE on ranks: the reference all-reduces c WITHOUT autograd support, so each rank backpropagates d loss(c_global) / dq
-        # of its own rows and DDP then AVERAGES the gradients - the 1/world_size of that average is the prescale below
-        value = _DeferredBackward.apply(pl_module.grad_anchor, value, backward, pl_module.grad_prescale())
-        # Reference behaviour: training_step sums every returned value whose key contains "loss" (vilt_module.py:475), and
-        # the two logged components ARE live graph tensors there (:486-487) - the step optimises loss + on_diag +
-        # adv_lr * off_diag = 2 x the loss.  The components therefore carry the same deferred backward (as a zero-valued term).
-        ret["barlowtwins_loss_invariance_img"] = on_diag + (value - value.detach())
-    ret["barlowtwins_loss"] = value / 1                                         # loss / loss_num with one view (:548)
+    loss, loss_num = 0, 0
+    views = []
+    txt_ids = txt_masks = None
+    if pl_module.text_view:                                                     # :464-498
+        aug = compute_geometric(pl_module, copy(batch), "barlowtwins", k_modality=zk)
+        txt_ids, txt_masks = aug["text_ids"], aug["text_masks"]
+        pt = eng.bind_text(pb, txt_ids, txt_masks, tag="bt_txt")
+        op_t = eng.make_operand(pb, out=pt.patchesT_full)
+        v, on_diag, red = _bt_view(pl_module, pt, op_t, zk, "txt", ret, phase, need_grad, training)
+        ret["barlowtwins_loss_invariance_text"], ret["barlowtwins_loss_redundancy_text"] = on_diag, red
+        loss, loss_num = loss + v, loss_num + 1
+        views.append(("txt", "text"))
+    if pl_module.image_view:                                                    # :500-525
+        pl_module.pgd_attacker.attack_patches(pl_module, pb, zk)                # compute_pgd (:503)
+        check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3, pb.d.patch_k // 3,
+                                          stream_ptr()), "delta_norm")
+        n_pix = pb.delta.numel() // 3 if pb.geom is None else pb.B * pb.geom.shape[2] * pb.geom.shape[3]
+        pl_module.log(f"barlowtwins_attack/{phase}/delta", _scalar(pb.loss_sum / float(n_pix)))
+        op_att = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pb.patchesT_full)
+        v, on_diag, red = _bt_view(pl_module, pb, op_att, zk, "img", ret, phase, need_grad, training)
+        ret["barlowtwins_loss_invariance_img"], ret["barlowtwins_loss_redundancy_img"] = on_diag, red
+        loss, loss_num = loss + v, loss_num + 1
+        views.append(("img", "img"))
+    if pl_module.image_view and pl_module.text_view:                            # :527-546
+        pbo = eng.bind_text(pb, txt_ids, txt_masks, tag="bt_both")
+        op_b = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pbo.patchesT_full)
+        v, on_diag, red = _bt_view(pl_module, pbo, op_b, zk, "both", ret, phase, need_grad, training)
+        ret["barlowtwins_loss_invariance_both"], ret["barlowtwins_loss_redundancy_both"] = on_diag, red
+        loss, loss_num = loss + v, loss_num + 1
+        views.append(("both", "both"))
+    ret["k"] = zk.clone()
+    ret["barlowtwins_loss"] = loss / loss_num                                   # :548
     pl_module.log(f"barlowtwins/{phase}/loss", ret["barlowtwins_loss"].detach())
-    pl_module.log(f"barlowtwins_dist_{phase}_L2/Pos_attacked_img", ret["pos_dist_attacked_img"])
-    pl_module.log(f"barlowtwins_dist_{phase}_Cosine/Pos_attacked_img", ret["pos_cosine_attacked_img"])
-    pl_module.log(f"barlowtwins_dist_{phase}_Dot/Pos_attacked_img", ret["pos_dot_attacked_img"])
-    pl_module.log(f"barlowtwins/{phase}/barlowtwins_loss_invariance_img", on_diag)
-    pl_module.log(f"barlowtwins/{phase}/barlowtwins_loss_redundancy_img", ret["barlowtwins_loss_redundancy_img"])
+    for suffix, name in views:                                                  # :555-600
+        pl_module.log(f"barlowtwins_dist_{phase}_L2/Pos_attacked_{suffix}", ret[f"pos_dist_attacked_{suffix}"])
+        pl_module.log(f"barlowtwins_dist_{phase}_Cosine/Pos_attacked_{suffix}", ret[f"pos_cosine_attacked_{suffix}"])
+        pl_module.log(f"barlowtwins_dist_{phase}_Dot/Pos_attacked_{suffix}", ret[f"pos_dot_attacked_{suffix}"])
+        pl_module.log(f"barlowtwins/{phase}/barlowtwins_loss_invariance_{name}", ret[f"barlowtwins_loss_invariance_{name}"].detach())
+        pl_module.log(f"barlowtwins/{phase}/barlowtwins_loss_redundancy_{name}", ret[f"barlowtwins_loss_redundancy_{name}"].detach())
     return ret

@@ -17,7 +17,7 @@ from ... import _lib as L
 from ..._lib import lib, check
 from ...runtime import Engine, EMA_GROUPS
 from ...attack.pgd_attack_vilt import PGDAttack_moco, PGDAttack_bartlowtwins
-from ...attack.greedy_attack_vilt import GreedyAttack_moco
+from ...attack.greedy_attack_vilt import GreedyAttack_moco, GreedyAttack_barlowtwins
 from . import objectives, vilt_utils, dist_utils
 
 
@@ -100,6 +100,8 @@ class ViLTransformerSS(nn.Module):
                 node.register_buffer("running_var", eng.bt_running[o + n:o + 2 * n])
                 node.register_buffer("num_batches_tracked", eng.bt_tracked[i])
                 o += 2 * n
+            if self.text_view and not self.augmentation:
+                self.greedy_attacker = GreedyAttack_barlowtwins(config)
             if self.image_view and not self.augmentation:
                 self.pgd_attacker = PGDAttack_bartlowtwins(config)
         self.grad_anchor = torch.zeros((), device=eng.device, requires_grad=True)

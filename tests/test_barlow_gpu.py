@@ -144,7 +144,7 @@ def test_barlowtwins_step_matches_reference_golden(tag):
     # projections: BatchNorm over 4 samples amplifies fp32 rounding in single features (tests/test_oracle_golden.py quantifies it
     # with an fp64 run of the restatement): bound max and mean
     dk = np.abs(eng.bt_bufs(B, "k").z.cpu().numpy() - g["k"])
-    dq = np.abs(eng.bt_bufs(B, "q").z.cpu().numpy() - g["q_image"])
+    dq = np.abs(eng.bt_bufs(B, "q_img").z.cpu().numpy() - g["q_image"])
     assert dk.max() < 5e-3 and dk.mean() < 1e-4, (dk.max(), dk.mean())
     assert dq.max() < (2e-2 if narrow else 0.3) and dq.mean() < (1e-3 if narrow else 5e-3), (dq.max(), dq.mean())
     logged = m.logged
@@ -197,3 +197,120 @@ def test_barlowtwins_bs64_bf16_step_and_optimizer():
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
     assert int(m.state_dict()["barlowtwins_head.norm.num_batches_tracked"]) == 8
+
+
+def test_barlowtwins_three_views_with_text_attack_match_reference_golden():
+    """text_view + image_view: the reference's compute_barlowtwins_contrastive with its GreedyAttack_barlowtwins (word level, toy
+    resources) and PGDAttack_bartlowtwins, loss sum of training_step, backward - attacked sentences, per-loop decisions,
+    losses of the three views, distance logs, gradient norms, BatchNorm buffers (7 head calls tracked)."""
+    from rmcl_amd.attack import word_substitution as WS
+    g = load("barlow3_L2_B4.npz")
+    B, sw, sb, L_, K, sh, h1, h2, h3, loops, n_cand = [int(x) for x in g["meta"]]
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ocfg = O.default_config(num_layers=L_, num_negative=1024, per_gpu_batchsize=B, adv_steps_img=K, barlowtwins_dims=(h1, h2, h3),
+                            image_view=True, text_view=True)
+    cfg = task_barlowtwins(num_layers=L_, adv_steps_img=K, per_gpu_batchsize=B, drop_rate=0.0, image_view=True, text_view=True, num_gpus=1,
+                           num_nodes=1, barlowtwins_dims=(h1, h2, h3), adv_lr=ocfg["adv_lr"], max_loops=loops, n_candidates=n_cand,
+                           tokenizer=os.path.join(gold, "toy_vocab.txt"), embedding_path=os.path.join(gold, "toy_counter_fitted.txt"),
+                           sim_path=None, stopwords=os.path.join(gold, "toy_stopwords.txt"))
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype="f32")
+    p = O.init_params(ocfg, sw)
+    p.update(O.bt_init_params(ocfg, sh))
+    m.load_state_dict({n: t.to(DEV) for n, t in p.items() if not n.startswith(("k_", "moco_head", "itm_score"))}, strict=False)
+    m.train()
+    table = m.greedy_attacker.synonyms
+    ref_order = {str(w): str(c).split("|") for w, c in zip(g["syn_words"], g["syn_cands"])}
+    for w, c in ref_order.items():
+        assert set(table(w)) == set(c)
+
+    class RefOrder:                                                    # the reference's set-iteration order of the same candidates
+        word2id = table.word2id
+        __contains__ = lambda self, w: w in table.word2id
+        __call__ = lambda self, w: ref_order.get(w, [w])
+
+    m.greedy_attacker.synonyms = RefOrder()
+    batch = dev_batch(O.synthetic_batch(ocfg, B, sb))
+    batch["text"] = [str(t) for t in g["text_in"]]
+    batch["text_ids"] = torch.from_numpy(g["text_ids_in"]).to(DEV)
+    batch["text_masks"] = torch.from_numpy(g["text_masks_in"]).to(DEV)
+    m.zero_grad()
+    loss = m.training_step(batch, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    att = m.greedy_attacker
+    for li, (replace_idx, new_text, all_num, best) in enumerate(att.trace):
+        assert [-1 if x is None else x for x in replace_idx] == g["replace_idx"][li].tolist(), li
+        assert new_text == [str(t) for t in g[f"new_text_{li}"]], li
+        assert best == g["best_idx"][li].tolist(), li
+    assert abs(float(loss) - float(g["total_loss"])) < 1e-3 * float(g["total_loss"])
+    lg = m.logged
+    assert abs(float(lg["barlowtwins/train/loss"]) - float(g["ret_barlowtwins_loss"])) < 1e-3 * float(g["ret_barlowtwins_loss"])
+    for name in ("text", "img", "both"):
+        for part in ("invariance", "redundancy"):
+            ref = float(g[f"ret_barlowtwins_loss_{part}_{name}"])
+            assert abs(float(lg[f"barlowtwins/train/barlowtwins_loss_{part}_{name}"]) - ref) < 2e-3 * ref, (name, part)
+    for suffix in ("txt", "img", "both"):
+        for kind, key in (("L2", "pos_dist"), ("Cosine", "pos_cosine"), ("Dot", "pos_dot")):
+            ref = float(g[f"ret_{key}_attacked_{suffix}"])
+            assert abs(float(lg[f"barlowtwins_dist_train_{kind}/Pos_attacked_{suffix}"]) - ref) < 3e-3 * max(1.0, abs(ref)), (suffix, kind)
+    assert abs(float(lg["barlowtwins_attack/train/num_changes"]) - float(g["log_barlowtwins_attack__train__num_changes"])) < 1e-9
+    params = dict(m.named_parameters())
+    rel = {str(n): abs(digest(params[str(n)].grad)[1] - d[1]) / (d[1] + 1e-12) for n, d in zip(g["grad_names"], g["grad_digest"])}
+    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:6]
+    # Three BatchNorms over 4 samples make the gradient's overall scale ill-conditioned: the oracle restatement in fp64 differs
+    # from its own fp32 run by 1.0 % (uniformly over all tensors) and from the reference by 0.7 %; HIP lands 1.4 % from the
+    # reference.  The well-conditioned text view alone is pinned to 1e-3 below.
+    assert worst[0][1] <= 2.5e-2, worst
+    sd = m.state_dict()
+    for key in ("projector.1", "projector.4", "norm"):
+        kk = key.replace(".", "__")
+        np.testing.assert_allclose(sd[f"barlowtwins_head.{key}.running_mean"].cpu().numpy(), g[f"buf_{kk}__running_mean"], atol=2e-4)
+        np.testing.assert_allclose(sd[f"barlowtwins_head.{key}.running_var"].cpu().numpy(), g[f"buf_{kk}__running_var"], rtol=2e-3, atol=1e-6)
+        assert int(sd[f"barlowtwins_head.{key}.num_batches_tracked"]) == int(g[f"buf_{kk}__num_batches_tracked"]) == 4
+
+
+def test_barlowtwins_text_view_backward_matches_oracle():
+    """The text view alone (attacked sentences taken from the reference fixture, no PGD in the chain): loss and the gradient of
+    every tensor against the oracle restatement - this view is well conditioned, so the bound is tight."""
+    g = load("barlow3_L2_B4.npz")
+    B, sw, sb, L_, K, sh, h1, h2, h3, loops, n_cand = [int(x) for x in g["meta"]]
+    ocfg = O.default_config(num_layers=L_, num_negative=1024, per_gpu_batchsize=B, adv_steps_img=K, barlowtwins_dims=(h1, h2, h3),
+                            image_view=False, text_view=True)
+    ids, masks = torch.from_numpy(g["text_ids_in"]), torch.from_numpy(g["text_masks_in"])
+    tids, tmasks = torch.from_numpy(g["text_ids_out"]), torch.from_numpy(g["text_masks_out"])
+    cfg = task_barlowtwins(num_layers=L_, adv_steps_img=K, per_gpu_batchsize=B, drop_rate=0.0, image_view=False, text_view=True, num_gpus=1,
+                           num_nodes=1, barlowtwins_dims=(h1, h2, h3), adv_lr=ocfg["adv_lr"])
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype="f32")
+    p = O.init_params(ocfg, sw)
+    p.update(O.bt_init_params(ocfg, sh))
+    m.load_state_dict({n: t.to(DEV) for n, t in p.items() if not n.startswith(("k_", "moco_head", "itm_score"))}, strict=False)
+    m.train()
+
+    class Fixed:                                                       # the attack's outcome, so that only the view is under test
+        def adv_attack_samples(self, pl_module, batch, k):
+            return {"txt_input_ids": tids.to(DEV), "text_masks": tmasks.to(DEV), "text": batch["text"], "num_changes": 0.0, "change_rate": 0.0}
+
+    m.greedy_attacker = Fixed()
+    batch0 = O.synthetic_batch(ocfg, B, sb)
+    batch = dev_batch(batch0)
+    batch["text_ids"], batch["text_masks"] = ids.to(DEV), masks.to(DEV)
+    m.zero_grad()
+    loss = m.training_step(batch, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    for n, t in p.items():
+        if not n.startswith("k_"):
+            t.requires_grad_(True)
+    run = O.bt_running_init(ocfg)
+    img = batch0["image"][0]
+    with torch.no_grad():
+        k = O.barlowtwins_head(p, O.infer(p, ocfg, ids, masks, img)["cls_feats"], run, True)
+    q = O.barlowtwins_head(p, O.infer(p, ocfg, tids, tmasks, img)["cls_feats"], run, True)
+    lo = O.barlow_loss(q, k, float(B), ocfg["adv_lr"])[0]
+    (2 * lo).backward()                                                # training_step's sum: loss + its two components
+    assert abs(float(loss) - 2 * float(lo)) < 1e-4 * 2 * float(lo)
+    params = dict(m.named_parameters())
+    for n, t in p.items():
+        if t.grad is not None and n in params:
+            a, b = digest(params[n].grad)[1], digest(t.grad)[1]
+            assert abs(a - b) <= 1e-3 * b + 1e-7, (n, a, b)
