@@ -29,6 +29,14 @@ extern "C" {
 #define RMCL_MODE_INFER 0 /* no activations kept (momentum encoder, clean query) */
 #define RMCL_MODE_DATA 1  /* keep what the data-gradient (PGD) backward needs     */
 #define RMCL_MODE_FULL 2  /* keep what the weight-gradient backward needs too     */
+/* OR-ed into the mode of rmcl_encoder_forward: the caller will read ONLY row 0 (the cls token) of every sample of xn - what
+ * the pooler does (heads.py:17) in the contrastive objectives.  Everything behind the last block's attention is row-wise
+ * (proj, LayerNorm 2, the MLP, the final LayerNorm), so it then runs on B rows instead of B * N; the other rows of xn are
+ * left unwritten.  The matching rmcl_encoder_backward must be called with cls_only = 2 (dxn = the [B, D] gradient of those
+ * rows): it back-propagates the compact tail and reduces the last layer's fc2 / fc1 / proj weight gradients over B rows.
+ * Requires dropout off and B <= 256.  Results equal the dense pass on the cls rows up to fp32 summation order (the tail
+ * uses the fp32 master weights).                                                                                     */
+#define RMCL_MODE_CLS_TAIL 16
 
 typedef struct rmcl_dims {
   int B;        /* samples in this pass                                              */
@@ -212,7 +220,8 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
                          uint32_t drop_seed, float drop_p, const rmcl_ragged* ragged, const rmcl_fold* fold, void* stream);
 
 /* Backward of the above.  dxn: gradient wrt xn, [B*N,D] f32, or [B,D] (row 0 of every sample)
- * when cls_only=1.  dpatches (optional) receives d loss/d patches [B*P,patch_k] in `dtype`
+ * when cls_only=1; cls_only=2: the same [B,D] gradient for a stash whose forward ran with RMCL_MODE_CLS_TAIL (compact last
+ * layer).  dpatches (optional) receives d loss/d patches [B*P,patch_k] in `dtype`
  * (the PGD data gradient, attack/pgd_attack_vilt.py:160-162).  dtext (optional) receives d loss/d
  * word-embedding output [B*L, D] f32 (the text-attack saliency, greedy_attack_vilt.py:414-452).
  * grads32 (mode FULL): gradient

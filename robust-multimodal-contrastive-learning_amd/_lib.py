@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librmcl_hip.so")
 
 F32, BF16 = 0, 1
 MODE_INFER, MODE_DATA, MODE_FULL = 0, 1, 2
+MODE_CLS_TAIL = 16        # include/rmcl.h RMCL_MODE_CLS_TAIL
 EPI_BIAS, EPI_GELU, EPI_SAVE_PREACT, EPI_RESIDUAL, EPI_DGELU, EPI_ATOMIC, EPI_ACCUM, EPI_TANH = 1, 2, 4, 8, 16, 32, 64, 128
 
 

@@ -300,7 +300,7 @@ class GreedyAttack_moco(GreedyAttack):
         reference's backward hook captures).  Returns (per-row CE [B], grads view [B,L,D] = `de`, q [B,128])."""
         eng = pl_module.engine
         Bn = pb.B
-        eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+        eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
         eng.heads_forward(pb, key=False)
         eng.infonce(pb, 1.0 / Bn, want_dq=True)
         ce0 = pb.rows[:, 0].clone()
@@ -311,7 +311,7 @@ class GreedyAttack_moco(GreedyAttack):
     def split_forward(self, pl_module, pc, n_real):
         """split_forward (:454-492), device part: candidates through the encoder, per-row CE against the same keys."""
         eng = pl_module.engine
-        eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT)
+        eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT, cls_tail=True)
         eng.heads_forward(pc, key=False)
         eng.infonce(pc, 0.0, want_dq=False)
         return pc.rows[:n_real, 0]
@@ -366,7 +366,7 @@ class GreedyAttack_barlowtwins(GreedyAttack):
         Returns (context for score(): the projections [B, H3], grads view [B,L,D], the projections)."""
         eng = pl_module.engine
         bb = eng.bt_bufs(pb.B, "txtatk")
-        eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+        eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
         eng.heads_forward(pb, key=False, want_q=False)
         eng.bt_forward(bb, pb.cls, training=True, track=False)
         eng.bt_loss(bb, self._zk, float(pb.B), pl_module.adv_lr, 1.0, want_dz=True)
@@ -384,7 +384,7 @@ class GreedyAttack_barlowtwins(GreedyAttack):
         the loss of the UNMODIFIED matrix for every sample (:684-688).  All n_real + 1 losses are produced on the device
         and read back once."""
         eng = pl_module.engine
-        eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT)
+        eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT, cls_tail=True)
         eng.heads_forward(pc, key=False, want_q=False)
         bc = eng.bt_bufs(n_real, "txtatk_cand")
         zc = eng.bt_forward(bc, pc.cls[:n_real].contiguous(), training=True, track=False)

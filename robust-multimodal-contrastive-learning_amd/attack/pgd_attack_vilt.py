@@ -45,7 +45,7 @@ class PGDAttack_moco(PGDAttack):
             if step == K - 1 and K > 1:
                 pb.delta_prev.copy_(pb.delta)
             op = eng.make_operand(pb, pb.delta)               # img_init + img_delta (:144)
-            eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+            eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
             eng.heads_forward(pb, key=False)
             if step == 0 and before_first_loss is not None:
                 before_first_loss()
@@ -88,7 +88,7 @@ class PGDAttack_bartlowtwins(PGDAttack):
             if step == K - 1 and K > 1:
                 pb.delta_prev.copy_(pb.delta)
             op = eng.make_operand(pb, pb.delta)
-            eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op)
+            eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
             eng.heads_forward(pb, key=False, want_q=False)
             eng.bt_forward(bb, pb.cls, training=True, track=False)
             eng.bt_loss(bb, zk, float(pb.B), pl_module.adv_lr, 1.0 / K, want_dz=True)

@@ -140,6 +140,37 @@ int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, l
   return 0;
 }
 
+// Row gather / scatter between a [rows, D] tensor of the GEMM operand type and compact fp32 rows (the cls-only tail of the last
+// encoder layer, encoder.cpp): out[r, :] = f32(in[r * stride + off, :]) and its inverse (no accumulation).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_gather_cast_kernel(const T* __restrict__ in, float* __restrict__ out, int R, int D, long stride, long off) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)R * D) return;
+  const int r = (int)(i / D), c = (int)(i % D);
+  out[i] = to_f32<T>(in[((long)r * stride + off) * D + c]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void rows_scatter_cast_kernel(const float* __restrict__ in, T* __restrict__ out, int R, int D, long stride, long off) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)R * D) return;
+  const int r = (int)(i / D), c = (int)(i % D);
+  out[((long)r * stride + off) * D + c] = from_f32<T>(in[i]);
+}
+int rmcl_rows_gather_cast(const void* in, int dt, float* out, int R, int D, long stride, long off, hipStream_t s) {
+  const dim3 grid(cdiv((long)R * D, 256));
+  if (dt == RMCL_F32) RMCL_LAUNCH(rows_gather_cast_kernel<float>, grid, dim3(256), 0, s, (const float*)in, out, R, D, stride, off);
+  else RMCL_LAUNCH(rows_gather_cast_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, out, R, D, stride, off);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+int rmcl_rows_scatter_cast(const float* in, void* out, int dt, int R, int D, long stride, long off, hipStream_t s) {
+  const dim3 grid(cdiv((long)R * D, 256));
+  if (dt == RMCL_F32) RMCL_LAUNCH(rows_scatter_cast_kernel<float>, grid, dim3(256), 0, s, in, (float*)out, R, D, stride, off);
+  else RMCL_LAUNCH(rows_scatter_cast_kernel<bf16_t>, grid, dim3(256), 0, s, in, (bf16_t*)out, R, D, stride, off);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Image token assembly (vision_transformer.py:661-667 + vilt_module.py:315-321):
 //   x[b*N + L]         = cls + pos[0] + vtype[1]

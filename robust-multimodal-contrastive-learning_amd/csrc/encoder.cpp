@@ -346,7 +346,10 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
   RMCL_REQUIRE(ragged || d->Pp == 0 || d->Pp == d->P, "encoder_forward: P != Pp needs the rmcl_ragged selection");
   RMCL_REQUIRE(params32 && text_ids && text_mask && patches && co_mask && workspace && xn, "encoder_forward: NULL argument");
   RMCL_REQUIRE(d->dtype == RMCL_F32 || params_lp, "encoder_forward: bf16 mode needs the bf16 shadow arena");
+  const bool tail_req = (mode & RMCL_MODE_CLS_TAIL) != 0;     // only the cls rows of xn will be read (include/rmcl.h)
+  mode &= ~RMCL_MODE_CLS_TAIL;
   RMCL_REQUIRE(mode == RMCL_MODE_INFER || stash, "encoder_forward: stash required unless mode is INFER");
+  RMCL_REQUIRE(!tail_req || (drop_p == 0.f && d->B <= 256), "encoder_forward: the cls-only tail needs dropout off and B <= 256");
   Ctx c{*d, params32, params_lp, {}, (hipStream_t)stream, d->dtype};
   rmcl_param_layout(d, &c.lay);
   const rmcl_layout& y = c.lay;
@@ -431,6 +434,41 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
       RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
     }
     RMCL_TRY(rmcl_attention_fwd_impl(qkv, co_mask, ao, probs, w.scores, B, N, d->H, dt, d->exact, s));
+    if (tail_req && l + 1 == d->layers) {
+      // cls-only tail: of the last block's output only row 0 of every sample is read (the pooler takes hidden_states[:, 0],
+      // heads.py:17), and everything behind the attention is row-wise - proj, LayerNorm 2, the MLP and the final LayerNorm run
+      // on the B cls rows (fp32, exact skinny GEMMs) instead of on all B * N tokens.  Compact results live in the FIRST B rows
+      // of the buffers the dense path would have filled (x_mid, u, h, ln2, x_final, the LN statistics) - the backward with
+      // cls_only = 2 reads them there.
+      float* ao_c = reinterpret_cast<float*>(w.dao);          // backward scratch, free during a forward
+      float* x_c = w.dln;
+      float* ln2_c = reinterpret_cast<float*>(full ? ls.ln2 : w.ln);
+      float* u_c = reinterpret_cast<float*>(keep ? ls.u : w.u);
+      float* h_c = reinterpret_cast<float*>(full ? ls.h : w.h);
+      float* xo_c = keep ? st.x_final : x_out;
+      RMCL_TRY(rmcl_rows_gather_cast(ao, dt, ao_c, B, D, N, 0, s));
+      RMCL_TRY(rmcl_gather_rows(x, x_c, B, D, 1, N, 0, s));
+      {
+        GemmArgs g = gemm_args(ao_c, c.V(c.L(l, y.proj_w)), x_mid, B, D, D, D, D, D);
+        g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x_c; g.ld_aux = D;
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
+      }
+      RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2_c, D, RMCL_F32, m2, r2, B, D, 0, s));
+      {
+        GemmArgs g = gemm_args(ln2_c, c.V(c.L(l, y.fc1_w)), h_c, B, d->mlp, D, D, D, d->mlp);
+        g.epi = EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT; g.bias = c.V(c.L(l, y.fc1_b)); g.C2 = u_c;
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
+      }
+      {
+        GemmArgs g = gemm_args(h_c, c.V(c.L(l, y.fc2_w)), xo_c, B, D, d->mlp, d->mlp, d->mlp, D);
+        g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.fc2_b)); g.aux = x_mid; g.ld_aux = D;
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
+      }
+      // final LayerNorm of the cls rows, written to their places in xn (row b * N); the other rows of xn are NOT written
+      RMCL_TRY(rmcl_ln_fwd(xo_c, D, c.V(y.norm_w), c.V(y.norm_b), 1e-6f, xn, (long)N * D, RMCL_F32, keep ? st.meanF : w.stat,
+                           keep ? st.rstdF : w.stat + M, B, D, 0, s));
+      return 0;
+    }
     {
       GemmArgs g = gemm_args(ao, c.W(c.L(l, y.proj_w)), x_mid, M, D, D, D, D, D);
       g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = D; g.tag = GEMM_TAG_PROJ;
@@ -489,7 +527,9 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
 
   // final LayerNorm backward -> dx (the residual-stream gradient, fp32)
   const float* dy = dxn;
-  if (cls_only) {
+  const bool tail = cls_only == 2;               // the forward of this stash used the cls-only tail (compact last-layer rows)
+  RMCL_REQUIRE(!tail || (drop_p == 0.f && d->B <= 256), "encoder_backward: the cls-only tail needs dropout off and B <= 256");
+  if (cls_only && !tail) {
     hipError_t e = hipMemsetAsync(w.dxn_full, 0, (size_t)M * D * sizeof(float), s);
     if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
     RMCL_TRY(rmcl_scatter_rows(dxn, w.dxn_full, B, D, 1, N, 0, 0, s));
@@ -524,9 +564,16 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   auto rep_slot = [&](int idx) { return grouped ? w.ln_rep + (size_t)idx * RMCL_LN_REP_FLOATS : nullptr; };   // 0: final norm, 1+2l: ln2, 2+2l: ln1
   if (grouped) HIP_TRY(hipMemsetAsync(w.ln_rep, 0, (size_t)(2 * Lr + 1) * RMCL_LN_REP_FLOATS * sizeof(float), s));
   int cur = 0;
-  RMCL_TRY(rmcl_ln_bwd_lp(dy, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), w.dx, D, 0,
-                          full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, T[0], dt,
-                          rmcl_site_seed(drop_seed, d->layers - 1, DROP_SITE_FC2), dth, dinv, rep_slot(0), s));
+  float* dxc = w.dxn_full;                       // tail: gradient of the B cls rows [B, D] f32
+  if (tail) {
+    // forward ran with RMCL_MODE_CLS_TAIL: final LayerNorm backward on the B compact rows
+    RMCL_TRY(rmcl_ln_bwd(dxn, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), dxc, D, 0,
+                         full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, B, D, 0, s));
+  } else {
+    RMCL_TRY(rmcl_ln_bwd_lp(dy, D, RMCL_F32, st.x_final, D, st.meanF, st.rstdF, c.V(y.norm_w), c.V(y.norm_b), w.dx, D, 0,
+                            full ? Gp(y.norm_w) : nullptr, full ? Gp(y.norm_b) : nullptr, M, D, 0, T[0], dt,
+                            rmcl_site_seed(drop_seed, d->layers - 1, DROP_SITE_FC2), dth, dinv, rep_slot(0), s));
+  }
   // gradient w.r.t. the LayerNorm outputs (dX GEMM -> LN backward): in the operand dtype, like du / dqkv / dao (bf16 mode
   // halves the 36 MB write + read per LayerNorm); fp32 mode is unchanged
   const int dln_dt = lpm ? dt : RMCL_F32;
@@ -535,8 +582,62 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     void* du = DU[l & 1];
     void* dqkv = DQ[l & 1];
     const int ia = cur, ib = grouped ? (cur + 1) % 3 : cur ^ 1, ic = grouped ? (cur + 2) % 3 : cur;
+    const bool tail_l = tail && l == Lr - 1;
+    if (tail_l) {
+      // ---- last layer, cls rows only: MLP, LayerNorm 2 and proj backward on [B, .] fp32 (exact skinny GEMMs); weight / bias
+      // gradients of fc2, fc1, proj reduce over B rows instead of B * N; then the two row sets the dense chain continues
+      // from are rebuilt: the residual-stream gradient w.dx and d(attention output) w.dao, zero except on the cls rows.
+      float* u_c = reinterpret_cast<float*>(ls.u);
+      float* h_c = reinterpret_cast<float*>(ls.h);
+      float* ln2_c = reinterpret_cast<float*>(ls.ln2);
+      float* du_c = reinterpret_cast<float*>(w.du);
+      float* dln_c = w.dln;
+      float* ao_c = reinterpret_cast<float*>(w.dqkv2);
+      float* dao_c = reinterpret_cast<float*>(w.du2);
+      {
+        GemmArgs g = gemm_args(dxc, c.V(c.L(l, y.fc2_w)), du_c, B, mlp, D, D, mlp, mlp);               // du = (dx W2) * gelu'(u)
+        g.epi = EPI_DGELU; g.aux = u_c; g.ld_aux = mlp;
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 0, s));
+      }
+      if (full) {
+        GemmArgs g = gemm_args(dxc, h_c, Gp(c.L(l, y.fc2_w)), D, mlp, B, D, mlp, mlp);                   // dW2 += dx^T h
+        g.epi = EPI_ACCUM;
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
+        RMCL_TRY(rmcl_colsum(dxc, D, RMCL_F32, Gp(c.L(l, y.fc2_b)), B, D, s));
+      }
+      {
+        GemmArgs g = gemm_args(du_c, c.V(c.L(l, y.fc1_w)), dln_c, B, D, mlp, mlp, D, D);                 // dln2 = du W1
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 0, s));
+      }
+      if (full) {
+        GemmArgs g = gemm_args(du_c, ln2_c, Gp(c.L(l, y.fc1_w)), mlp, D, B, mlp, D, D);                  // dW1 += du^T ln2
+        g.epi = EPI_ACCUM;
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
+        RMCL_TRY(rmcl_colsum(du_c, mlp, RMCL_F32, Gp(c.L(l, y.fc1_b)), B, mlp, s));
+      }
+      RMCL_TRY(rmcl_ln_bwd(dln_c, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), dxc, D, 1,
+                           full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, B, D, 0, s));   // dxc = d x_mid
+      {
+        GemmArgs g = gemm_args(dxc, c.V(c.L(l, y.proj_w)), dao_c, B, D, D, D, D, D);                     // dao = dx Wproj
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 0, s));
+      }
+      if (full) {
+        RMCL_TRY(rmcl_rows_gather_cast(ls.ao, dt, ao_c, B, D, N, 0, s));
+        GemmArgs g = gemm_args(dxc, ao_c, Gp(c.L(l, y.proj_w)), D, D, B, D, D, D);                       // dWproj += dx^T ao
+        g.epi = EPI_ACCUM;
+        RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
+        RMCL_TRY(rmcl_colsum(dxc, D, RMCL_F32, Gp(c.L(l, y.proj_b)), B, D, s));
+      }
+      HIP_TRY(hipMemsetAsync(w.dx, 0, (size_t)M * D * sizeof(float), s));
+      RMCL_TRY(rmcl_scatter_rows(dxc, w.dx, B, D, 1, N, 0, 0, s));
+      HIP_TRY(hipMemsetAsync(w.dao, 0, (size_t)M * D * esz(dt), s));
+      RMCL_TRY(rmcl_rows_scatter_cast(dao_c, w.dao, dt, B, D, N, 0, s));
+      if (full && !grouped && use_side) HIP_TRY(hipEventRecord(EV(1, l), cs.s));   // (no MLP weight-gradient work on the side stream)
+    }
     // ---- MLP ----
     const void* dxT = lpm ? T[ia] : (const void*)w.dx;
+    const void* dxT_b = lpm ? T[ib] : (const void*)w.dx;
+    if (!tail_l) {
     if (use_side && !grouped && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(1, l + 2), 0));   // du buffer free again
     {
       GemmArgs g = gemm_args(dxT, WT ? WTp(c.L(l, y.fc2_w)) : c.W(c.L(l, y.fc2_w)), du, M, mlp, D, D, WT ? D : mlp, mlp);   // du = (dx W2) * gelu'(u)
@@ -563,18 +664,20 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
                             full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, M, D, 0, T[ib], dt,
                             rmcl_site_seed(drop_seed, l, DROP_SITE_PROJ), dth, dinv, rep_slot(1 + 2 * l), s));
     // ---- attention ----
-    const void* dxT_b = lpm ? T[ib] : (const void*)w.dx;
     {
       GemmArgs g = gemm_args(dxT_b, WT ? WTp(c.L(l, y.proj_w)) : c.W(c.L(l, y.proj_w)), w.dao, M, D, D, D, D, D);   // dao = dx Wproj
       g.tag = GEMM_TAG_DX;
       RMCL_TRY(gemm(c, g, dt, dt, 1, WT ? 1 : 0));
     }
+    }   // !tail_l
     if (use_side && !grouped && l + 2 < Lr) HIP_TRY(hipStreamWaitEvent(s, EV(2, l + 2), 0));   // dqkv buffer free again
     RMCL_TRY(rmcl_attention_bwd_impl(ls.qkv, co_mask, ls.probs, w.dao, ls.ao, dqkv, w.scores, w.dS, B, N, d->H, dt, d->exact, s));
     if (full && !grouped) {
       if (use_side) { HIP_TRY(hipEventRecord(EV(0, 2 * l + 1), s)); HIP_TRY(hipStreamWaitEvent(cs.s, EV(0, 2 * l + 1), 0)); }
-      RMCL_TRY(gemm_dw(cs, dxT_b, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
-      RMCL_TRY(rmcl_colsum(dxT_b, D, dt, Gp(c.L(l, y.proj_b)), M, D, cs.s));
+      if (!tail_l) {
+        RMCL_TRY(gemm_dw(cs, dxT_b, D, ls.ao, D, Gp(c.L(l, y.proj_w)), D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
+        RMCL_TRY(rmcl_colsum(dxT_b, D, dt, Gp(c.L(l, y.proj_b)), M, D, cs.s));
+      }
       RMCL_TRY(gemm_dw(cs, dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
       RMCL_TRY(rmcl_colsum(dqkv, 3 * D, dt, Gp(c.L(l, y.qkv_b)), M, 3 * D, cs.s));
       if (use_side) HIP_TRY(hipEventRecord(EV(2, l), cs.s));
@@ -587,12 +690,18 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
     if (use_side && !grouped) HIP_TRY(hipStreamWaitEvent(s, EV(1, l), 0));                 // T[ic] free again
     RMCL_TRY(rmcl_ln_bwd_lp(w.dln, D, dln_dt, ls.x_in, D, ls.mean1, ls.rstd1, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), w.dx, D, 1,
                             full ? Gp(c.L(l, y.ln1_w)) : nullptr, full ? Gp(c.L(l, y.ln1_b)) : nullptr, M, D, 0, T[ic], dt,
-                            rmcl_site_seed(drop_seed, l - 1, DROP_SITE_FC2), l > 0 ? dth : 0u, dinv, rep_slot(2 + 2 * l), s));
+                            rmcl_site_seed(drop_seed, l - 1, DROP_SITE_FC2), l > 0 ? dth : 0u, dinv, tail_l ? nullptr : rep_slot(2 + 2 * l), s));
     cur = ic;
     // EV(3, l): everything of layer l that runs on the main stream is enqueued (with the grouped launch on the SAME stream that
     // includes the launch, recorded below)
     if (full && (use_side || !grouped)) HIP_TRY(hipEventRecord(EV(3, l), s));
-    if (grouped) {
+    if (grouped && tail_l) {
+      // tail layer: fc2 / fc1 / proj gradients were formed from the B cls rows above; only qkv reduces over all tokens
+      if (use_side) HIP_TRY(hipStreamWaitEvent(cs.s, EV(3, l), 0));
+      RMCL_TRY(gemm_dw(cs, dqkv, 3 * D, ls.ln1, D, Gp(c.L(l, y.qkv_w)), 3 * D, D, M, dt, w.slab, SLAB_FLOATS(*d)));
+      RMCL_TRY(rmcl_colsum(dqkv, 3 * D, dt, Gp(c.L(l, y.qkv_b)), M, 3 * D, cs.s));
+      HIP_TRY(hipEventRecord(EV(use_side ? 2 : 3, l), cs.s));
+    } else if (grouped) {
       // everything the layer's weight gradients read is final: both dx copies, du, dqkv, the stash, the LN replicas
       if (use_side) HIP_TRY(hipStreamWaitEvent(cs.s, EV(3, l), 0));
       DwGroupArgs a{};

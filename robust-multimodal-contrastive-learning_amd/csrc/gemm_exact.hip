@@ -297,21 +297,128 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
     if (row < g.M && n < g.N) {
       float v = g.alpha * acc[r];
       if (g.epi & EPI_BIAS) v += g.bias[n];
-      if (g.epi & EPI_TANH) v = tanhf(v);
       const long ci = (long)row * g.ldc + n;
+      if (g.epi & EPI_SAVE_PREACT) reinterpret_cast<float*>(g.C2)[ci] = v;
+      if (g.epi & EPI_GELU) v = gelu_erf(v);
+      if (g.epi & EPI_TANH) v = tanhf(v);
+      if (g.epi & EPI_DGELU) v *= gelu_erf_grad(reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n]);
+      if (g.epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n];
       if (g.epi & EPI_ACCUM) v += C[ci];
       C[ci] = v;
     }
   }
 }
 
+// Second form of the skinny GEMM: the four waves of a workgroup split K instead of the rows.  Every wave covers all 64 rows
+// (4 row tiles) x NT columns over its quarter of K, so a B fragment feeds 4 (x NT/16) MFMAs instead of 1, the serial k-loop
+// of a workgroup is 4x shorter (N = 768, K = 3072: 48 workgroups were looping 3072 deep), and the partial tiles meet in LDS
+// where the epilogue runs.  NT = 32 halves the re-reads of the A panel for very wide outputs (Barlow-Twins head, N = 8192).
+// Same operand trick as above: lane (c, g) holds k = 16 s + 4 g + j in component j of one float4, on both operands.
+template <bool B_KC, int NT>
+__global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs g) {
+  constexpr int CT = NT / 16;
+  __shared__ float red[4][64][NT + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, gq = lane >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * NT;
+  const int kq = g.K / 4, k_lo = wave * kq, k_hi = k_lo + kq;
+  const float* Ap[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) Ap[rt] = reinterpret_cast<const float*>(g.A) + (long)min(m0 + rt * 16 + c, g.M - 1) * g.lda + 4 * gq;
+  const float* Bp[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    const int nc = min(n0 + ct * 16 + c, g.N - 1);
+    Bp[ct] = reinterpret_cast<const float*>(g.B) + (B_KC ? (long)nc * g.ldb + 4 * gq : (long)(4 * gq) * g.ldb + nc);
+  }
+  f32x4 acc[4][CT];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = k_lo; k < k_hi; k += 32) {
+    float4 av[2][4];
+    float bv[2][CT][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (k + 16 * u < k_hi) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) av[u][rt] = *reinterpret_cast<const float4*>(Ap[rt] + k + 16 * u);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          if (B_KC) {
+            const float4 t = *reinterpret_cast<const float4*>(Bp[ct] + k + 16 * u);
+            bv[u][ct][0] = t.x; bv[u][ct][1] = t.y; bv[u][ct][2] = t.z; bv[u][ct][3] = t.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[u][ct][j] = Bp[ct][(long)(k + 16 * u + j) * g.ldb];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                     // every load of the iteration is in flight before the first MFMA waits
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (k + 16 * u < k_hi) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt].x, bv[u][ct][0], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt].y, bv[u][ct][1], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt].z, bv[u][ct][2], acc[rt][ct], 0, 0, 0);
+            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt].w, bv[u][ct][3], acc[rt][ct], 0, 0, 0);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * gq + r][ct * 16 + c] = acc[rt][ct][r];
+  __syncthreads();
+  float* C = reinterpret_cast<float*>(g.C);
+  for (int i = threadIdx.x; i < 64 * NT; i += 256) {
+    const int rl = i / NT, cl = i % NT, row = m0 + rl, n = n0 + cl;
+    if (row >= g.M || n >= g.N) continue;
+    float v = g.alpha * ((red[0][rl][cl] + red[1][rl][cl]) + (red[2][rl][cl] + red[3][rl][cl]));      // k order: wave 0..3
+    if (g.epi & EPI_BIAS) v += g.bias[n];
+    const long ci = (long)row * g.ldc + n;
+    if (g.epi & EPI_SAVE_PREACT) reinterpret_cast<float*>(g.C2)[ci] = v;
+    if (g.epi & EPI_GELU) v = gelu_erf(v);
+    if (g.epi & EPI_TANH) v = tanhf(v);
+    if (g.epi & EPI_DGELU) v *= gelu_erf_grad(reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n]);
+    if (g.epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n];
+    if (g.epi & EPI_ACCUM) v += C[ci];
+    C[ci] = v;
+  }
+}
+
 bool rmcl_gemm_skinny_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc) {
   return a_kc && dt_in == RMCL_F32 && dt_out == RMCL_F32 && g.M <= 256 && g.K % 16 == 0 && g.K >= 64 && g.splitk <= 1 &&
-         g.nb1 * g.nb2 == 1 && (g.epi & ~(EPI_BIAS | EPI_TANH | EPI_ACCUM)) == 0 && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
+         g.nb1 * g.nb2 == 1 && (g.epi & ~(EPI_BIAS | EPI_TANH | EPI_ACCUM | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_RESIDUAL)) == 0 &&
+         !((g.epi & EPI_DGELU) && (g.epi & EPI_RESIDUAL)) && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
          ((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0;
 }
 
+static int g_skinny_form = -1;      // rmcl_tune_set key 6: 0 = row-split waves (first form) only, else k-split where K % 64 == 0
+void rmcl_gemm_skinny_set_form(int v) { g_skinny_form = v; }
+
 int rmcl_launch_gemm_skinny(const GemmArgs& g, int b_kc, hipStream_t s) {
+  if (g_skinny_form != 0 && g.K % 64 == 0 && g.K >= 128) {
+    if (g.N >= 4096) {
+      dim3 grid(cdiv(g.N, 32), cdiv(g.M, 64));
+      if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 32>), grid, dim3(256), 0, s, g);
+      else RMCL_LAUNCH((gemm_skinny_ksplit_kernel<false, 32>), grid, dim3(256), 0, s, g);
+    } else {
+      dim3 grid(cdiv(g.N, 16), cdiv(g.M, 64));
+      if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 16>), grid, dim3(256), 0, s, g);
+      else RMCL_LAUNCH((gemm_skinny_ksplit_kernel<false, 16>), grid, dim3(256), 0, s, g);
+    }
+    RMCL_CHECK_LAUNCH();
+    return 0;
+  }
   dim3 grid(cdiv(g.N, 16), cdiv(g.M, 64));
   if (b_kc) RMCL_LAUNCH(gemm_skinny_kernel<true>, grid, dim3(256), 0, s, g);
   else RMCL_LAUNCH(gemm_skinny_kernel<false>, grid, dim3(256), 0, s, g);

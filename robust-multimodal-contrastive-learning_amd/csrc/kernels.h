@@ -11,6 +11,7 @@ bool rmcl_gemm_fast_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc
 int rmcl_launch_gemm_fast_slab(const GemmArgs& g, float* slab, float* out, hipStream_t s);
 int rmcl_slab_reduce(const float* slab, float* out, long n, int nz, hipStream_t s);
 int rmcl_gemm_fast_get_cfg();
+void rmcl_gemm_skinny_set_form(int v);     // gemm_exact.hip: 0 = row-split skinny kernel only
 bool rmcl_gemm_routes_to_tile192(const GemmArgs& g, int a_kc, int b_kc);
 // LayerNorm fold (gemm.h EPI_LNFOLD): per layer W' = bf16(W * gamma) for qkv (3D rows) then fc1 (mlp rows), and s / c vectors
 int rmcl_ln_fold_launch(const float* p32, long layer0, long stride, int layers, long ln1_w, long ln1_b, long qkv_w, long qkv_b, long ln2_w,
@@ -60,6 +61,8 @@ int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, floa
                             long pad_id, hipStream_t s);
 int rmcl_gather_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, hipStream_t s);
 int rmcl_scatter_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, int add, hipStream_t s);
+int rmcl_rows_gather_cast(const void* in, int dt, float* out, int R, int D, long stride, long off, hipStream_t s);
+int rmcl_rows_scatter_cast(const float* in, void* out, int dt, int R, int D, long stride, long off, hipStream_t s);
 int rmcl_image_assemble_fwd(const float* pe, const float* cls, const float* pos, const float* vtype1, float* x, int B, int P,
                             int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, int pos_per_sample, hipStream_t s);
 int rmcl_image_assemble_bwd(const float* dx, void* dpe, int dt, float* dpos, float* dcls, float* dvtype1, int B, int P, int L,

@@ -156,6 +156,7 @@ class PassBuffers:
         self.text_mask = None
         self.pos_tok = self.dpos_tok = None      # per-sample position rows of a zero-padded batch and their gradient (lazy)
         self.drop = {L.MODE_INFER: (0, 0.0), L.MODE_DATA: (0, 0.0), L.MODE_FULL: (0, 0.0)}
+        self.tail = {}                           # mode -> the last forward in that mode used the cls-only tail
 
 
 class RaggedGeometry:
@@ -419,9 +420,14 @@ class Engine:
         return out
 
     # ---- encoder passes ------------------------------------------------------------------------
-    def encoder_forward(self, pb: PassBuffers, key: bool, mode: int, patchesT: torch.Tensor):
+    def encoder_forward(self, pb: PassBuffers, key: bool, mode: int, patchesT: torch.Tensor, cls_tail: bool = False):
+        """cls_tail: the caller reads only the cls row of every sample of pb.xn (the contrastive objectives: pooler -> head); the
+        last block then runs its row-wise part on B rows (include/rmcl.h RMCL_MODE_CLS_TAIL).  Remembered per (buffers, mode):
+        the matching encoder_backward picks the compact form by itself.  Off with dropout (masks are indexed by dense rows)."""
         if self.lp_stale:
             self.refresh_shadows()
+        tail = bool(cls_tail) and not self.dropout_on and pb.B <= 256 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"
+        pb.tail[mode] = tail
         # dropout (reference: live in every train-mode forward incl. the key encoder and the PGD copies, SURVEY
         # quirk 6): a fresh seed per pass, remembered per stash so the matching backward regenerates the masks
         self.pass_counter += 1
@@ -430,7 +436,7 @@ class Engine:
         pb.drop[mode] = (seed, p)
         p32, plp = (self.k32, self.k_lp) if key else (self.q32, self.q_lp)
         stash = {L.MODE_INFER: None, L.MODE_DATA: pb.stash_data, L.MODE_FULL: pb.stash_full}[mode]
-        check(lib.rmcl_encoder_forward(C.byref(pb.d), mode, P(p32), P(plp), P(pb.text_ids), P(pb.text_mask), P(patchesT),
+        check(lib.rmcl_encoder_forward(C.byref(pb.d), mode | (L.MODE_CLS_TAIL if tail else 0), P(p32), P(plp), P(pb.text_ids), P(pb.text_mask), P(patchesT),
                                        P(pb.co_mask), P(stash), P(pb.workspace), P(pb.xn), C.c_uint32(seed), F(p), self._rg(pb),
                                        self.fold_of(key) if (mode != L.MODE_FULL and pb.dtype == L.BF16) else None, stream_ptr()),
               "encoder_forward")
@@ -456,8 +462,11 @@ class Engine:
     def encoder_backward(self, pb: PassBuffers, mode: int, patchesT, dxn, cls_only: bool, dpatches, dtext=None):
         stash = pb.stash_data if mode == L.MODE_DATA else pb.stash_full
         seed, p = pb.drop[mode]
+        co = (2 if pb.tail.get(mode) else 1) if cls_only else 0
+        if pb.tail.get(mode) and not cls_only:
+            raise L.RmclError("encoder_backward: the forward of these buffers kept only the cls rows (cls_tail) - a full-row gradient has nowhere to go")
         check(lib.rmcl_encoder_backward(C.byref(pb.d), mode, P(self.q32), P(self.q_lp), P(pb.text_ids), P(patchesT),
-                                        P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), int(cls_only), P(dpatches), P(dtext),
+                                        P(pb.co_mask), P(stash), P(pb.workspace), P(dxn), co, P(dpatches), P(dtext),
                                         P(self.g32 if mode == L.MODE_FULL else None), C.c_uint32(seed), F(p), self._rg(pb),
                                         P(self.weights_T() if pb.dtype == L.BF16 else None), stream_ptr()), "encoder_backward")
 

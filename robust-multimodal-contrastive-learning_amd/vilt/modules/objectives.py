@@ -68,7 +68,7 @@ def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_origin
     eng = pl_module.engine
     B = pv.B
     need_grad = torch.is_grad_enabled() and pl_module.training
-    eng.encoder_forward(pv, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op)
+    eng.encoder_forward(pv, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op, cls_tail=True)
     eng.heads_forward(pv, key=False)
     if before_loss is not None:
         before_loss()                                  # e.g. join the key-encoder stream: k is needed from here on
@@ -216,7 +216,7 @@ def compute_moco_contrastive(pl_module, batch):
     eng.ema(pl_module.momentum)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op)
+        eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op, cls_tail=True)
         eng.heads_forward(pk, key=True)
     gather_box = {}
 
@@ -245,7 +245,7 @@ def compute_moco_contrastive(pl_module, batch):
         loss = loss + loss_c
         loss_num += 1
     elif not fuse_clean:
-        eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)     # clean query
+        eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op, cls_tail=True)     # clean query
         eng.heads_forward(pb, key=False)
         join_key_stream()
         eng.infonce(pb, 0.0, want_dq=False)
@@ -318,7 +318,7 @@ def _bt_view(pl_module, pv, op, zk, suffix, ret, phase, need_grad, training):
     head (running estimates updated in training), c = q^T k / per_step_bs summed over ranks, on/off-diagonal loss, distance
     logs; returns (loss value with a deferred HIP backward, on_diag, adv_lr * off_diag)."""
     eng = pl_module.engine
-    eng.encoder_forward(pv, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op)
+    eng.encoder_forward(pv, key=False, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op, cls_tail=True)
     eng.heads_forward(pv, key=False, want_q=False)
     bq = eng.bt_bufs(pv.B, "q_" + suffix)
     eng.bt_forward(bq, pv.cls, training, track=training)
@@ -373,7 +373,7 @@ def compute_barlowtwins_contrastive(pl_module, batch):
     B = pb.B
     op = eng.make_operand(pb)
     bk = eng.bt_bufs(B, "k")
-    eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op)          # :460-462
+    eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op, cls_tail=True)          # :460-462
     eng.heads_forward(pb, key=False, want_q=False)
     zk = eng.bt_forward(bk, pb.cls, training, track=training)
     loss, loss_num = 0, 0

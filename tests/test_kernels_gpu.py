@@ -422,6 +422,30 @@ def test_gemm_skinny_heads_shapes():
         assert rel_err(out, X.double() @ W.double().t() + base.double()) < 2e-5
 
 
+@pytest.mark.parametrize("form", [0, 1])
+def test_gemm_skinny_epilogues_and_forms(form):
+    """Both forms of the skinny fp32 GEMM (rmcl_tune_set key 6: 0 = waves split the rows, else waves split K where K % 64 == 0)
+    with the epilogues of the encoder's cls-only tail: bias + GELU + saved pre-activation, bias + residual, GELU' of a saved
+    pre-activation (data gradient, B stored [K][N]), and the 8192-wide Barlow-Twins shape (32-column tiles)."""
+    check(lib.rmcl_tune_set(6, form))
+    try:
+        gelu = lambda t: 0.5 * t * (1 + torch.erf(t / 2 ** 0.5))
+        dgelu = lambda t: 0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * torch.pi) ** 0.5
+        for M, N, K in ((64, 3072, 768), (64, 768, 3072), (37, 768, 768), (64, 128, 768), (64, 8192, 2048), (130, 8192, 256)):
+            X, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3)
+            pre = X.double() @ W.double().t() + b.double()
+            out, c2 = gemm(X, W, M, N, K, 1, 1, L.F32, L.F32, bias=b, epi=1 | 2 | 4, want_c2=True)          # bias, GELU, save pre-activation
+            assert rel_err(c2, pre) < 2e-5 and rel_err(out, gelu(pre)) < 2e-5, (M, N, K)
+            res = rnd(M, N, seed=7)
+            out = gemm(X, W, M, N, K, 1, 1, L.F32, L.F32, bias=b, aux=res, ld_aux=N, epi=1 | 8)
+            assert rel_err(out, pre + res.double()) < 2e-5, (M, N, K)
+            u = rnd(M, N, seed=9)
+            out = gemm(X, W.t().contiguous(), M, N, K, 1, 0, L.F32, L.F32, aux=u, ld_aux=N, epi=16)          # (X W^T) * gelu'(u), B as [K][N]
+            assert rel_err(out, (X.double() @ W.double().t()) * dgelu(u.double())) < 2e-5, (M, N, K)
+    finally:
+        check(lib.rmcl_tune_set(6, -1))
+
+
 # ------------------------------------------------------------------------- LayerNorm folded into the consuming GEMM
 @pytest.mark.parametrize("N2,gelu", [(2304, 0), (3072, 1)])
 def test_layernorm_fold_gemm_pair_matches_layernorm_then_linear(N2, gelu):
