@@ -18,8 +18,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement): metric/value/un
                  (per-launch event brackets inside the step add ~20 us of marker/dispatch latency each, so
                  they over-state the duration rocprofv3 reports); algorithmic FLOPs / average duration vs
                  the dense bf16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md (2.5 PFLOP/s);
-  step_mfma_frac - whole-step algorithmic FLOPs ((4+2K)F per pair with dropout off - the clean query forward IS PGD step
-                 0's forward and runs once - else SURVEY 8d's (5+2K)F) / step time / peak;
+  step_mfma_frac - whole-step EXECUTED FLOPs / step time / peak: (4+2K) forward-equivalents per pair with dropout off (the
+                 clean query forward IS PGD step 0's forward and runs once; SURVEY 8d counts (5+2K)F), each F less the part of
+                 the last block the cls-only tail does not execute (5.9 % of F; F_TAIL_SKIPPED) - work that is skipped is not
+                 credited; `value` (pairs/s) is what the skipping buys;
   cpu_baseline - the CPU oracle (port of the reference algorithm, oracle/rmcl_oracle.py) timed on this
                  host's cores on a bounded sample of the same workload (rank 0, N=1 only).
 
@@ -47,6 +49,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15          # dense bf16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 F_PER_PAIR = 33.386e9       # one encoder forward, SURVEY.md 8(d)
+# cls-only tail (include/rmcl.h RMCL_MODE_CLS_TAIL): in a contrastive pass the last block's proj / fc1 / fc2 (9 of its 12 D x D
+# linear units) run on the cls row only - FLOPs NOT executed per forward-equivalent and pair (N = 185 tokens, D = 768)
+F_TAIL_SKIPPED = 0.75 * (2 * 185 * 12 * 768 * 768) * 184 / 185
 
 
 def synthetic_batch(cfg, B, seed, device):
@@ -265,26 +270,28 @@ def main():
         value = pairs / elapsed
         # algorithmic FLOPs per GPU per step: SURVEY 8(d) counts (5+2K)F; with dropout off the clean query forward
         # and PGD step 0's forward are the same computation and run once -> (4+2K)F are executed and credited
-        step_flops = ((4 if args.drop_rate == 0 else 5) + 2 * K) * F_PER_PAIR * B
+        tail = args.drop_rate == 0 and B <= 256 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"
+        F_c = F_PER_PAIR - (F_TAIL_SKIPPED if tail else 0.0)           # executed FLOPs of one contrastive forward-equivalent
+        step_flops = ((4 if args.drop_rate == 0 else 5) + 2 * K) * F_c * B
         workload = (f"RMCL step, PGD K={K} image attack + MoCo InfoNCE (queue 65536) + full backward + AdamW, "
                     f"ViLT-B/32, bs={B}/GPU, 384x384 img + 40 tok (BASELINE configs[2]; [3] when n_gpus=8)")
         metric = f"image-text pairs/sec, ViLT-B/32 RMCL step (PGD K={K})"
         if clean:                                        # key 1F + clean query fwd+bwd 3F + ITM fwd+bwd 3F (SURVEY 8d Config 2)
-            step_flops = 7 * F_PER_PAIR * B
+            step_flops = (4 * F_c + 3 * F_PER_PAIR) * B               # the ITM pass needs every token of the last block
             workload = (f"clean ITM + contrastive step: ITM + word-patch alignment (IPOT) + CE on the clean InfoNCE logits (queue 65536) "
                         f"+ full backward + AdamW, ViLT-B/32, bs={B}/GPU, 384x384 img + 40 tok (BASELINE configs[1])")
             metric = "image-text pairs/sec, ViLT-B/32 clean ITM+contrastive step"
         if full:
             # SURVEY 8d Config 5: 11F (key, clean, three attacked views fwd+bwd) + 2K F (PGD) + the text attack: per loop 2F
             # (saliency fwd + data backward) + 5F (five candidate sentences per sample) = 70F for 10 loops; K = 5
-            step_flops = (11 + 2 * K + 10 * (2 + 5)) * F_PER_PAIR * B
+            step_flops = (11 + 2 * K + 10 * (2 + 5)) * F_c * B
             workload = (f"full RMCL step: PGD K={K} image attack + greedy text attack (10 loops x 5 synthetic candidates per sample) + text / "
                         f"image / both views + MoCo InfoNCE (queue 65536) + full backward + AdamW, ViLT-B/32, bs={B}/GPU (BASELINE configs[4])")
             metric = f"image-text pairs/sec, ViLT-B/32 full RMCL step (PGD K={K} + text attack)"
         if barlow:
             # clean forward 1F + K PGD steps 2F each + attacked forward/backward 3F; the head adds 3 x 2 x B x 8192^2-ish FLOPs per
             # pass (weight-streaming, HBM-bound) and the 8192 x 8192 x B correlation - not counted in F
-            step_flops = (4 + 2 * K) * F_PER_PAIR * B
+            step_flops = (4 + 2 * K) * F_c * B
             workload = (f"Barlow-Twins variant of the RMCL step: clean projection + PGD K={K} on the cross-correlation loss + attacked view + "
                         f"full backward + AdamW (ViLT-B/32 + 768-8192-8192-8192 BatchNorm head), bs={B}/GPU (objectives.py:449-602)")
             metric = f"image-text pairs/sec, ViLT-B/32 Barlow-Twins step (PGD K={K})"

@@ -617,3 +617,68 @@ def test_two_closure_step_reduces_once_on_one_rank():
         m.step_sync.algo = "ring"
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,Bn,layers", [("f32", 5, 2), ("bf16", 64, 3)])
+def test_cls_only_tail_equals_the_dense_last_block(dtype, Bn, layers):
+    """RMCL_MODE_CLS_TAIL (include/rmcl.h): with only the cls rows of the encoder output read, the last block's row-wise part
+    runs on B rows - cls features, the PGD data gradient (DATA mode) and every parameter gradient (FULL mode, incl. the last
+    layer's fc1 / fc2 / proj / LayerNorm tensors reduced over B rows) must equal the dense pass up to summation order
+    (f32) / up to the bf16 rounding of the dense last block (bf16: the tail keeps fp32 operands)."""
+    from rmcl_amd import _lib as L
+    ocfg = O.default_config(num_layers=layers, num_negative=1024, per_gpu_batchsize=Bn)
+    cfg = task_moco(num_layers=layers, num_negative=1024, per_gpu_batchsize=Bn, drop_rate=0.0, image_view=True, num_gpus=1, num_nodes=1)
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype=dtype)
+    p = O.init_params(ocfg, 3)
+    m.load_state_dict({n: t.to(DEV) for n, t in p.items()}, strict=False)
+    m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+    batch = O.synthetic_batch(ocfg, Bn, 4, ragged_text=True)
+    eng = m.engine
+    eng.dropout_on = False
+    pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], batch["image"][0])
+    op = eng.make_operand(pb, out=pb.patchesT_full)
+    k = torch.nn.functional.normalize(torch.randn(Bn, 128, generator=torch.Generator().manual_seed(1)), dim=1)
+    pb.k.copy_(k.to(DEV))
+    res = {}
+    for tail in (False, True):
+        out = {}
+        for mode in (L.MODE_INFER, L.MODE_DATA, L.MODE_FULL):
+            eng.zero_grads()
+            eng.encoder_forward(pb, key=False, mode=mode, patchesT=op, cls_tail=tail)
+            assert pb.tail[mode] == tail
+            eng.heads_forward(pb, key=False)
+            out[("cls", mode)] = pb.cls.clone()
+            if mode == L.MODE_INFER:
+                continue
+            eng.infonce(pb, 1.0 / Bn, want_dq=True)
+            eng.heads_backward(pb, pb.dq, None, with_grads=mode == L.MODE_FULL)
+            dpat = torch.zeros_like(pb.patchesT_full)
+            eng.encoder_backward(pb, mode, op, pb.dcls, cls_only=True, dpatches=dpat)
+            torch.cuda.synchronize()
+            out[("dpat", mode)] = dpat.float().clone()
+            if mode == L.MODE_FULL:
+                out["g"] = eng.g32.clone()
+        res[tail] = out
+    # f32: the same arithmetic in another summation order.  bf16: the dense last block rounds its operands and activations to
+    # bf16, the tail keeps fp32 - the difference is the dense pass's own rounding noise (gradients: a few % of the maximum)
+    for key in res[False]:
+        a, b = res[False][key], res[True][key]
+        if key == "g":
+            continue
+        tol = 2e-5 if dtype == "f32" else (3e-2 if key[0] == "cls" else 0.15)
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-12, key
+    ga, gb = res[False]["g"], res[True]["g"]
+    lay = eng.layout
+    specs = {n: (off, shape) for n, off, shape in eng.specs}
+    for n, (off, shape) in specs.items():
+        cnt = 1
+        for v in shape:
+            cnt *= v
+        a, b = ga[off:off + cnt], gb[off:off + cnt]
+        if float(a.abs().max()) == 0.0:
+            continue
+        assert float((a - b).abs().max()) <= (1e-4 if dtype == "f32" else 0.12) * float(a.abs().max()) + 1e-12, n
+    # a full-row gradient cannot be back-propagated through buffers whose forward kept only the cls rows
+    eng.encoder_forward(pb, key=False, mode=L.MODE_FULL, patchesT=op, cls_tail=True)
+    with pytest.raises(L.RmclError):
+        eng.encoder_backward(pb, L.MODE_FULL, op, pb.xn, cls_only=False, dpatches=None)
