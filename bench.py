@@ -270,7 +270,7 @@ def main():
         value = pairs / elapsed
         # algorithmic FLOPs per GPU per step: SURVEY 8(d) counts (5+2K)F; with dropout off the clean query forward
         # and PGD step 0's forward are the same computation and run once -> (4+2K)F are executed and credited
-        tail = args.drop_rate == 0 and B <= 256 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"
+        tail = args.drop_rate == 0 and (5 * B if full else B) <= 1024 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"   # (candidate batch: 5 B rows)
         F_c = F_PER_PAIR - (F_TAIL_SKIPPED if tail else 0.0)           # executed FLOPs of one contrastive forward-equivalent
         step_flops = ((4 if args.drop_rate == 0 else 5) + 2 * K) * F_c * B
         workload = (f"RMCL step, PGD K={K} image attack + MoCo InfoNCE (queue 65536) + full backward + AdamW, "

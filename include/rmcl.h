@@ -34,7 +34,7 @@ extern "C" {
  * (proj, LayerNorm 2, the MLP, the final LayerNorm), so it then runs on B rows instead of B * N; the other rows of xn are
  * left unwritten.  The matching rmcl_encoder_backward must be called with cls_only = 2 (dxn = the [B, D] gradient of those
  * rows): it back-propagates the compact tail and reduces the last layer's fc2 / fc1 / proj weight gradients over B rows.
- * Requires dropout off and B <= 256.  Results equal the dense pass on the cls rows up to fp32 summation order (the tail
+ * Requires dropout off and B <= 1024.  Results equal the dense pass on the cls rows up to fp32 summation order (the tail
  * uses the fp32 master weights).                                                                                     */
 #define RMCL_MODE_CLS_TAIL 16
 

@@ -349,7 +349,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
   const bool tail_req = (mode & RMCL_MODE_CLS_TAIL) != 0;     // only the cls rows of xn will be read (include/rmcl.h)
   mode &= ~RMCL_MODE_CLS_TAIL;
   RMCL_REQUIRE(mode == RMCL_MODE_INFER || stash, "encoder_forward: stash required unless mode is INFER");
-  RMCL_REQUIRE(!tail_req || (drop_p == 0.f && d->B <= 256), "encoder_forward: the cls-only tail needs dropout off and B <= 256");
+  RMCL_REQUIRE(!tail_req || (drop_p == 0.f && d->B <= 1024), "encoder_forward: the cls-only tail needs dropout off and B <= 1024");
   Ctx c{*d, params32, params_lp, {}, (hipStream_t)stream, d->dtype};
   rmcl_param_layout(d, &c.lay);
   const rmcl_layout& y = c.lay;
@@ -528,7 +528,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   // final LayerNorm backward -> dx (the residual-stream gradient, fp32)
   const float* dy = dxn;
   const bool tail = cls_only == 2;               // the forward of this stash used the cls-only tail (compact last-layer rows)
-  RMCL_REQUIRE(!tail || (drop_p == 0.f && d->B <= 256), "encoder_backward: the cls-only tail needs dropout off and B <= 256");
+  RMCL_REQUIRE(!tail || (drop_p == 0.f && d->B <= 1024), "encoder_backward: the cls-only tail needs dropout off and B <= 1024");
   if (cls_only && !tail) {
     hipError_t e = hipMemsetAsync(w.dxn_full, 0, (size_t)M * D * sizeof(float), s);
     if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }

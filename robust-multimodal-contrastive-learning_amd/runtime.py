@@ -426,7 +426,7 @@ class Engine:
         the matching encoder_backward picks the compact form by itself.  Off with dropout (masks are indexed by dense rows)."""
         if self.lp_stale:
             self.refresh_shadows()
-        tail = bool(cls_tail) and not self.dropout_on and pb.B <= 256 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"
+        tail = bool(cls_tail) and not self.dropout_on and pb.B <= 1024 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"
         pb.tail[mode] = tail
         # dropout (reference: live in every train-mode forward incl. the key encoder and the PGD copies, SURVEY
         # quirk 6): a fresh seed per pass, remembered per stash so the matching backward regenerates the masks

@@ -241,7 +241,9 @@ def test_barlowtwins_three_views_with_text_attack_match_reference_golden():
     for li, (replace_idx, new_text, all_num, best) in enumerate(att.trace):
         assert [-1 if x is None else x for x in replace_idx] == g["replace_idx"][li].tolist(), li
         assert new_text == [str(t) for t in g[f"new_text_{li}"]], li
-        assert best == g["best_idx"][li].tolist(), li
+        # index 0 and -1 both mean "keep the sentence" (only an index > 0 is accepted, greedy_attack_vilt.py:568); a candidate
+        # equal to the original sentence scores an exact tie in exact arithmetic, so the two are not distinguished here
+        assert [max(j, 0) for j in best] == [max(int(j), 0) for j in g["best_idx"][li]], li
     assert abs(float(loss) - float(g["total_loss"])) < 1e-3 * float(g["total_loss"])
     lg = m.logged
     assert abs(float(lg["barlowtwins/train/loss"]) - float(g["ret_barlowtwins_loss"])) < 1e-3 * float(g["ret_barlowtwins_loss"])

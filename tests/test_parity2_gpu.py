@@ -365,7 +365,9 @@ def test_word_level_text_attack_matches_reference_end_to_end():
     for li, (replace_idx, new_text, all_num, best) in enumerate(att.trace):
         assert [-1 if x is None else x for x in replace_idx] == g["replace_idx"][li].tolist(), li
         assert new_text == [str(t) for t in g[f"new_text_{li}"]], li
-        assert best == g["best_idx"][li].tolist(), li
+        # index 0 and -1 both mean "keep the sentence" (only an index > 0 is accepted, greedy_attack_vilt.py:568); a candidate
+        # equal to the original sentence scores an exact tie in exact arithmetic, so the two are not distinguished here
+        assert [max(j, 0) for j in best] == [max(int(j), 0) for j in g["best_idx"][li]], li
     assert res["text"] == [str(t) for t in g["text_out"]]
     assert torch.equal(res["txt_input_ids"].cpu(), torch.from_numpy(g["text_ids_out"]))
     assert torch.equal(res["text_masks"].cpu(), torch.from_numpy(g["text_masks_out"]))
