@@ -165,8 +165,8 @@ def traffic_record(kernel_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--adv-steps", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
