@@ -692,10 +692,11 @@ def barlow_loss(zq: Tensor, zk: Tensor, denom: float, lam: float, gathered_c=Non
     return on + lam * off, on, off
 
 
-def bt_pgd_attack(p: Params, cfg: dict, batch: dict, k: Tensor, return_steps: bool = False):
+def bt_pgd_attack(p: Params, cfg: dict, batch: dict, k: Tensor, return_steps: bool = False, running: Optional[Params] = None,
+                  training: bool = True):
     """PGDAttack_bartlowtwins.pgd_attack (attack/pgd_attack_vilt.py:198-236): like the MoCo PGD with the loss
-    (on_diag + adv_lr * off_diag) / K on c = q^T k / B (LOCAL batch, no all-reduce); the head is a deep copy in train mode,
-    so its running statistics are not those of the module."""
+    (on_diag + adv_lr * off_diag) / K on c = q^T k / B (LOCAL batch, no all-reduce); the head is a deep copy that keeps the
+    module's mode: batch statistics in training (its running estimates are a private copy), the running estimates in eval."""
     K, lr, eps = cfg["adv_steps_img"], cfg["adv_lr_img"], cfg["adv_max_norm_img"]
     img0 = batch["image"][0]
     delta = torch.zeros_like(img0)
@@ -704,7 +705,7 @@ def bt_pgd_attack(p: Params, cfg: dict, batch: dict, k: Tensor, return_steps: bo
         d = delta.detach().clone().requires_grad_(True)
         with torch.enable_grad():
             out = infer(p, cfg, batch["text_ids"], batch["text_masks"], img0 + d)
-            q = barlowtwins_head(p, out["cls_feats"], None, True)
+            q = barlowtwins_head(p, out["cls_feats"], None if training else running, training)
             loss = barlow_loss(q, k, float(q.shape[0]), cfg["adv_lr"])[0] / float(K)
             (g,) = torch.autograd.grad(loss, d)
         den = g.abs().flatten(1).max(dim=1).values.clamp_min(1e-8).view(-1, 1, 1, 1)
@@ -729,7 +730,7 @@ def compute_barlowtwins_contrastive(p: Params, cfg: dict, batch: dict, running: 
     with torch.no_grad():
         k = barlowtwins_head(p, infer(p, cfg, ids, masks, img)["cls_feats"], running, training)
     pd = {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in p.items()}
-    delta, steps = bt_pgd_attack(pd, cfg, batch, k, return_steps=True)
+    delta, steps = bt_pgd_attack(pd, cfg, batch, k, return_steps=True, running=running, training=training)
     prev = steps[-2] if len(steps) >= 2 else torch.zeros_like(delta)
     attacked = img + prev + delta                                          # same in-place quirk as the MoCo path
     out = infer(p, cfg, ids, masks, attacked)

@@ -351,8 +351,9 @@ class GreedyAttack_moco(GreedyAttack):
 
 class GreedyAttack_barlowtwins(GreedyAttack):
     """attack/greedy_attack_vilt.py:602-700: the same greedy attack maximising the Barlow-Twins loss
-    on_diag + adv_lr * off_diag of c = q^T k / B (local batch; q = barlowtwins_head(cls_feats) with BATCH statistics - the
-    reference attacks a deep copy of the head left in train mode, so a candidate batch is normalised by its own rows)."""
+    on_diag + adv_lr * off_diag of c = q^T k / B (local batch; q = barlowtwins_head(cls_feats): the reference attacks a deep
+    copy of the head, which keeps the module's mode - in training BATCH statistics, so a candidate batch is normalised by its
+    own rows; in validation the running estimates)."""
 
     def __init__(self, config, candidate_fn: Optional[Callable] = None, tokenizer=None, stopwords=None, synonyms=None):
         super().__init__(config, "barlowtwins", candidate_fn, tokenizer, stopwords, synonyms)
@@ -368,9 +369,10 @@ class GreedyAttack_barlowtwins(GreedyAttack):
         bb = eng.bt_bufs(pb.B, "txtatk")
         eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
         eng.heads_forward(pb, key=False, want_q=False)
-        eng.bt_forward(bb, pb.cls, training=True, track=False)
+        mode = bool(pl_module.training)           # the attacked head is a deep copy: it keeps the module's train / eval flag
+        eng.bt_forward(bb, pb.cls, training=mode, track=False)
         eng.bt_loss(bb, self._zk, float(pb.B), pl_module.adv_lr, 1.0, want_dz=True)
-        dcls = eng.bt_backward(bb, bb.dz, training=True, with_grads=False)
+        dcls = eng.bt_backward(bb, bb.dz, training=mode, with_grads=False)
         eng.heads_backward(pb, None, dcls, with_grads=False)
         eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=None, dtext=de)
         z = bb.z.clone()
@@ -387,7 +389,7 @@ class GreedyAttack_barlowtwins(GreedyAttack):
         eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=pc.patchesT, cls_tail=True)
         eng.heads_forward(pc, key=False, want_q=False)
         bc = eng.bt_bufs(n_real, "txtatk_cand")
-        zc = eng.bt_forward(bc, pc.cls[:n_real].contiguous(), training=True, track=False)
+        zc = eng.bt_forward(bc, pc.cls[:n_real].contiguous(), training=bool(pl_module.training), track=False)
         Z = ctx.clone()
         vals = torch.empty(n_real + 1, 2, device=Z.device)
         lam = pl_module.adv_lr

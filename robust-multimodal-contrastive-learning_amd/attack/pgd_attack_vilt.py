@@ -72,8 +72,9 @@ class PGDAttack_moco(PGDAttack):
 
 class PGDAttack_bartlowtwins(PGDAttack):
     """attack/pgd_attack_vilt.py:178-236 (the reference's spelling of the class name is kept): loss =
-    (on_diag + adv_lr * off_diag) / K on c = q^T k / B over the LOCAL batch, q = barlowtwins_head(cls_feats) with batch
-    statistics (the reference attacks a deep copy of the head in train mode, so the module's running estimates stay)."""
+    (on_diag + adv_lr * off_diag) / K on c = q^T k / B over the LOCAL batch, q = barlowtwins_head(cls_feats) of a deep copy of
+    the head: batch statistics in training (the module's running estimates stay untouched), the running estimates in
+    validation."""
 
     def __init__(self, config):
         super().__init__(config, "barlowtwins")
@@ -82,6 +83,7 @@ class PGDAttack_bartlowtwins(PGDAttack):
         eng = pl_module.engine
         K = self.adv_steps_img
         bb = eng.bt_bufs(pb.B, "pgd")
+        mode = bool(pl_module.training)           # deepcopy(pl_module.barlowtwins_head) keeps the train / eval flag (:189)
         pb.delta.zero_()
         pb.delta_prev.zero_()
         for step in range(K):
@@ -90,9 +92,9 @@ class PGDAttack_bartlowtwins(PGDAttack):
             op = eng.make_operand(pb, pb.delta)
             eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
             eng.heads_forward(pb, key=False, want_q=False)
-            eng.bt_forward(bb, pb.cls, training=True, track=False)
+            eng.bt_forward(bb, pb.cls, training=mode, track=False)
             eng.bt_loss(bb, zk, float(pb.B), pl_module.adv_lr, 1.0 / K, want_dz=True)
-            dcls = eng.bt_backward(bb, bb.dz, training=True, with_grads=False)
+            dcls = eng.bt_backward(bb, bb.dz, training=mode, with_grads=False)
             eng.heads_backward(pb, None, dcls, with_grads=False)
             eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=pb.gpatch)
             eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img)

@@ -316,3 +316,33 @@ def test_barlowtwins_text_view_backward_matches_oracle():
         if t.grad is not None and n in params:
             a, b = digest(params[n].grad)[1], digest(t.grad)[1]
             assert abs(a - b) <= 1e-3 * b + 1e-7, (n, a, b)
+
+
+def test_barlowtwins_validation_step_uses_running_statistics():
+    """validation (module.eval()): every BatchNorm of the head - in the clean projection, in the PGD's deep copy and in the
+    attacked view - normalises with the running estimates and leaves them untouched; loss and logs against the oracle."""
+    g = load("barlow_L2_B4_ragged.npz")
+    B, sw, sb, ragged, L_, K, sh, h1, h2, h3 = [int(x) for x in g["meta"]]
+    ocfg = O.default_config(num_layers=L_, num_negative=1024, per_gpu_batchsize=B, adv_steps_img=K, barlowtwins_dims=(h1, h2, h3),
+                            image_view=True, text_view=False)
+    m, p = make_bt_module(ocfg, sw, sh, "f32")
+    batch0 = O.synthetic_batch(ocfg, B, sb, ragged_text=bool(ragged))
+    gen = torch.Generator().manual_seed(8)
+    run = O.bt_running_init(ocfg)
+    for key in ("projector.1", "projector.4", "norm"):                   # non-trivial running estimates
+        run[f"barlowtwins_head.{key}.running_mean"].copy_(0.1 * torch.randn(run[f"barlowtwins_head.{key}.running_mean"].shape, generator=gen))
+        run[f"barlowtwins_head.{key}.running_var"].copy_(0.5 + torch.rand(run[f"barlowtwins_head.{key}.running_var"].shape, generator=gen))
+    m.load_state_dict({n: t.to(DEV) for n, t in run.items()}, strict=False)
+    before = {n: t.clone() for n, t in m.state_dict().items() if "running" in n or "num_batches" in n}
+    m.eval()
+    out = m.validation_step(dev_batch(batch0), 0)
+    torch.cuda.synchronize()
+    for n, t in before.items():
+        assert torch.equal(m.state_dict()[n], t), n
+    ref = O.compute_barlowtwins_contrastive(p, ocfg, batch0, {n: t.clone() for n, t in run.items()}, training=False)
+    lo = float(ref["barlowtwins_loss"])
+    assert abs(float(out["barlowtwins_loss"]) - lo) < 1e-3 * lo
+    assert abs(float(m.logged["barlowtwins/val/barlowtwins_loss_invariance_img"]) - float(ref["barlowtwins_loss_invariance_img"])) \
+        < 1e-3 * float(ref["barlowtwins_loss_invariance_img"])
+    delta = m.engine.patches_to_image(m.engine.bufs(B, "bt").delta, m.engine.bufs(B, "bt")).cpu()
+    np.testing.assert_allclose(delta[:, :, ::8, ::8].numpy(), ref["delta"][:, :, ::8, ::8].numpy(), atol=5e-5)
