@@ -314,13 +314,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
 // of a workgroup is 4x shorter (N = 768, K = 3072: 48 workgroups were looping 3072 deep), and the partial tiles meet in LDS
 // where the epilogue runs.  NT = 32 halves the re-reads of the A panel for very wide outputs (Barlow-Twins head, N = 8192).
 // Same operand trick as above: lane (c, g) holds k = 16 s + 4 g + j in component j of one float4, on both operands.
-template <bool B_KC, int NT>
-__global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs g) {
+template <bool B_KC, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g) {
   constexpr int CT = NT / 16;
-  __shared__ float red[4][64][NT + 1];
+  __shared__ float red[NW][64][NT + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, gq = lane >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * NT;
-  const int kq = g.K / 4, k_lo = wave * kq, k_hi = k_lo + kq;
+  const int kq = g.K / NW, k_lo = wave * kq, k_hi = k_lo + kq;            // kq % 16 == 0 (launcher)
   const float* Ap[4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) Ap[rt] = reinterpret_cast<const float*>(g.A) + (long)min(m0 + rt * 16 + c, g.M - 1) * g.lda + 4 * gq;
@@ -335,42 +335,46 @@ __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs g) {
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k = k_lo; k < k_hi; k += 32) {
-    float4 av[2][4];
-    float bv[2][CT][4];
+  // register double buffer over 16-k steps: the loads of step i + 1 are issued before the MFMAs of step i (the waves are few and
+  // the k-loop is a dependent chain of L2 / HBM round trips otherwise)
+  float4 av[2][4];
+  float bv[2][CT][4];
+  auto load = [&](int buf, int k) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (k + 16 * u < k_hi) {
+    for (int rt = 0; rt < 4; ++rt) av[buf][rt] = *reinterpret_cast<const float4*>(Ap[rt] + k);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) av[u][rt] = *reinterpret_cast<const float4*>(Ap[rt] + k + 16 * u);
+    for (int ct = 0; ct < CT; ++ct) {
+      if (B_KC) {
+        const float4 t = *reinterpret_cast<const float4*>(Bp[ct] + k);
+        bv[buf][ct][0] = t.x; bv[buf][ct][1] = t.y; bv[buf][ct][2] = t.z; bv[buf][ct][3] = t.w;
+      } else {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          if (B_KC) {
-            const float4 t = *reinterpret_cast<const float4*>(Bp[ct] + k + 16 * u);
-            bv[u][ct][0] = t.x; bv[u][ct][1] = t.y; bv[u][ct][2] = t.z; bv[u][ct][3] = t.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[u][ct][j] = Bp[ct][(long)(k + 16 * u + j) * g.ldb];
-          }
-        }
+        for (int j = 0; j < 4; ++j) bv[buf][ct][j] = Bp[ct][(long)(k + j) * g.ldb];
       }
     }
-    __builtin_amdgcn_sched_barrier(0);                     // every load of the iteration is in flight before the first MFMA waits
+  };
+  auto mac = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (k + 16 * u < k_hi) {
+    for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt].x, bv[u][ct][0], acc[rt][ct], 0, 0, 0);
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt].y, bv[u][ct][1], acc[rt][ct], 0, 0, 0);
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt].z, bv[u][ct][2], acc[rt][ct], 0, 0, 0);
-            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][rt].w, bv[u][ct][3], acc[rt][ct], 0, 0, 0);
-          }
+      for (int ct = 0; ct < CT; ++ct) {
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][rt].x, bv[buf][ct][0], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][rt].y, bv[buf][ct][1], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][rt].z, bv[buf][ct][2], acc[rt][ct], 0, 0, 0);
+        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][rt].w, bv[buf][ct][3], acc[rt][ct], 0, 0, 0);
       }
-    }
+  };
+  load(0, k_lo);
+  int k = k_lo;
+  for (; k + 32 <= k_hi; k += 32) {                     // two steps per trip so that the buffer index is a compile-time constant
+    load(1, k + 16);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(0);
+    if (k + 32 < k_hi) load(0, k + 32);
+    __builtin_amdgcn_sched_barrier(0);
+    mac(1);
   }
+  if (k < k_hi) mac(0);                                 // odd number of 16-k steps: the last one is already in buffer 0
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -379,10 +383,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_ksplit_kernel(GemmArgs g) {
       for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * gq + r][ct * 16 + c] = acc[rt][ct][r];
   __syncthreads();
   float* C = reinterpret_cast<float*>(g.C);
-  for (int i = threadIdx.x; i < 64 * NT; i += 256) {
+  for (int i = threadIdx.x; i < 64 * NT; i += 64 * NW) {
     const int rl = i / NT, cl = i % NT, row = m0 + rl, n = n0 + cl;
     if (row >= g.M || n >= g.N) continue;
-    float v = g.alpha * ((red[0][rl][cl] + red[1][rl][cl]) + (red[2][rl][cl] + red[3][rl][cl]));      // k order: wave 0..3
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += red[w][rl][cl];                                              // k order: wave 0 .. NW-1
+    v *= g.alpha;
     if (g.epi & EPI_BIAS) v += g.bias[n];
     const long ci = (long)row * g.ldc + n;
     if (g.epi & EPI_SAVE_PREACT) reinterpret_cast<float*>(g.C2)[ci] = v;
@@ -407,14 +414,20 @@ void rmcl_gemm_skinny_set_form(int v) { g_skinny_form = v; }
 
 int rmcl_launch_gemm_skinny(const GemmArgs& g, int b_kc, hipStream_t s) {
   if (g_skinny_form != 0 && g.K % 64 == 0 && g.K >= 128) {
+    // 8 waves (K split 8 ways) where the reduction is long and the grid small; 32-column tiles for very wide outputs
+    const bool w8 = g.K % 128 == 0 && g.K >= 2048 && g.N < 4096;
     if (g.N >= 4096) {
       dim3 grid(cdiv(g.N, 32), cdiv(g.M, 64));
-      if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 32>), grid, dim3(256), 0, s, g);
-      else RMCL_LAUNCH((gemm_skinny_ksplit_kernel<false, 32>), grid, dim3(256), 0, s, g);
+      if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 32, 4>), grid, dim3(256), 0, s, g);
+      else RMCL_LAUNCH((gemm_skinny_ksplit_kernel<false, 32, 4>), grid, dim3(256), 0, s, g);
+    } else if (w8) {
+      dim3 grid(cdiv(g.N, 16), cdiv(g.M, 64));
+      if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 16, 8>), grid, dim3(512), 0, s, g);
+      else RMCL_LAUNCH((gemm_skinny_ksplit_kernel<false, 16, 8>), grid, dim3(512), 0, s, g);
     } else {
       dim3 grid(cdiv(g.N, 16), cdiv(g.M, 64));
-      if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 16>), grid, dim3(256), 0, s, g);
-      else RMCL_LAUNCH((gemm_skinny_ksplit_kernel<false, 16>), grid, dim3(256), 0, s, g);
+      if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 16, 4>), grid, dim3(256), 0, s, g);
+      else RMCL_LAUNCH((gemm_skinny_ksplit_kernel<false, 16, 4>), grid, dim3(256), 0, s, g);
     }
     RMCL_CHECK_LAUNCH();
     return 0;
