@@ -202,9 +202,75 @@ static int launch_layout(const GemmArgs& g, int a_kc, int b_kc, dim3 grid, hipSt
 
 bool rmcl_gemm_skinny_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc);
 int rmcl_launch_gemm_skinny(const GemmArgs& g, int b_kc, hipStream_t s);
+static int g_skinny_form = -1;      // rmcl_tune_set key 6: 0 = the first forms only (row-split skinny kernel, LDS-staged TN kernel)
+
+// Outer-product-like fp32 GEMM: C[M, N] (+)= alpha * A^T B with A [K, M], B [K, N] and a SHORT reduction (K = the batch rows:
+// the weight gradients of the heads, of the encoder's cls-only tail and of the Barlow-Twins head, and its cross-correlation
+// matrix).  The 128x128x16 LDS-staged kernel above spends its time in four barrier-separated k-tiles for 64 k; here every
+// wave owns a 64 x 64 output tile and streams both operands straight from L2 (lane (c, g) of a 16x16x4 MFMA reads A[k0+g][m0+c]
+// and B[k0+g][n0+c]: 64-byte rows), 16 MFMAs per 8 loads, no LDS, no barrier.
+__global__ __launch_bounds__(256) void gemm_tn_shortk_kernel(GemmArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, gq = lane >> 4;
+  const int m0 = blockIdx.y * 128 + (wave >> 1) * 64, n0 = blockIdx.x * 128 + (wave & 1) * 64;
+  if (m0 >= g.M || n0 >= g.N) return;
+  const float* A = reinterpret_cast<const float*>(g.A);
+  const float* B = reinterpret_cast<const float*>(g.B);
+  int am[4], bn[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    am[t] = min(m0 + t * 16 + c, g.M - 1);
+    bn[t] = min(n0 + t * 16 + c, g.N - 1);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < g.K; k0 += 8) {                    // two 4-k steps per trip, all 16 loads in flight before the MFMAs
+    float a[2][4], b[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = min(k0 + 4 * u + gq, g.K - 1);
+      const bool live = k0 + 4 * u + gq < g.K;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        a[u][t] = live ? A[(long)k * g.lda + am[t]] : 0.f;
+        b[u][t] = live ? B[(long)k * g.ldb + bn[t]] : 0.f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+  }
+  float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + i * 16 + 4 * gq + r, col = n0 + j * 16 + c;
+        if (row < g.M && col < g.N) {
+          const long ci = (long)row * g.ldc + col;
+          float v = g.alpha * acc[i][j][r];
+          if (g.epi & EPI_ACCUM) v += C[ci];
+          C[ci] = v;
+        }
+      }
+}
 
 int rmcl_launch_gemm_exact(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc, hipStream_t s) {
   if (g.A && g.B && g.C && g.M > 0 && g.N > 0 && rmcl_gemm_skinny_supported(g, dt_in, dt_out, a_kc)) return rmcl_launch_gemm_skinny(g, b_kc, s);
+  if (g.A && g.B && g.C && g.M > 0 && g.N > 0 && !a_kc && !b_kc && dt_in == RMCL_F32 && dt_out == RMCL_F32 && g.K >= 1 && g.K <= 256 &&
+      g.splitk <= 1 && g.nb1 * g.nb2 == 1 && (g.epi & ~EPI_ACCUM) == 0 && g_skinny_form != 0) {
+    RMCL_LAUNCH(gemm_tn_shortk_kernel, dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(256), 0, s, g);
+    RMCL_CHECK_LAUNCH();
+    return 0;
+  }
   const int V = dt_in == RMCL_F32 ? 4 : 8;
   RMCL_REQUIRE(g.M > 0 && g.N > 0 && g.K >= 0, "gemm: bad dims");
   RMCL_REQUIRE(g.lda % V == 0 && g.ldb % V == 0, "gemm: lda/ldb must be a multiple of the 16-byte vector width");
@@ -409,7 +475,6 @@ bool rmcl_gemm_skinny_supported(const GemmArgs& g, int dt_in, int dt_out, int a_
          ((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0;
 }
 
-static int g_skinny_form = -1;      // rmcl_tune_set key 6: 0 = row-split waves (first form) only, else k-split where K % 64 == 0
 void rmcl_gemm_skinny_set_form(int v) { g_skinny_form = v; }
 
 int rmcl_launch_gemm_skinny(const GemmArgs& g, int b_kc, hipStream_t s) {

@@ -442,6 +442,13 @@ def test_gemm_skinny_epilogues_and_forms(form):
             u = rnd(M, N, seed=9)
             out = gemm(X, W.t().contiguous(), M, N, K, 1, 0, L.F32, L.F32, aux=u, ld_aux=N, epi=16)          # (X W^T) * gelu'(u), B as [K][N]
             assert rel_err(out, (X.double() @ W.double().t()) * dgelu(u.double())) < 2e-5, (M, N, K)
+        # short-K outer-product form C += alpha A^T B (weight gradients over B rows, the Barlow-Twins correlation)
+        for K, M, N in ((64, 768, 3072), (4, 256, 384), (37, 132, 200), (64, 1000, 520)):
+            A, Bm, base = rnd(K, M, seed=11), rnd(K, N, seed=12), rnd(M, N, seed=13)
+            out = gemm(A, Bm, M, N, K, 0, 0, L.F32, L.F32, lda=M, ldb=N, epi=64, alpha=0.5, C_init=base)
+            assert rel_err(out, 0.5 * A.double().t() @ Bm.double() + base.double()) < 2e-5, (K, M, N)
+            out = gemm(A, Bm, M, N, K, 0, 0, L.F32, L.F32, lda=M, ldb=N)
+            assert rel_err(out, A.double().t() @ Bm.double()) < 2e-5, (K, M, N)
     finally:
         check(lib.rmcl_tune_set(6, -1))
 
