@@ -107,13 +107,13 @@ extern int g_st_reserve_cus;
 extern bool g_attn_fused_bwd;
 extern bool g_dw_grouped;
 extern int g_attn_fwd_waves;
-extern bool g_infonce_fold;
+extern int g_infonce_fold;
 int rmcl_tune_set(int key, int value) {
   if (key == 6) { rmcl_gemm_skinny_set_form(value); return 0; }                                   // 0: skinny GEMMs in the row-split form only
   if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }
   if (key == 1) { g_st_reserve_cus = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }   // CUs left free by the activation GEMMs
   if (key == 2) { g_attn_fused_bwd = value != 0; return 0; }                                    // 0: two-kernel attention backward
-  if (key == 5) { g_infonce_fold = value != 0; return 0; }                                        // 0: one-slice-per-workgroup InfoNCE
+  if (key == 5) { g_infonce_fold = value != 0; return 0; }                                        // 0: one-slice-per-workgroup InfoNCE + per-row combine
   if (key == 4) { g_attn_fwd_waves = value; return 0; }                                          // waves per workgroup of the attention forward
   if (key == 3) { g_dw_grouped = value != 0; return 0; }                                        // 0: per-GEMM weight gradients (split-K slabs)
   rmcl_set_error("tune_set: unknown key");

@@ -155,14 +155,58 @@ __global__ __launch_bounds__(256) void infonce_partial_kernel(const float* __res
 #define NS2 4        // sub-slices per workgroup
 #define ILD2 65
 
+
+// MFMA loops of the folded forms.  hipcc serialises "ds_read -> s_waitcnt lgkmcnt(0) -> MFMA" when the LDS operand of each MFMA
+// is read inside the loop (one LDS round trip per MFMA pair, the matrix cores idle half of the time), so the operands are read
+// in batches into registers one batch AHEAD of the MFMAs that use them, with scheduling barriers pinning the two blocks.
+// (Measured: this alone does not move the kernel - 44.6 -> 44.2 us - the MFMAs are not what bounds it; an eight-wave
+// ping-pong form of the same pass, two groups one barrier apart, measured 46.6 - 50 us and was dropped.  What did cost was the
+// query block: indexed by a rolled loop it lived in SCRATCH memory, every MFMA fetching its A operand from there: 51.3 -> 44.6 us.)
+// logits: a0 += q[:, 2i..2i+1] x Qs[2i..2i+1, :] for i < PD/2 (areg[i] = this lane's q value of k-step i)
+#define NCE_LOGITS_MFMA(a0, areg, bp)                                                                               \
+  {                                                                                                                 \
+    float bv[2][8];                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) bv[0][j] = (bp)[2 * j * ILD2];                                    \
+    _Pragma("unroll") for (int ic = 0; ic < PD / 2; ic += 8) {                                                      \
+      if (ic + 8 < PD / 2) {                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) bv[((ic >> 3) + 1) & 1][j] = (bp)[2 * (ic + 8 + j) * ILD2];   \
+      }                                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                                 \
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32((areg)[ic + j], bv[(ic >> 3) & 1][j], a0, 0, 0, 0);               \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }                                                                                                               \
+  }
+// dq: d0 / d1 += (fsr * P[:, k..k+1]) x Qs^T[k..k+1, 0..31 / 32..63] for k < SL2
+#define NCE_DQ_MFMA(d0, d1, ap, bp0, bp1, fsr)                                                                      \
+  {                                                                                                                 \
+    float av[2][4], b0v[2][4], b1v[2][4];                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) { av[0][j] = (ap)[2 * j]; b0v[0][j] = (bp0)[2 * j]; b1v[0][j] = (bp1)[2 * j]; } \
+    _Pragma("unroll") for (int kc = 0; kc < SL2 / 2; kc += 4) {                                                     \
+      const int cur = (kc >> 2) & 1, nxt = cur ^ 1;                                                                 \
+      if (kc + 4 < SL2 / 2) {                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+          av[nxt][j] = (ap)[2 * (kc + 4 + j)]; b0v[nxt][j] = (bp0)[2 * (kc + 4 + j)]; b1v[nxt][j] = (bp1)[2 * (kc + 4 + j)]; \
+        }                                                                                                           \
+      }                                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+        const float a = av[cur][j] * (fsr);                                                                         \
+        d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0v[cur][j], d0, 0, 0, 0);                                     \
+        d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1v[cur][j], d1, 0, 0, 0);                                     \
+      }                                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }                                                                                                               \
+  }
+
 __global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __restrict__ q, const float* __restrict__ queue, long Kq,
                                                                int B, float invT, float* __restrict__ part, float* __restrict__ dq_part,
                                                                int Bpad) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   auto Qbuf = [&](int i) { return sm + i * (PD * ILD2); };   // two [PD][ILD2] buffers: Qs[c][j]
   float* Ps = sm + 2 * PD * ILD2;        // [RT][ILD2]
-  float* c2 = Ps + RT * ILD2;            // [SL2]
-  float* q2 = c2 + SL2;                  // [RT]
+  float* c2p = Ps + RT * ILD2;           // [4][SL2] squared column norms: the partial of each wave's 32 rows (written by deposit)
+  float* q2 = c2p + 4 * SL2;             // [RT]
   float* fo = q2 + RT;                   // [RT] rescale of the running sums for this sub-slice
   float* fs = fo + RT;                   // [RT] weight of this sub-slice
 
@@ -180,6 +224,10 @@ __global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __re
       if (r0 + r < B) x = *reinterpret_cast<const float4*>(q + (long)(r0 + r) * PD + cq);
       float* d = qs + r * 129 + cq;
       d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+      float sq = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);   // squared row norm: the 32 lanes of a half-wave hold row r
+#pragma unroll
+      for (int o = 1; o <= 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+      if ((t & 31) == 0) q2[r] = sq;
     }
   }
   float4 pre[8];                                               // one sub-slice in flight: 32 floats per thread
@@ -190,12 +238,25 @@ __global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __re
       pre[i] = *reinterpret_cast<const float4*>(queue + (long)c * Kq + j00 + (long)s * SL2 + jq);
     }
   };
+  // registers -> LDS image; the squared column norms of the sub-slice (queue-distance metrics) are summed on the way: a thread
+  // holds 8 rows x 4 columns, the 4 lanes with equal lane % 16 cover this wave's 32 rows (a 64-thread serial walk down the
+  // 128 rows of the image cost 3.4 us per sub-slice with the other three waves waiting at the barrier)
   auto deposit = [&](float* Qs) {
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int v = t + 256 * i, c = v >> 4, jq = (v & 15) * 4;
       float* d = Qs + c * ILD2 + jq;
       d[0] = pre[i].x; d[1] = pre[i].y; d[2] = pre[i].z; d[3] = pre[i].w;
+      cs0 += pre[i].x * pre[i].x; cs1 += pre[i].y * pre[i].y; cs2 += pre[i].z * pre[i].z; cs3 += pre[i].w * pre[i].w;
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      cs0 += __shfl_xor(cs0, o, 64); cs1 += __shfl_xor(cs1, o, 64); cs2 += __shfl_xor(cs2, o, 64); cs3 += __shfl_xor(cs3, o, 64);
+    }
+    if (lane < 16) {
+      float* o = c2p + wave * SL2 + lane * 4;
+      o[0] = cs0; o[1] = cs1; o[2] = cs2; o[3] = cs3;
     }
   };
   fetch(0);
@@ -205,11 +266,6 @@ __global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __re
     const float* ap = Qbuf(1) + (32 * wm + (lane & 31)) * 129 + (lane >> 5);
 #pragma unroll
     for (int i = 0; i < PD / 2; ++i) areg[i] = ap[2 * i];
-  }
-  if (t < RT) {
-    float s = 0.f;
-    for (int c = 0; c < PD; ++c) { const float v = Qbuf(1)[t * 129 + c]; s += v * v; }
-    q2[t] = s;
   }
   deposit(Qbuf(0));
   __syncthreads();                                             // (Qb[1] is free from here: q lives in registers)
@@ -226,18 +282,12 @@ __global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __re
   for (int s = 0; s < NS2; ++s) {
     float* Qs = Qbuf(s & 1);
     if (s + 1 < NS2) fetch(s + 1);
-    if (t < SL2) {
-      float a = 0.f;
-      for (int c = 0; c < PD; ++c) { const float v = Qs[c * ILD2 + t]; a += v * v; }
-      c2[t] = a;
-    }
     {  // step 1: S[64 x 64] = q @ Qs: one 32x32 tile per wave
       f32x16 a0;
 #pragma unroll
       for (int r = 0; r < 16; ++r) a0[r] = 0.f;
       const float* bp = Qs + (lane >> 5) * ILD2 + 32 * wn + (lane & 31);
-#pragma unroll 8
-      for (int i = 0; i < PD / 2; ++i) a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i], bp[2 * i * ILD2], a0, 0, 0, 0);
+      NCE_LOGITS_MFMA(a0, areg, bp);                               // (static areg indices: a rolled loop puts areg in scratch memory)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -252,7 +302,7 @@ __global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __re
         const int col = 4 * i + sub;
         const float dot = Ps[row * ILD2 + col];
         if (dot > sbest) { sbest = dot; sbi = col; }
-        const float cc = c2[col];
+        const float cc = (c2p[col] + c2p[SL2 + col]) + (c2p[2 * SL2 + col] + c2p[3 * SL2 + col]);
         sd += sqrtf(fmaxf(qq + cc - 2.f * dot, 0.f));
         sc += dot / fmaxf(sqrtf(qq) * sqrtf(cc), 1e-6f);
         so += dot;
@@ -291,12 +341,7 @@ __global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __re
       const float* ap = Ps + (32 * wm + (lane & 31)) * ILD2 + (lane >> 5);
       const float* bp0 = Qs + (64 * wn + (lane & 31)) * ILD2 + (lane >> 5);
       const float* bp1 = bp0 + 32 * ILD2;
-#pragma unroll 8
-      for (int k = 0; k < SL2; k += 2) {
-        const float a = ap[k] * fsr;
-        d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp0[k], d0, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp1[k], d1, 0, 0, 0);
-      }
+      NCE_DQ_MFMA(d0, d1, ap, bp0, bp1, fsr);
     }
     if (s + 1 < NS2) deposit(Qbuf((s + 1) & 1));                 // the other buffer: its last readers passed the barrier above one
     __syncthreads();                                           // sub-slice ago; also fences Ps / fo / fs for the next round
@@ -412,7 +457,96 @@ __global__ __launch_bounds__(CMB_G * PD) void infonce_combine_kernel(const float
   (void)sh;
 }
 
-bool g_infonce_fold = true;          // rmcl_tune_set key 5: 0 selects the one-slice-per-workgroup kernel
+// The same merge with the dq columns of a row split over PD / CW workgroups (B x 4 instead of B workgroups: with 64 rows the
+// one-workgroup-per-row form kept 64 of 256 CUs busy reading the 8.4 MB of dq partials).  Every workgroup repeats the scalar
+// bookkeeping of its row (256 x 8 floats); threads 0..127 play the scalar role, all 256 threads = 8 slice groups x CW columns
+// the dq role.  rows_out / loss_sum are written by column block 0.
+#define CW 32
+__global__ __launch_bounds__(CMB_G * CW) void infonce_combine2_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                      const float* __restrict__ part, const float* __restrict__ dq_part,
+                                                                      int nslice, int B, int Bpad, long Kq, float invT, float gscale,
+                                                                      float* __restrict__ dq, float* __restrict__ rows_out,
+                                                                      float* __restrict__ loss_sum) {
+  __shared__ float red[4][2];
+  __shared__ float r2[2][8];
+  __shared__ float accs[CMB_G][CW];
+  __shared__ float zs[CMB_G];
+  const int i = blockIdx.x, cb = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const bool scalar = t < PD;                                  // waves 0 and 1
+  const int c = t & (PD - 1);
+  const float qc = q[(long)i * PD + c], kc = k[(long)i * PD + c];
+  {
+    const float s_qk = wave_sum(qc * kc), s_qq = wave_sum(qc * qc), s_kk = wave_sum(kc * kc), s_d = wave_sum((qc - kc) * (qc - kc));
+    if (scalar && lane == 0) { red[0][wave] = s_qk; red[1][wave] = s_qq; red[2][wave] = s_kk; red[3][wave] = s_d; }
+  }
+  __syncthreads();
+  const float dotp = red[0][0] + red[0][1], qq = red[1][0] + red[1][1], kk = red[2][0] + red[2][1], dd = red[3][0] + red[3][1];
+  const float lpos = dotp * invT;
+  float M = lpos, best = -INFINITY;
+  int bidx = 0;
+  float sd = 0.f, sc = 0.f, so = 0.f;
+  for (int s = scalar ? c : nslice; s < nslice; s += PD) {
+    const float* o = part + ((long)s * Bpad + i) * NPART;
+    M = fmaxf(M, o[0]);
+    const int oi = __float_as_int(o[3]);
+    if (o[2] > best || (o[2] == best && oi < bidx)) { best = o[2]; bidx = oi; }
+    sd += o[4]; sc += o[5]; so += o[6];
+  }
+  M = wave_max(M);
+  sd = wave_sum(sd); sc = wave_sum(sc); so = wave_sum(so);
+  float wb = best; int wi = bidx;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(wb, o, 64); const int oi = __shfl_xor(wi, o, 64);
+    if (ob > wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
+  }
+  if (scalar && lane == 0) { r2[wave][0] = M; r2[wave][1] = sd; r2[wave][2] = sc; r2[wave][3] = so; r2[wave][4] = wb; r2[wave][5] = __int_as_float(wi); }
+  __syncthreads();
+  M = fmaxf(r2[0][0], r2[1][0]);
+  sd = r2[0][1] + r2[1][1]; sc = r2[0][2] + r2[1][2]; so = r2[0][3] + r2[1][3];
+  {
+    const float b0 = r2[0][4], b1 = r2[1][4];
+    const int i0 = __float_as_int(r2[0][5]), i1 = __float_as_int(r2[1][5]);
+    if (b1 > b0 || (b1 == b0 && i1 < i0)) { best = b1; bidx = i1; } else { best = b0; bidx = i0; }
+  }
+  // Z and dq: slice group grp, column cb * CW + cc
+  const int grp = t / CW, cc = t - grp * CW, col = cb * CW + cc;
+  float Z = 0.f, acc = 0.f;
+#pragma unroll 8
+  for (int s = grp; s < nslice; s += CMB_G) {
+    const float* o = part + ((long)s * Bpad + i) * NPART;
+    const float f = __expf(o[0] - M);
+    Z += o[1] * f;
+    acc += f * dq_part[((long)s * Bpad + i) * PD + col];
+  }
+  accs[grp][cc] = acc;
+  if (cc == 0) zs[grp] = Z;
+  __syncthreads();
+  if (grp != 0) return;
+  Z = 0.f; acc = 0.f;
+#pragma unroll
+  for (int gi = 0; gi < CMB_G; ++gi) { Z += zs[gi]; acc += accs[gi][cc]; }
+  const float epos = __expf(lpos - M);
+  Z += epos;
+  const float lse = logf(Z) + M;
+  if (dq) dq[(long)i * PD + col] = gscale * invT * ((epos / Z - 1.0f) * k[(long)i * PD + col] + acc / Z);
+  if (cb == 0 && cc == 0) {
+    float* o = rows_out + (long)i * 10;
+    const float loss = lse - lpos;
+    o[0] = loss;
+    o[1] = (dotp >= best) ? 0.f : (float)(bidx + 1);
+    o[2] = lpos;
+    o[3] = sqrtf(dd);
+    o[4] = dotp / fmaxf(sqrtf(qq) * sqrtf(kk), 1e-6f);
+    o[5] = dotp;
+    o[6] = sd / (float)Kq; o[7] = sc / (float)Kq; o[8] = so / (float)Kq;
+    o[9] = lse;
+    if (loss_sum) atomicAdd(loss_sum, loss / (float)B);
+  }
+}
+
+int g_infonce_fold = 1;              // rmcl_tune_set key 5: 0 = one slice per workgroup + one-workgroup-per-row combine (round-1 form)
+
 
 long rmcl_infonce_workspace_bytes(int B, long Kq) {
   const long Bpad = (B + RT - 1) / RT * RT, ns = Kq / SLICE;
@@ -434,9 +568,9 @@ int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int 
     attr_set = true;
   }
   int nparts = ns;
-  if (Kq % (SL2 * NS2) == 0 && g_infonce_fold) {               // 256 columns per workgroup, four folded 64-column sub-slices
+  if (Kq % (SL2 * NS2) == 0 && g_infonce_fold >= 1) {           // 256 columns per workgroup, four folded 64-column sub-slices
     nparts = (int)(Kq / (SL2 * NS2));
-    const size_t lds2 = (2 * PD * ILD2 + RT * ILD2 + SL2 + 3 * RT) * sizeof(float);
+    const size_t lds2 = (2 * PD * ILD2 + RT * ILD2 + 4 * SL2 + 3 * RT) * sizeof(float);
     static bool attr2 = false;
     if (!attr2) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
@@ -447,8 +581,12 @@ int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int 
     RMCL_LAUNCH(infonce_partial_kernel, dim3(ns, Bpad / RT), dim3(256), lds, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
   }
   RMCL_CHECK_LAUNCH();
-  RMCL_LAUNCH(infonce_combine_kernel, dim3(B), dim3(CMB_G * PD), 0, s, q, k, part, dq_part, nparts, B, Bpad, Kq, 1.0f / T, gscale, dq,
-                     rows_out, loss_sum);
+  if (g_infonce_fold >= 1)
+    RMCL_LAUNCH(infonce_combine2_kernel, dim3(B, PD / CW), dim3(CMB_G * CW), 0, s, q, k, part, dq_part, nparts, B, Bpad, Kq, 1.0f / T, gscale, dq,
+                rows_out, loss_sum);
+  else
+    RMCL_LAUNCH(infonce_combine_kernel, dim3(B), dim3(CMB_G * PD), 0, s, q, k, part, dq_part, nparts, B, Bpad, Kq, 1.0f / T, gscale, dq,
+                rows_out, loss_sum);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

@@ -163,10 +163,12 @@ def test_attention_bwd_one_kernel_full_batch():
 
 
 # --------------------------------------------------------------------------------------- InfoNCE
+@pytest.mark.parametrize("form", [1, 0])                       # rmcl_tune_set key 5: folded sub-slices + column-split combine (default) / one slice
 @pytest.mark.parametrize("B,Kq", [(4, 1024), (64, 65536), (70, 4096)])
-def test_infonce_matches_oracle(B, Kq):
+def test_infonce_matches_oracle(B, Kq, form):
     from oracle import rmcl_oracle as O
     T = 0.07
+    check(lib.rmcl_tune_set(5, form))
     q = torch.nn.functional.normalize(rnd(B, 128, seed=1), dim=1)
     k = torch.nn.functional.normalize(rnd(B, 128, seed=2) + 2 * q, dim=1)
     queue = rnd(128, Kq, seed=3)
@@ -179,6 +181,7 @@ def test_infonce_matches_oracle(B, Kq):
     dq, rows, lsum = torch.empty(B, 128, device=DEV), torch.empty(B, 10, device=DEV), torch.zeros(1, device=DEV)
     check(lib.rmcl_infonce_f32(P(q), P(k), P(queue), B, 128, I64(Kq), F(T), F(1.0 / (3.0 * B)), P(dq), P(rows), P(lsum), P(ws),
                                stream()))
+    check(lib.rmcl_tune_set(5, 1))
     assert abs(float(lsum) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
     assert rel_err(dq.cpu(), qd.grad) < 1e-4
     assert torch.equal(rows[:, 1].cpu().long(), logits.argmax(-1))

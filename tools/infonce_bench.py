@@ -1,4 +1,4 @@
-"""Times the fused InfoNCE (forward + dq + metrics) at the step's shape (B=64, 128-d, queue 65536), both partial kernels."""
+"""Times the fused InfoNCE (forward + dq + metrics) at the step's shape (B=64, 128-d, queue 65536), both forms (rmcl_tune_set key 5)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -33,4 +33,5 @@ for fold in (0, 1):
     run()
     res[fold] = (dq.clone(), rows.clone(), float(loss))
     print(f"fold={fold}: {t():.1f} us per call (partial + combine); queue 33.5 MB -> {33.5e6 / (t() * 1e-6) / 1e12:.2f} TB/s effective")
-print("max |dq diff|", float((res[0][0] - res[1][0]).abs().max()), " rows diff", float((res[0][1] - res[1][1]).abs().max()), res[0][2], res[1][2])
+for f in (1,):
+    print(f"form {f} vs 0: max |dq diff|", float((res[0][0] - res[f][0]).abs().max()), " rows diff", float((res[0][1] - res[f][1]).abs().max()), res[0][2], res[f][2])
