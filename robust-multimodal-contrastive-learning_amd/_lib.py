@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librmcl_hip.so")
+LIB_PATH = os.environ.get("RMCL_LIB") or os.path.join(_HERE, "lib", "librmcl_hip.so")   # (RMCL_LIB: A/B runs of two builds in one call)
 
 F32, BF16 = 0, 1
 MODE_INFER, MODE_DATA, MODE_FULL = 0, 1, 2

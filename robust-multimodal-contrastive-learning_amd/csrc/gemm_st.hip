@@ -33,6 +33,23 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define ST_STAGE (2 * ST_OP_BYTES)          // 48 KiB
 #define ST_LDS (3 * ST_STAGE)               // 144 KiB
 
+
+// In-kernel phase trace (developer builds only: hipcc ... -DST_TRACE): lane 0 of waves 0 and 4 of workgroup ST_TRACE_WG stamps
+// the 100 MHz wall clock at phase boundaries; tools/st_trace.py reads the stamps through rmcl_debug_st_trace.
+#ifdef ST_TRACE
+#ifndef ST_TRACE_WG
+#define ST_TRACE_WG 100
+#endif
+__device__ long long g_st_trace[2][32];
+#define ST_STAMP(i)                                                                                              \
+  if (blockIdx.x == ST_TRACE_WG && (threadIdx.x & 255) == 0) g_st_trace[threadIdx.x >> 8][i] = wall_clock64()
+extern "C" int rmcl_debug_st_trace(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st_trace), sizeof(long long) * 64);
+}
+#else
+#define ST_STAMP(i)
+#endif
+
 template <int N>
 __device__ __forceinline__ void st_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -299,6 +316,25 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
   asm volatile("" : "+v"(lane));
   const int nb = T.n0 + wn * 48 + 4 * (lane >> 4);
   const int mb = T.m0 + wm * 96 + (lane & 15);
+  // aux operand (fp32 residual / bf16 pre-activation) of chunk ch + 1 is fetched while chunk ch is converted and stored: the
+  // residual stream is HBM-cold here, and a load -> wait -> compute sequence per chunk put its latency on every chunk
+  float4 resb[2][AUX == ST_AUX_RES ? RI : 1][3];
+  uint2 preb[2][AUX == ST_AUX_DGELU ? RI : 1][3];
+  auto aux_fetch = [&](int ch, int buf) {
+#pragma unroll
+    for (int il = 0; il < RI; ++il) {
+      const long mr = min(mb + (ch * RI + il) * 16, g.M - 1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (AUX == ST_AUX_RES) resb[buf][il][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+        if (AUX == ST_AUX_DGELU) preb[buf][il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
+      }
+    }
+  };
+  // chunk 0's fetch is issued HERE, ahead of the epilogue's first barrier: group 1 runs one barrier behind group 0, and behind that
+  // barrier its fetch went out only when group 0 had already waited for its own (HBM-cold residual: ~5 us) - the two groups paid
+  // the latency one after the other (tools/st_trace.py: fc2 epilogue 20 us)
+  if constexpr (AUX != ST_AUX_NONE) aux_fetch(0, 0);
   float4 bias[3], lns[LNF == 1 ? 3 : 1];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -333,28 +369,14 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
+  ST_STAMP(3);
   __builtin_amdgcn_s_barrier();                              // the other group's last reads of this stage have retired
+  ST_STAMP(4);
   float2 rs[LNF == 1 ? 6 : 1];
   if constexpr (LNF == 1) {                                    // mean / rstd of this lane's six rows, read once
 #pragma unroll
     for (int i = 0; i < 6; ++i) rs[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
   }
-  // aux operand (fp32 residual / bf16 pre-activation) of chunk ch + 1 is fetched while chunk ch is converted and stored: the
-  // residual stream is HBM-cold here, and a load -> wait -> compute sequence per chunk put its latency on every chunk
-  float4 resb[2][AUX == ST_AUX_RES ? RI : 1][3];
-  uint2 preb[2][AUX == ST_AUX_DGELU ? RI : 1][3];
-  auto aux_fetch = [&](int ch, int buf) {
-#pragma unroll
-    for (int il = 0; il < RI; ++il) {
-      const long mr = min(mb + (ch * RI + il) * 16, g.M - 1);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        if (AUX == ST_AUX_RES) resb[buf][il][j] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + mr * g.ld_aux + nb + j * 16);
-        if (AUX == ST_AUX_DGELU) preb[buf][il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
-      }
-    }
-  };
-  if constexpr (AUX != ST_AUX_NONE) aux_fetch(0, 0);
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     if constexpr (AUX != ST_AUX_NONE) { if (ch + 1 < NCH) aux_fetch(ch + 1, (ch + 1) & 1); }
@@ -421,7 +443,9 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
           *reinterpret_cast<float2*>(g.ln_part + ((long)m * g.ln_nparts + (T.n0 / ST_T) * 4 + wn) * 2) = make_float2(ps1, ps2);
       }
     }
+    ST_STAMP(5 + 4 * ch);
     __builtin_amdgcn_s_barrier();                            // the group's image of this chunk is complete
+    ST_STAMP(6 + 4 * ch);
     int tg = (wave & 3) * 64 + lane;                         // lane id inside the group
     asm volatile("" : "+v"(tg));                             // (keeps the read-back addresses from being hoisted out of the tile loop as live registers)
 #pragma unroll
@@ -452,7 +476,9 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
         }
       }
     }
+    ST_STAMP(7 + 4 * ch);
     __builtin_amdgcn_s_barrier();                            // image consumed: the next chunk may overwrite it
+    ST_STAMP(8 + 4 * ch);
   }
   __builtin_amdgcn_s_barrier();                              // the OTHER group (one barrier behind) has consumed its last image too:
 }                                                            // the next tile's LDS-DMA may now target this stage
@@ -492,6 +518,7 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
     c.boffj[j] = k * 384 + (((c8 >> 1) ^ (st_gk(k) << 1)) * 16) + (c8 & 1) * 8;
   }
 
+  ST_STAMP(0);
   int id = st_tile_id(bidx, 0, G, ntiles);
   if (id < 0) return;                                        // (whole workgroup: id is uniform)
   STTile cur, nxt;
@@ -510,6 +537,7 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
   if (wm == 1) __builtin_amdgcn_s_barrier();                 // skew: group 1 runs one barrier behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
+  ST_STAMP(1);
   int sc = 0, sn = 2;                                        // LDS stage of the current k-tile / of the k-tile two ahead
   for (int r = 0;; ++r) {
     const int nid = st_tile_id(bidx, r + 1, G, ntiles);
@@ -539,6 +567,7 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
       sc = sc == 2 ? 0 : sc + 1;
       st_tile<2, A_KC, B_KC, PH>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
     }
+    ST_STAMP(2);
     // the stage the tile's last k-tile was read from (sc has already moved on when the stream continues): 24 KiB per group
     const int s_free = nid >= 0 ? (sc == 0 ? 2 : sc - 1) : sc;
     st_epilogue_lds<AUX, TO, DROP, LNF>(acc, g, cur, wm, wn, lane, wave, smem + s_free * ST_STAGE + wm * (ST_STAGE / 2),
@@ -546,7 +575,12 @@ __global__ __launch_bounds__(512) void gemm_st_kernel(GemmArgs g, int tiles_m, i
     if (nid < 0) break;
     cur = nxt;
   }
+  ST_STAMP(20);
   if (wm == 0) __builtin_amdgcn_s_barrier();
+#ifdef ST_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ST_STAMP(21);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,51 @@
+"""Phase timeline of ONE workgroup of gemm_st_kernel (developer build: csrc/build.sh with RMCL_EXTRA_FLAGS=-DST_TRACE).
+Usage: python tools/st_trace.py {proj|fc2|qkv|projdx}   - launches the step's form of that GEMM 5x and prints the last stamps."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tests.gpu_util import L, lib, check, P, I64, F, stream, DEV
+
+which = sys.argv[1] if len(sys.argv) > 1 else "proj"
+M, D = 11840, 768
+g = torch.Generator().manual_seed(0)
+if which in ("proj", "fc2"):
+    K = 768 if which == "proj" else 3072
+    A = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    W = (torch.randn(D, K, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    b, res = torch.zeros(D, device=DEV), torch.randn(M, D, generator=g).to(DEV)
+    out, outb = torch.empty(M, D, device=DEV), torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    prt = torch.empty(M, 16, 2, device=DEV)
+    run = lambda: check(lib.rmcl_linear_rowstat(P(A), P(W), P(b), P(res), P(out), P(outb), P(prt), M, D, K, stream()))
+elif which == "qkv":
+    N = 2304
+    xb = torch.randn(M, D, generator=g).to(DEV).to(torch.bfloat16)
+    part = torch.rand(M, 16, 2, generator=g).to(DEV) + 1.0
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    W = (torch.randn(N, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    s_, c_ = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    run = lambda: check(lib.rmcl_linear_lnfold(P(xb), P(W), P(s_), P(c_), P(part), 16, P(out), None, M, N, D, 0, F(1e-6), P(mean), P(rstd), stream()))
+else:                                     # plain bf16-out NT GEMM, K = 768 (proj-dX)
+    A = torch.randn(M, D, generator=g).to(DEV).to(torch.bfloat16)
+    W = (torch.randn(D, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    out = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
+    run = lambda: check(lib.rmcl_gemm(P(A), P(W), P(out), None, None, None, M, D, D, I64(D), I64(D), D, 0, F(1.0), 0, 1, L.BF16, L.BF16, 1, 1, 0, stream()))
+big = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+for _ in range(5):
+    big.zero_()                            # evict the operands from L2 / MALL: the step's GEMMs start cold
+    run()
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 64)()
+assert lib.rmcl_debug_st_trace(buf) == 0
+names = {0: "start", 1: "prologue landed", 2: "k-loop done", 3: "epi: vectors/rowstat", 4: "epi: barrier", 20: "epilogue done", 21: "stores drained"}
+for ch in range(3):
+    names.update({5 + 4 * ch: f"chunk{ch}: math+LDS write", 6 + 4 * ch: f"chunk{ch}: barrier", 7 + 4 * ch: f"chunk{ch}: read-back+stores issued",
+                  8 + 4 * ch: f"chunk{ch}: barrier"})
+for w in range(2):
+    t = [buf[w * 32 + i] for i in range(32)]
+    print(f"--- wave {4 * w} (group {w}) of workgroup 100, us from kernel start of that wave")
+    prev = t[0]
+    for i in sorted(names):
+        if t[i] >= t[0] and t[i] > 0:
+            print(f"  {names[i]:38s} {(t[i] - t[0]) / 100:7.2f}  (+{(t[i] - prev) / 100:.2f})")
+            prev = t[i]
