@@ -253,6 +253,15 @@ int rmcl_infonce_f32(const float* q, const float* k, const float* queue, int B, 
 /* PGD ascent step in patch layout (attack/pgd_attack_vilt.py:162-173).  amax_scratch: B uint32.  */
 int rmcl_pgd_step(const void* grad, int dtype, float* delta, uint32_t* amax_scratch, int B, int64_t per_sample,
                   float lr, float eps, void* stream);
+/* The same step fused with the loop's next operand (attack/pgd_attack_vilt.py:144,162-173): delta is updated in place and, when
+ * `operand` is given, operand = cast(base + delta_new) - the next encoder forward's patch rows - in the same pass.
+ * RMCL_PGD_DELTA_ZERO: the incoming delta is the all-zero delta_0 and is not read (the buffer need not be cleared).
+ * RMCL_PGD_SUM_PREV: operand = cast((base + delta_old) + delta_new): the attacked view img + delta_{K-1} + delta_K that
+ * objectives.py:176 builds on the batch image pgd_attack left behind.  base: the clean patch rows (fp32).                 */
+#define RMCL_PGD_DELTA_ZERO 1
+#define RMCL_PGD_SUM_PREV 2
+int rmcl_pgd_step_fused(const void* grad, int dtype, float* delta, uint32_t* amax_scratch, int B, int64_t per_sample, float lr,
+                        float eps, const float* base, void* operand, int operand_dtype, int flags, void* stream);
 /* sum over (row, pixel) of the channel-wise L2 norm of delta (objectives.py:184); out += sum     */
 int rmcl_delta_channel_norm(const float* delta, float* out, int64_t rows, int C, int pp, void* stream);
 

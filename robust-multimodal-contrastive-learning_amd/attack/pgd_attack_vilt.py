@@ -26,9 +26,13 @@ class PGDAttack_moco(PGDAttack):
     def __init__(self, config):
         super().__init__(config, "moco")
 
-    def attack_patches(self, pl_module, pb, k, before_first_loss=None, clean_out=None):
-        """K-step attack in patch layout.  Leaves delta_K in ``pb.delta`` and delta_{K-1} in
-        ``pb.delta_prev`` (needed for the reference's attacked view, see compute_pgd).
+    def attack_patches(self, pl_module, pb, k, before_first_loss=None, clean_out=None, keep_prev=False):
+        """K-step attack in patch layout.  Leaves delta_K in ``pb.delta`` and the ATTACKED VIEW's operand
+        cast(img + delta_{K-1} + delta_K) (see compute_pgd / objectives.py:176) in ``pb.patchesT_full``; with ``keep_prev``
+        also delta_{K-1} in ``pb.delta_prev`` (the public ``pgd_attack`` needs it for the batch image it leaves behind).
+
+        Every step's update kernel also writes the next forward's operand (``Engine.pgd_step``), step 0 starts from the
+        implicit delta_0 = 0: no zero fills, no separate add + cast passes, no delta copy inside the loop.
 
         ``before_first_loss``: callback run once between the first encoder forward and the first InfoNCE (the
         caller joins the key-encoder stream there).  ``clean_out``: dict that receives the clean-query statistics:
@@ -36,15 +40,13 @@ class PGDAttack_moco(PGDAttack):
         objectives.py:267-275, so that forward is not computed twice when dropout is off."""
         eng = pl_module.engine
         K = self.adv_steps_img
-        pb.delta.zero_()                                      # pgd_attack_vilt.py:136
-        pb.delta_prev.zero_()
         if k is not None and k.data_ptr() != pb.k.data_ptr():
             pb.k.copy_(k)
+        pb0 = pb
         pb = eng.pgd_bufs(pb)                                 # fp32 twin when the engine runs PGD in fp32 (:141)
+        op = eng.make_operand(pb)                             # img_init + delta_0, delta_0 = 0 (:136,144)
         for step in range(K):
-            if step == K - 1 and K > 1:
-                pb.delta_prev.copy_(pb.delta)
-            op = eng.make_operand(pb, pb.delta)               # img_init + img_delta (:144)
+            last = step == K - 1
             eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
             eng.heads_forward(pb, key=False)
             if step == 0 and before_first_loss is not None:
@@ -56,14 +58,20 @@ class PGDAttack_moco(PGDAttack):
                 clean_out["q"] = pb.q.clone()
             eng.heads_backward(pb, pb.dq, None, with_grads=False)
             eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=pb.gpatch)
-            eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img)   # :162-173
+            if last and keep_prev:
+                if K > 1:
+                    pb.delta_prev.copy_(pb.delta)
+                else:
+                    pb.delta_prev.zero_()
+            op = pb0.patchesT_full if last else pb.patchesT
+            eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img, first=step == 0, out=op, sum_prev=last)   # :162-173
         return pb.delta
 
     def pgd_attack(self, pl_module, batch, k_modality=None):
         eng = pl_module.engine
         img_init = batch["image"][0]
         pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], img_init)
-        delta_p = self.attack_patches(pl_module, pb, k_modality)
+        delta_p = self.attack_patches(pl_module, pb, k_modality, keep_prev=True)
         B = img_init.shape[0]
         # the reference leaves batch['image'][0] = img_init + delta_{K-1} behind (:144)
         batch["image"][0] = img_init.to(eng.device) + eng.patches_to_image(pb.delta_prev, pb)
@@ -79,17 +87,14 @@ class PGDAttack_bartlowtwins(PGDAttack):
     def __init__(self, config):
         super().__init__(config, "barlowtwins")
 
-    def attack_patches(self, pl_module, pb, zk):
+    def attack_patches(self, pl_module, pb, zk, keep_prev=False):
         eng = pl_module.engine
         K = self.adv_steps_img
         bb = eng.bt_bufs(pb.B, "pgd")
         mode = bool(pl_module.training)           # deepcopy(pl_module.barlowtwins_head) keeps the train / eval flag (:189)
-        pb.delta.zero_()
-        pb.delta_prev.zero_()
+        op = eng.make_operand(pb)                 # delta_0 = 0
         for step in range(K):
-            if step == K - 1 and K > 1:
-                pb.delta_prev.copy_(pb.delta)
-            op = eng.make_operand(pb, pb.delta)
+            last = step == K - 1
             eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
             eng.heads_forward(pb, key=False, want_q=False)
             eng.bt_forward(bb, pb.cls, training=mode, track=False)
@@ -97,13 +102,19 @@ class PGDAttack_bartlowtwins(PGDAttack):
             dcls = eng.bt_backward(bb, bb.dz, training=mode, with_grads=False)
             eng.heads_backward(pb, None, dcls, with_grads=False)
             eng.encoder_backward(pb, L.MODE_DATA, op, pb.dcls, cls_only=True, dpatches=pb.gpatch)
-            eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img)
+            if last and keep_prev:
+                if K > 1:
+                    pb.delta_prev.copy_(pb.delta)
+                else:
+                    pb.delta_prev.zero_()
+            op = pb.patchesT_full if last else pb.patchesT
+            eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img, first=step == 0, out=op, sum_prev=last)
         return pb.delta
 
     def pgd_attack(self, pl_module, batch, k_modality=None):
         eng = pl_module.engine
         img_init = batch["image"][0]
         pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], img_init, tag="bt")
-        delta_p = self.attack_patches(pl_module, pb, k_modality.to(eng.device, torch.float32).contiguous())
+        delta_p = self.attack_patches(pl_module, pb, k_modality.to(eng.device, torch.float32).contiguous(), keep_prev=True)
         batch["image"][0] = img_init.to(eng.device) + eng.patches_to_image(pb.delta_prev, pb)
         return eng.patches_to_image(delta_p, pb)

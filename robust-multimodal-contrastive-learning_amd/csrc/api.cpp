@@ -286,6 +286,12 @@ int rmcl_pgd_step(const void* grad, int dtype, float* delta, uint32_t* amax_scra
   RMCL_REQUIRE(grad && delta && amax_scratch, "pgd_step: NULL argument");
   return rmcl_pgd_update(grad, dtype, delta, amax_scratch, B, per_sample, lr, eps, (hipStream_t)stream);
 }
+int rmcl_pgd_step_fused(const void* grad, int dtype, float* delta, uint32_t* amax_scratch, int B, int64_t per_sample, float lr,
+                        float eps, const float* base, void* operand, int operand_dtype, int flags, void* stream) {
+  RMCL_REQUIRE(grad && delta && amax_scratch, "pgd_step_fused: NULL argument");
+  RMCL_REQUIRE((flags & ~(RMCL_PGD_DELTA_ZERO | RMCL_PGD_SUM_PREV)) == 0, "pgd_step_fused: unknown flag");
+  return rmcl_pgd_update_fused(grad, dtype, delta, amax_scratch, B, per_sample, lr, eps, base, operand, operand_dtype, flags, (hipStream_t)stream);
+}
 int rmcl_delta_channel_norm(const float* delta, float* out, int64_t rows, int C, int pp, void* stream) {
   return rmcl_delta_chan_norm(delta, out, rows, C, pp, (hipStream_t)stream);
 }

@@ -569,6 +569,73 @@ int rmcl_pgd_update(const void* g, int dt, float* delta, unsigned* amax_bits, in
   return 0;
 }
 
+// The same step fused with what the loop does next: delta_new = clamp(delta_old + lr * g / max|g|, +-eps) AND, in the same pass,
+// the operand of the next encoder forward, cast(base + delta_new) (pgd_attack_vilt.py:144) - or, on the last step, the attacked view
+// cast((base + delta_old) + delta_new) (the reference's img + delta_{K-1} + delta_K, objectives.py:176).  ZERO: delta_old is the
+// all-zero delta_0 of step 0 and is not read (no zero fill of the 113 MB buffer).  Replaces pgd_update + add_cast (+ the
+// delta_prev copy and the three-input add_cast of the attacked view): 623 -> 510 MB per step and one launch less.
+template <typename T, typename TO, bool ZERO, bool SUMPREV>
+__global__ __launch_bounds__(256) void pgd_update_fused_kernel(const T* __restrict__ g, const unsigned* __restrict__ amax_bits,
+                                                               float* __restrict__ delta, const float* __restrict__ base,
+                                                               TO* __restrict__ out, long per_sample, float lr, float eps) {
+  const int b = blockIdx.y;
+  const float den = fmaxf(__uint_as_float(amax_bits[b]), 1e-8f);
+  const long off = (long)b * per_sample;
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 1024) {
+    float old[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!ZERO) { const float4 v = *reinterpret_cast<const float4*>(delta + off + i); old[0] = v.x; old[1] = v.y; old[2] = v.z; old[3] = v.w; }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = old[j] + lr * to_f32<T>(g[off + i + j]) / den;
+      if (eps > 0.f) o[j] = fminf(fmaxf(o[j], -eps), eps);
+    }
+    *reinterpret_cast<float4*>(delta + off + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (out) {
+      const float4 a = *reinterpret_cast<const float4*>(base + off + i);
+      float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = SUMPREV ? (v[j] + old[j]) + o[j] : v[j] + o[j];
+      if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(out + off + i) = make_float4(v[0], v[1], v[2], v[3]);
+      else {
+        uint2 pk;
+        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(out + off + i) = pk;
+      }
+    }
+  }
+}
+template <typename T, typename TO>
+static void pgd_fused_launch(const void* g, const unsigned* amax, float* delta, const float* base, void* out, long per, float lr, float eps,
+                             int flags, dim3 grid, hipStream_t s) {
+  const T* gp = (const T*)g;
+  TO* op = (TO*)out;
+  const bool zero = flags & 1, sum = (flags & 2) && !zero;       // (delta_old = 0: the sum with it is the plain form)
+  if (zero) RMCL_LAUNCH((pgd_update_fused_kernel<T, TO, true, false>), grid, dim3(256), 0, s, gp, amax, delta, base, op, per, lr, eps);
+  else if (sum) RMCL_LAUNCH((pgd_update_fused_kernel<T, TO, false, true>), grid, dim3(256), 0, s, gp, amax, delta, base, op, per, lr, eps);
+  else RMCL_LAUNCH((pgd_update_fused_kernel<T, TO, false, false>), grid, dim3(256), 0, s, gp, amax, delta, base, op, per, lr, eps);
+}
+int rmcl_pgd_update_fused(const void* g, int dt, float* delta, unsigned* amax_bits, int B, long per_sample, float lr, float eps,
+                          const float* base, void* out, int dt_out, int flags, hipStream_t s) {
+  RMCL_REQUIRE(per_sample % 4 == 0, "pgd_update: per_sample%4");
+  RMCL_REQUIRE(!out || base, "pgd_update: an operand output needs the base image");
+  hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned) * B, s);
+  if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+  dim3 grid(std::min<long>(cdiv(per_sample, 1024), 64), B);
+  if (dt == RMCL_F32) RMCL_LAUNCH(absmax_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, per_sample);
+  else RMCL_LAUNCH(absmax_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, amax_bits, per_sample);
+  if (dt == RMCL_F32) {
+    if (dt_out == RMCL_F32) pgd_fused_launch<float, float>(g, amax_bits, delta, base, out, per_sample, lr, eps, flags, grid, s);
+    else pgd_fused_launch<float, bf16_t>(g, amax_bits, delta, base, out, per_sample, lr, eps, flags, grid, s);
+  } else {
+    if (dt_out == RMCL_F32) pgd_fused_launch<bf16_t, float>(g, amax_bits, delta, base, out, per_sample, lr, eps, flags, grid, s);
+    else pgd_fused_launch<bf16_t, bf16_t>(g, amax_bits, delta, base, out, per_sample, lr, eps, flags, grid, s);
+  }
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
 // mean over (b, y, x) of the channel-wise L2 norm of delta (objectives.py:184), delta in patch layout
 // [B*P, C*pp]: out += sum_{row, i<pp} sqrt(sum_c delta[row][c*pp + i]^2)   (caller divides by B*P*pp)
 __global__ __launch_bounds__(256) void delta_chan_norm_kernel(const float* __restrict__ d, float* __restrict__ out, long rows, int C, int pp) {

@@ -82,6 +82,8 @@ int rmcl_k_shard_sum(const void* pieces, int dt, int W, long n, float* out32, vo
 int rmcl_cast(const float* in, void* out, int dt, long n, hipStream_t s);
 int rmcl_co_mask(const long* text_mask, const void* pat, int dt, int* co, int B, int L, int P, int C, int pp, hipStream_t s);
 int rmcl_pgd_update(const void* g, int dt, float* delta, unsigned* amax_bits, int B, long per_sample, float lr, float eps, hipStream_t s);
+int rmcl_pgd_update_fused(const void* g, int dt, float* delta, unsigned* amax_bits, int B, long per_sample, float lr, float eps,
+                          const float* base, void* out, int dt_out, int flags, hipStream_t s);
 int rmcl_delta_chan_norm(const float* d, float* out, long rows, int C, int pp, hipStream_t s);
 int rmcl_ema(float* k, const float* q, void* k_lp, float m, long n, hipStream_t s);
 int rmcl_enqueue(float* queue, const float* keys, int n, int Pd, long Kq, long ptr, hipStream_t s);

@@ -513,10 +513,19 @@ class Engine:
         check(lib.rmcl_bt_pair_metrics(P(bb.z), P(zk), bb.B, self.bt.H3, P(bb.rows), stream_ptr()), "bt_pair_metrics")
         return bb.rows
 
-    def pgd_step(self, pb: PassBuffers, lr: float, eps: float):
+    def pgd_step(self, pb: PassBuffers, lr: float, eps: float, first: bool = False, out: torch.Tensor = None, sum_prev: bool = False):
+        """delta <- clamp(delta + lr g / max|g|, +-eps) (pgd_attack_vilt.py:162-173).  ``out``: also written in the same pass,
+        cast(patches32 + delta_new) = the next forward's operand (:144), or with ``sum_prev`` cast(patches32 + delta_old + delta_new) =
+        the attacked view of objectives.py:176.  ``first``: the incoming delta is delta_0 = 0 and is not read (no zero fill)."""
         per = pb.d.P * pb.d.patch_k
-        check(lib.rmcl_pgd_step(P(pb.gpatch), pb.dtype, P(pb.delta), P(pb.amax), pb.B, I64(per), F(lr), F(eps),
-                                stream_ptr()), "pgd_step")
+        if out is None and not first:
+            check(lib.rmcl_pgd_step(P(pb.gpatch), pb.dtype, P(pb.delta), P(pb.amax), pb.B, I64(per), F(lr), F(eps),
+                                    stream_ptr()), "pgd_step")
+            return
+        flags = (L.PGD_DELTA_ZERO if first else 0) | (L.PGD_SUM_PREV if sum_prev else 0)
+        odt = L.F32 if (out is not None and out.dtype == torch.float32) else L.BF16
+        check(lib.rmcl_pgd_step_fused(P(pb.gpatch), pb.dtype, P(pb.delta), P(pb.amax), pb.B, I64(per), F(lr), F(eps), P(pb.patches32),
+                                      P(out), odt, flags, stream_ptr()), "pgd_step_fused")
 
     def enqueue(self, keys_all: torch.Tensor, ptr: int):
         check(lib.rmcl_enqueue_f32(P(self.queue), P(keys_all), keys_all.shape[0], 128, I64(self.num_negative), I64(ptr),

@@ -274,8 +274,8 @@ def compute_moco_contrastive(pl_module, batch):
         # a zero-padded batch carry delta = 0 and are not stored in the patch layout
         n_pix = pb.delta.numel() // 3 if pb.geom is None else pb.B * pb.geom.shape[2] * pb.geom.shape[3]
         pl_module.log(f"moco_attack/{phase}/delta", _scalar(pb.loss_sum / float(n_pix)))
-        # attacked view = img + delta_{K-1} + delta_K  (pgd_attack_vilt.py:144 + objectives.py:176)
-        op_att = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pb.patchesT_full)
+        # attacked view = img + delta_{K-1} + delta_K  (pgd_attack_vilt.py:144 + objectives.py:176): written by the last PGD update
+        op_att = pb.patchesT_full
         loss_i = _attacked_view(pl_module, pb, op_att, k, "img", "PGD_success_rate", prediction_original, ret, phase)
         ret["logit_pos_img_attack"] = pb.rows[:, 2].clone()
         ret["lse_img_attack"] = pb.rows[:, 9].clone()
@@ -284,7 +284,7 @@ def compute_moco_contrastive(pl_module, batch):
         loss_num += 1
     if pl_module.image_view and pl_module.text_view:                        # :356-392 attacked image AND attacked text
         pbo = eng.bind_text(pb, txt_ids, txt_masks, tag="moco_both")
-        op_b = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pbo.patchesT_full)
+        op_b = pbo.patchesT_full.copy_(pb.patchesT_full)                    # the same attacked image (own buffer: read again by the backward)
         loss_b = _attacked_view(pl_module, pbo, op_b, k, "both", "Both_success_rate", prediction_original, ret, phase)
         pl_module.log("moco_loss/attacked_both_loss", loss_b.detach())
         loss = loss + loss_b
@@ -394,14 +394,14 @@ def compute_barlowtwins_contrastive(pl_module, batch):
                                           stream_ptr()), "delta_norm")
         n_pix = pb.delta.numel() // 3 if pb.geom is None else pb.B * pb.geom.shape[2] * pb.geom.shape[3]
         pl_module.log(f"barlowtwins_attack/{phase}/delta", _scalar(pb.loss_sum / float(n_pix)))
-        op_att = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pb.patchesT_full)
+        op_att = pb.patchesT_full                                               # written by the last PGD update
         v, on_diag, red = _bt_view(pl_module, pb, op_att, zk, "img", ret, phase, need_grad, training)
         ret["barlowtwins_loss_invariance_img"], ret["barlowtwins_loss_redundancy_img"] = on_diag, red
         loss, loss_num = loss + v, loss_num + 1
         views.append(("img", "img"))
     if pl_module.image_view and pl_module.text_view:                            # :527-546
         pbo = eng.bind_text(pb, txt_ids, txt_masks, tag="bt_both")
-        op_b = eng.make_operand(pb, pb.delta_prev, pb.delta, out=pbo.patchesT_full)
+        op_b = pbo.patchesT_full.copy_(pb.patchesT_full)
         v, on_diag, red = _bt_view(pl_module, pbo, op_b, zk, "both", ret, phase, need_grad, training)
         ret["barlowtwins_loss_invariance_both"], ret["barlowtwins_loss_redundancy_both"] = on_diag, red
         loss, loss_num = loss + v, loss_num + 1

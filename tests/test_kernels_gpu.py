@@ -207,6 +207,37 @@ def test_pgd_step(dt):
     assert float(delta.abs().max()) <= 0.005
 
 
+@pytest.mark.parametrize("dt,odt", [(L.BF16, L.BF16), (L.F32, L.F32), (L.F32, L.BF16)])
+def test_pgd_step_fused(dt, odt):
+    """rmcl_pgd_step_fused = rmcl_pgd_step + the operand the loop forms next (pgd_attack_vilt.py:144 / objectives.py:176), bit for bit."""
+    B, per = 3, 144 * 3072
+    g = rnd(B, per, seed=1).to(tdt(dt))
+    g[2] = 0
+    base = rnd(B, per, seed=3)
+    delta0 = (rnd(B, per, seed=2) * 0.002).clamp(-0.005, 0.005)
+    amax = torch.empty(B, dtype=torch.int32, device=DEV)
+    ref = delta0.clone()
+    check(lib.rmcl_pgd_step(P(g), dt, P(ref), P(amax), B, I64(per), F(0.05), F(0.005), stream()))
+    for flags in (0, L.PGD_SUM_PREV, L.PGD_DELTA_ZERO, L.PGD_DELTA_ZERO | L.PGD_SUM_PREV):
+        zero = bool(flags & L.PGD_DELTA_ZERO)
+        delta = torch.full_like(delta0, float("nan")) if zero else delta0.clone()      # (DELTA_ZERO must not read the buffer)
+        out = torch.empty(B, per, dtype=tdt(odt), device=DEV)
+        check(lib.rmcl_pgd_step_fused(P(g), dt, P(delta), P(amax), B, I64(per), F(0.05), F(0.005), P(base), P(out), odt, flags, stream()))
+        if zero:
+            want = torch.zeros_like(delta0)
+            check(lib.rmcl_pgd_step(P(g), dt, P(want), P(amax), B, I64(per), F(0.05), F(0.005), stream()))
+            old = torch.zeros_like(delta0)
+        else:
+            want, old = ref, delta0
+        assert torch.equal(delta, want)
+        op = (base + old) + want if (flags & L.PGD_SUM_PREV) and not zero else base + want
+        assert torch.equal(out, op.to(tdt(odt)))
+    # no operand: the update alone
+    delta = delta0.clone()
+    check(lib.rmcl_pgd_step_fused(P(g), dt, P(delta), P(amax), B, I64(per), F(0.05), F(0.005), None, None, odt, 0, stream()))
+    assert torch.equal(delta, ref)
+
+
 def test_ema_and_cast():
     n = 1 << 20
     k, q = rnd(n, seed=1), rnd(n, seed=2)
