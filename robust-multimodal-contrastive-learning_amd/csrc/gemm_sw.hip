@@ -24,6 +24,19 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #define SW_BUF (3 * SW_UNIT)                 // A, B0, B1
 #define SW_LDS (2 * SW_BUF)                  // 144 KiB
 
+
+// In-kernel phase trace (developer builds: RMCL_EXTRA_FLAGS=-DST_TRACE, tools/st_trace.py), as in gemm_st.hip
+#ifdef ST_TRACE
+__device__ long long g_sw_trace[2][32];
+#define SW_STAMP(i)                                                                                              \
+  if (blockIdx.x == 100 && (threadIdx.x & 255) == 0) g_sw_trace[threadIdx.x >> 8][i] = wall_clock64()
+extern "C" int rmcl_debug_sw_trace(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sw_trace), sizeof(long long) * 64);
+}
+#else
+#define SW_STAMP(i)
+#endif
+
 template <int N>
 __device__ __forceinline__ void sw_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -182,6 +195,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  SW_STAMP(0);
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -244,15 +258,49 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
 
   char* buf0 = smem;
   char* buf1 = smem + SW_BUF;
+  // LayerNorm-folded consumer: the row statistics of the tile's 192 rows come from the PRODUCER's partial sums, which are complete
+  // when this kernel starts - fetched here, under the latency of the first k-tile's LDS-DMA, instead of at the head of the
+  // epilogue (tools/st_trace.py: chunk 0 of the epilogue 5.7 us against 3.4 us for chunk 1, the difference being this round trip)
+  float4 pst[LNF == 1 ? 8 : 1];
+  if constexpr (LNF == 1) {
+    if (t < 192) {
+      const float4* pp = reinterpret_cast<const float4*>(g.ln_part + min((long)m0 + t, (long)g.M - 1) * (long)(g.ln_nparts * 2));
+      if (g.ln_nparts == 16) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pst[q] = pp[q];
+      }
+    }
+  }
   sw_stage(c.A, c.oa, 0, buf0, wave);
   sw_stage(c.B, c.ob0, 0, buf0 + SW_UNIT, wave);
   sw_stage(c.B, c.ob1, 0, buf0 + 2 * SW_UNIT, wave);
+  if constexpr (LNF == 1) {
+    if (t < 192) {
+      const long m = min((long)m0 + t, (long)g.M - 1);
+      float s1 = 0.f, s2 = 0.f;
+      if (g.ln_nparts == 16) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1 += pst[q].x + pst[q].z; s2 += pst[q].y + pst[q].w; }
+      } else {
+        const float4* pp = reinterpret_cast<const float4*>(g.ln_part + m * (long)(g.ln_nparts * 2));
+        for (int q = 0; q < g.ln_nparts / 2; ++q) { const float4 v = pp[q]; s1 += v.x + v.z; s2 += v.y + v.w; }
+      }
+      const float inv = 1.0f / (float)g.ln_cols, mean = s1 * inv;
+      const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + g.ln_eps);
+      float* rowstat0 = reinterpret_cast<float*>(smem + SW_LDS);
+      rowstat0[2 * t] = mean;
+      rowstat0[2 * t + 1] = rstd;
+      if (n0 == 0 && g.ln_mean && m0 + t < m_end) { g.ln_mean[m] = mean; g.ln_rstd[m] = rstd; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (published by the barrier below; first read in the epilogue)
+  }
   sw_wait_vm<0>();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   if (wm == 1) __builtin_amdgcn_s_barrier();                 // skew: group 1 runs one barrier behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
+  SW_STAMP(1);
   int it = 0;
   for (; it + 1 < nk; ++it) {
     char* cur = (it & 1) ? buf1 : buf0;
@@ -275,6 +323,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
   if (wm == 0) __builtin_amdgcn_s_barrier();
   if constexpr (AUX_LDS) __builtin_amdgcn_s_barrier();         // every wave's aux DMA has landed
 
+  SW_STAMP(2);
   // epilogue (order as gemm_st.hip: alpha, bias, gelu'(aux), stash, gelu, residual)
   const int epi = g.epi;
   TO* C = reinterpret_cast<TO*>(g.C);
@@ -290,22 +339,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     // image in the other one)
     char* img = AUX_LDS ? last_cur + wm * IMG : smem + wm * (2 * IMG);
     const bool stash = !AUX_LDS && (epi & EPI_SAVE_PREACT) != 0;
-    float* rowstat = reinterpret_cast<float*>(smem + SW_LDS);  // LNF: 192 x (mean, rstd), beyond the two operand buffers
-    if constexpr (LNF == 1) {
-      if (t < 192) {
-        const long m = min(m0 + t, g.M - 1);
-        const float4* pp = reinterpret_cast<const float4*>(g.ln_part + m * (long)(g.ln_nparts * 2));
-        float s1 = 0.f, s2 = 0.f;
-        for (int q = 0; q < g.ln_nparts / 2; ++q) { const float4 v = pp[q]; s1 += v.x + v.z; s2 += v.y + v.w; }
-        const float inv = 1.0f / (float)g.ln_cols, mean = s1 * inv;
-        const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + g.ln_eps);
-        rowstat[2 * t] = mean;
-        rowstat[2 * t + 1] = rstd;
-        if (n0 == 0 && g.ln_mean && m0 + t < m_end) { g.ln_mean[m] = mean; g.ln_rstd[m] = rstd; }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
+    float* rowstat = reinterpret_cast<float*>(smem + SW_LDS);  // LNF: 192 x (mean, rstd), beyond the two operand buffers (filled at kernel start)
     // per-column vectors of both column halves and (LNF) the statistics of this lane's six rows: fetched ONCE, ahead of the chunk
     // loop (inside it every (chunk, half) paid an L2 / LDS round trip before its first FMA)
     // (the GELU' form carries no bias - fc2-dX - and has no registers to spare: its zero "bias" stays a constant)
@@ -396,6 +430,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
           }
         }
       }
+      SW_STAMP(4 + 3 * ch);
       __builtin_amdgcn_s_barrier();                          // the group's images of this chunk are complete
       if constexpr (AUX_LDS) {                                 // (both groups are past their aux reads of chunk 0: fetch chunk 1)
         if (ch == 0) {
@@ -417,7 +452,9 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
         }
       }
       if constexpr (AUX_LDS) { if (ch == 0) sw_wait_vm<0>(); }
+      SW_STAMP(5 + 3 * ch);
       __builtin_amdgcn_s_barrier();                          // images consumed (AUX_LDS: and chunk 1's aux has landed)
+      SW_STAMP(6 + 3 * ch);
     }
   } else {
 #pragma unroll
@@ -458,6 +495,11 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
       }
     }
   }
+#ifdef ST_TRACE
+  SW_STAMP(10);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SW_STAMP(11);
+#endif
 }
 
 bool rmcl_gemm_sw_supported(const GemmArgs& g, int a_kc, int b_kc) {

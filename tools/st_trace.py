@@ -1,5 +1,5 @@
 """Phase timeline of ONE workgroup of gemm_st_kernel (developer build: csrc/build.sh with RMCL_EXTRA_FLAGS=-DST_TRACE).
-Usage: python tools/st_trace.py {proj|fc2|qkv|projdx}   - launches the step's form of that GEMM 5x and prints the last stamps."""
+Usage: python tools/st_trace.py {proj|fc2|qkv|projdx|fc1|fc2dx}   - launches the step's form of that GEMM 5x and prints the last stamps."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,6 +25,22 @@ elif which == "qkv":
     s_, c_ = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     run = lambda: check(lib.rmcl_linear_lnfold(P(xb), P(W), P(s_), P(c_), P(part), 16, P(out), None, M, N, D, 0, F(1e-6), P(mean), P(rstd), stream()))
+elif which in ("fc1", "fc2dx"):             # the 192x384-tile kernel (gemm_sw.hip): fc1 forward with stash, fc2-dX with GELU'
+    H = 3072
+    if which == "fc1":
+        xb = torch.randn(M, D, generator=g).to(DEV).to(torch.bfloat16)
+        part = torch.rand(M, 16, 2, generator=g).to(DEV) + 1.0
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        W = (torch.randn(H, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+        s_, c_ = torch.randn(H, generator=g).to(DEV), torch.randn(H, generator=g).to(DEV)
+        out, pre = torch.empty(M, H, dtype=torch.bfloat16, device=DEV), torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+        run = lambda: check(lib.rmcl_linear_lnfold(P(xb), P(W), P(s_), P(c_), P(part), 16, P(out), P(pre), M, H, D, 1, F(1e-6), P(mean), P(rstd), stream()))
+    else:
+        dy = torch.randn(M, D, generator=g).to(DEV).to(torch.bfloat16)
+        W = (torch.randn(H, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)          # transposed shadow: [N = 3072][K = 768]
+        u = torch.randn(M, H, generator=g).to(DEV).to(torch.bfloat16)
+        out = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+        run = lambda: check(lib.rmcl_gemm(P(dy), P(W), P(out), None, None, P(u), M, H, D, I64(D), I64(D), H, H, F(1.0), 16, 1, L.BF16, L.BF16, 1, 1, 0, stream()))
 else:                                     # plain bf16-out NT GEMM, K = 768 (proj-dX)
     A = torch.randn(M, D, generator=g).to(DEV).to(torch.bfloat16)
     W = (torch.randn(D, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
@@ -36,9 +52,15 @@ for _ in range(5):
     run()
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 64)()
-assert lib.rmcl_debug_st_trace(buf) == 0
-names = {0: "start", 1: "prologue landed", 2: "k-loop done", 3: "epi: vectors/rowstat", 4: "epi: barrier", 20: "epilogue done", 21: "stores drained"}
-for ch in range(3):
+if which in ("fc1", "fc2dx"):
+    assert lib.rmcl_debug_sw_trace(buf) == 0
+    names = {0: "start", 1: "prologue landed", 2: "k-loop done", 10: "epilogue done", 11: "stores drained"}
+    for ch in range(2):
+        names.update({4 + 3 * ch: f"chunk{ch}: math + LDS images", 5 + 3 * ch: f"chunk{ch}: barrier + read-back + stores issued", 6 + 3 * ch: f"chunk{ch}: barrier"})
+else:
+    assert lib.rmcl_debug_st_trace(buf) == 0
+    names = {0: "start", 1: "prologue landed", 2: "k-loop done", 3: "epi: vectors/rowstat", 4: "epi: barrier", 20: "epilogue done", 21: "stores drained"}
+for ch in range(3 if which not in ("fc1", "fc2dx") else 0):
     names.update({5 + 4 * ch: f"chunk{ch}: math+LDS write", 6 + 4 * ch: f"chunk{ch}: barrier", 7 + 4 * ch: f"chunk{ch}: read-back+stores issued",
                   8 + 4 * ch: f"chunk{ch}: barrier"})
 for w in range(2):
