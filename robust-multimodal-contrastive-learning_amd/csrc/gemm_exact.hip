@@ -401,10 +401,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g)
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // register double buffer over 16-k steps: the loads of step i + 1 are issued before the MFMAs of step i (the waves are few and
-  // the k-loop is a dependent chain of L2 / HBM round trips otherwise)
-  float4 av[2][4];
-  float bv[2][CT][4];
+  // register ring over 16-k steps, PD - 1 steps of loads in flight ahead of the MFMAs: the waves are few and every step is an L2 /
+  // HBM round trip (64-byte row pieces of A), so with one step of lookahead the k-loop was a chain of 12 - 24 such round trips
+  // (K = 3072, 8 waves: 41.8 us for 9 MB of weights).  The ring index is a compile-time constant (PD steps per trip).
+  constexpr int PD = 4;
+  float4 av[PD][4];
+  float bv[PD][CT][4];
   auto load = [&](int buf, int k) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) av[buf][rt] = *reinterpret_cast<const float4*>(Ap[rt] + k);
@@ -430,17 +432,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g)
         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][rt].w, bv[buf][ct][3], acc[rt][ct], 0, 0, 0);
       }
   };
-  load(0, k_lo);
-  int k = k_lo;
-  for (; k + 32 <= k_hi; k += 32) {                     // two steps per trip so that the buffer index is a compile-time constant
-    load(1, k + 16);
-    __builtin_amdgcn_sched_barrier(0);
-    mac(0);
-    if (k + 32 < k_hi) load(0, k + 32);
-    __builtin_amdgcn_sched_barrier(0);
-    mac(1);
+  const int nsteps = kq / 16;
+#pragma unroll
+  for (int i = 0; i < PD - 1; ++i)
+    if (i < nsteps) load(i, k_lo + 16 * i);
+  for (int s0 = 0; s0 < nsteps; s0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      const int step = s0 + j;
+      if (step < nsteps) {
+        if (step + PD - 1 < nsteps) load((j + PD - 1) % PD, k_lo + 16 * (step + PD - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mac(j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
-  if (k < k_hi) mac(0);                                 // odd number of 16-k steps: the last one is already in buffer 0
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
