@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g)
   __shared__ float red[NW][64][NT + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, gq = lane >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * NT;
-  const int kq = g.K / NW, k_lo = wave * kq, k_hi = k_lo + kq;            // kq % 16 == 0 (launcher)
+  const int kq = g.K / NW, k_lo = wave * kq;                               // kq % 16 == 0 (launcher)
   const float* Ap[4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) Ap[rt] = reinterpret_cast<const float*>(g.A) + (long)min(m0 + rt * 16 + c, g.M - 1) * g.lda + 4 * gq;

@@ -451,7 +451,12 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
           if (stash) *reinterpret_cast<float4*>(C2 + dst) = *reinterpret_cast<const float4*>(img + IMG + row * ROWB + cp * 16);
         }
       }
-      if constexpr (AUX_LDS) { if (ch == 0) sw_wait_vm<0>(); }
+      if constexpr (AUX_LDS) {
+        // chunk 1's aux DMA (3 instructions per wave) was issued BEFORE this chunk's 9 row stores and vmcnt retires in issue order:
+        // vmcnt(9) proves the DMA without waiting for the stores to drain (tools/st_trace.py: 9.3 us here with vmcnt(0)).  Only
+        // when every row of chunk 0 is live - otherwise a wave may skip store instructions and the count would not hold.
+        if (ch == 0) { if (m0 + 144 <= m_end) sw_wait_vm<9>(); else sw_wait_vm<0>(); }
+      }
       SW_STAMP(5 + 3 * ch);
       __builtin_amdgcn_s_barrier();                          // images consumed (AUX_LDS: and chunk 1's aux has landed)
       SW_STAMP(6 + 3 * ch);

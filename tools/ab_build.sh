@@ -7,7 +7,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 PKG="$ROOT/robust-multimodal-contrastive-learning_amd"
 TMP=$(mktemp -d)
 git -C "$ROOT" archive "$REV" robust-multimodal-contrastive-learning_amd/csrc include | tar -x -C "$TMP"
-bash "$TMP/robust-multimodal-contrastive-learning_amd/csrc/build.sh" > /dev/null
+bash "$TMP/robust-multimodal-contrastive-learning_amd/csrc/build.sh" > /dev/null 2>&1
 cp "$TMP/robust-multimodal-contrastive-learning_amd/lib/librmcl_hip.so" "$PKG/lib/librmcl_hip_ref.so"
 rm -rf "$TMP"
 echo "built $PKG/lib/librmcl_hip_ref.so from $REV"
