@@ -389,6 +389,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
   }
 }
 
+
+// In-kernel phase trace (developer builds: RMCL_EXTRA_FLAGS=-DST_TRACE, tools/st_trace.py attnbwd / attnfwd), as in gemm_st.hip
+#ifdef ST_TRACE
+__device__ long long g_at_trace[2][32];
+#define AT_STAMP(i)                                                                                              \
+  if (blockIdx.x == 300 && (threadIdx.x == 0 || threadIdx.x == 320)) g_at_trace[threadIdx.x != 0][i] = wall_clock64()
+extern "C" int rmcl_debug_at_trace(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_at_trace), sizeof(long long) * 64);
+}
+#else
+#define AT_STAMP(i)
+#endif
+
 // ================================================================================== backward: ONE kernel (dQ, dK, dV)
 // One workgroup of NKT waves per (batch, head); wave w owns KEY tile w in phase 1 and QUERY tile w in phase 2.
 //   phase 0: Q, dO, K -> LDS (transposed-read images); K / V row fragments of the wave's key tile -> registers;
@@ -412,6 +425,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
   float* Ds = Ls + NKP;                                         // delta per query
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * 64;
+  AT_STAMP(0);
   const long ld = 3 * D;
   const bf16_t* base = qkv + (long)b * N * ld + h * 64;
   const bf16_t* dob = dout + (long)b * N * D + h * 64;
@@ -419,41 +433,48 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
   stage_rows<true, NW>(Qtr, base, ld, N, NKP, wave, lane);
   stage_rows<true, NW>(Dtr, dob, D, N, NKP, wave, lane);
   stage_rows<true, NW>(Ktr, base + D, ld, N, NKP, wave, lane);
+  AT_STAMP(1);
   for (int j = t; j < NKP; j += NW * 64) Ls[j] = j < N ? lse[((long)blockIdx.x) * NKP + j] * LOG2E : INFINITY;
-  {                                                            // delta of query tile `wave`: lane = (query lane&15, 16 head dims 16g..)
-    const int q = wave * 16 + (lane & 15);
-    float dl = 0.f;
-    if (q < N) {
-      const uint4* pd = reinterpret_cast<const uint4*>(dob + (long)q * D + 16 * g);
-      const uint4* po = reinterpret_cast<const uint4*>(ob + (long)q * D + 16 * g);
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const uint4 a = pd[v], c = po[v];
-        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, cw[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dl = fmaf(__uint_as_float(aw[e] << 16), __uint_as_float(cw[e] << 16), dl);
-          dl = fmaf(__uint_as_float(aw[e] & 0xffff0000u), __uint_as_float(cw[e] & 0xffff0000u), dl);
-        }
-      }
-    }
-    dl = group_sum(dl);
-    if (g == 0) Ds[q] = dl;
-  }
-  // this wave's key tile: K / V row fragments and the key mask stay in registers
+  // this wave's key tile: K / V row fragments and the key mask stay in registers.  Issued BEFORE the delta loads are waited for: behind
+  // them they were a second HBM round trip of the load phase (tools/st_trace.py attnbwd: +2.7 us of a 22 us workgroup)
   bf16x8 kf[2], vf[2];
   const int* mrow = mask + (long)b * N;
   const int key = wave * 16 + (lane & 15);
   const float mbk = (key < N && mrow[key] != 0) ? 0.f : -INFINITY;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    kf[s] = frag_row_global(base + D, ld, wave * 16, N, s, lane);
-    vf[s] = frag_row_global(base + 2 * D, ld, wave * 16, N, s, lane);
-  }
+  for (int s = 0; s < 2; ++s) vf[s] = frag_row_global(base + 2 * D, ld, wave * 16, N, s, lane);   // (K: out of its LDS image, below)
+  // delta of query tile `wave`: O row fragments from global now, dO out of its LDS image after the barrier (dO is staged for the
+  // transposed reads anyway: no second global read of it)
+  bf16x8 of[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) of[s] = frag_row_global(ob, D, wave * 16, N, s, lane);
+  AT_STAMP(2);
   f32x4 dK[4], dV[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  AT_STAMP(3);
   __syncthreads();
+  AT_STAMP(4);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) kf[s] = frag_row_ldsT(Ktr, wave * 16, s, lane);    // the K image is staged anyway (phase 2): no second global read of K
+  {
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      union { bf16x8 v; uint32_t w[4]; } a, c;
+      a.v = frag_row_ldsT(Dtr, wave * 16, s, lane);
+      c.v = of[s];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dl = fmaf(__uint_as_float(a.w[e] << 16), __uint_as_float(c.w[e] << 16), dl);
+        dl = fmaf(__uint_as_float(a.w[e] & 0xffff0000u), __uint_as_float(c.w[e] & 0xffff0000u), dl);
+      }
+    }
+    dl = group_sum(dl);
+    const int q = wave * 16 + (lane & 15);
+    if (g == 0) Ds[q] = q < N ? dl : 0.f;
+  }
+  __syncthreads();                                             // delta of every query tile is in LDS
 
   // ---- phase 1 -------------------------------------------------------------------------------------------------------
   for (int qt = 0; qt < NKT; ++qt) {
@@ -498,6 +519,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
       dK[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtr[dt], sa, dK[dt], 0, 0, 0);   // += Q^T dS
     }
   }
+  AT_STAMP(5);
   if (key < N) {
     bf16_t* o = dqkv + ((long)b * N + key) * ld + h * 64 + 4 * g;
 #pragma unroll
@@ -511,7 +533,9 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
       *reinterpret_cast<uint2*>(o + 2 * D + 16 * dt) = pv;
     }
   }
+  AT_STAMP(6);
   __syncthreads();
+  AT_STAMP(7);
 
   // ---- phase 2: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for query tile `wave` ------------------------------------
   {
@@ -526,6 +550,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dQ[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr32_lds(Ktr, 32 * u, dt, lane), sb, dQ[dt], 0, 0, 0);
     }
+    AT_STAMP(8);
     const int q_lane = qt * 16 + (lane & 15);
     if (q_lane < N) {
       bf16_t* o = dqkv + ((long)b * N + q_lane) * ld + h * 64 + 4 * g;
@@ -538,6 +563,11 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
       }
     }
   }
+#ifdef ST_TRACE
+  AT_STAMP(9);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AT_STAMP(10);
+#endif
 }
 
 // ================================================================================== launchers

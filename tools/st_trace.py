@@ -41,6 +41,19 @@ elif which in ("fc1", "fc2dx"):             # the 192x384-tile kernel (gemm_sw.h
         u = torch.randn(M, H, generator=g).to(DEV).to(torch.bfloat16)
         out = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
         run = lambda: check(lib.rmcl_gemm(P(dy), P(W), P(out), None, None, P(u), M, H, D, I64(D), I64(D), H, H, F(1.0), 16, 1, L.BF16, L.BF16, 1, 1, 0, stream()))
+elif which == "attnbwd":                    # one-kernel attention backward, B = 64, N = 185, 12 heads
+    B, N, Hh = 64, 185, 12
+    qkv = torch.randn(B * N, 3 * D, generator=g).to(DEV).to(torch.bfloat16)
+    mask = torch.ones(B, N, dtype=torch.int32, device=DEV)
+    o = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+    lib.rmcl_attention_scratch_elems.restype = ctypes.c_int64
+    ne = lib.rmcl_attention_scratch_elems(B, Hh, N)
+    probs = torch.empty(ne, dtype=torch.bfloat16, device=DEV)   # (the fused path keeps the per-row log-sum-exp here)
+    scores, dS = torch.empty(ne, device=DEV), torch.empty(ne, dtype=torch.bfloat16, device=DEV)
+    check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(o), P(probs), P(scores), B, N, Hh, L.BF16, 0, stream()))
+    do = torch.randn(B * N, D, generator=g).to(DEV).to(torch.bfloat16)
+    dqkv = torch.empty(B * N, 3 * D, dtype=torch.bfloat16, device=DEV)
+    run = lambda: check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(do), P(o), P(dqkv), P(scores), P(dS), B, N, Hh, L.BF16, 0, stream()))
 else:                                     # plain bf16-out NT GEMM, K = 768 (proj-dX)
     A = torch.randn(M, D, generator=g).to(DEV).to(torch.bfloat16)
     W = (torch.randn(D, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
@@ -52,7 +65,11 @@ for _ in range(5):
     run()
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 64)()
-if which in ("fc1", "fc2dx"):
+if which == "attnbwd":
+    assert lib.rmcl_debug_at_trace(buf) == 0
+    names = {0: "start", 1: "Q / dO / K staging issued", 2: "delta done (dO, O rows from global)", 3: "K / V fragments in registers", 4: "barrier (images landed)",
+             5: "phase 1 done (12 query tiles)", 6: "dK / dV stores issued", 7: "barrier", 8: "phase 2 done (dQ)", 9: "dQ stores issued", 10: "stores drained"}
+elif which in ("fc1", "fc2dx"):
     assert lib.rmcl_debug_sw_trace(buf) == 0
     names = {0: "start", 1: "prologue landed", 2: "k-loop done", 10: "epilogue done", 11: "stores drained"}
     for ch in range(2):
@@ -60,12 +77,12 @@ if which in ("fc1", "fc2dx"):
 else:
     assert lib.rmcl_debug_st_trace(buf) == 0
     names = {0: "start", 1: "prologue landed", 2: "k-loop done", 3: "epi: vectors/rowstat", 4: "epi: barrier", 20: "epilogue done", 21: "stores drained"}
-for ch in range(3 if which not in ("fc1", "fc2dx") else 0):
+for ch in range(3 if which not in ("fc1", "fc2dx", "attnbwd") else 0):
     names.update({5 + 4 * ch: f"chunk{ch}: math+LDS write", 6 + 4 * ch: f"chunk{ch}: barrier", 7 + 4 * ch: f"chunk{ch}: read-back+stores issued",
                   8 + 4 * ch: f"chunk{ch}: barrier"})
 for w in range(2):
     t = [buf[w * 32 + i] for i in range(32)]
-    print(f"--- wave {4 * w} (group {w}) of workgroup 100, us from kernel start of that wave")
+    print(f"--- traced wave {w} (GEMMs: wave {4 * w} of workgroup 100; attention: wave {5 * w} of workgroup 300), us from that wave's start")
     prev = t[0]
     for i in sorted(names):
         if t[i] >= t[0] and t[i] > 0:
