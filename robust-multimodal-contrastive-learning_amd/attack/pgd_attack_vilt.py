@@ -26,7 +26,7 @@ class PGDAttack_moco(PGDAttack):
     def __init__(self, config):
         super().__init__(config, "moco")
 
-    def attack_patches(self, pl_module, pb, k, before_first_loss=None, clean_out=None, keep_prev=False):
+    def attack_patches(self, pl_module, pb, k, before_first_loss=None, clean_out=None, keep_prev=False, clean_op=None):
         """K-step attack in patch layout.  Leaves delta_K in ``pb.delta`` and the ATTACKED VIEW's operand
         cast(img + delta_{K-1} + delta_K) (see compute_pgd / objectives.py:176) in ``pb.patchesT_full``; with ``keep_prev``
         also delta_{K-1} in ``pb.delta_prev`` (the public ``pgd_attack`` needs it for the batch image it leaves behind).
@@ -44,7 +44,8 @@ class PGDAttack_moco(PGDAttack):
             pb.k.copy_(k)
         pb0 = pb
         pb = eng.pgd_bufs(pb)                                 # fp32 twin when the engine runs PGD in fp32 (:141)
-        op = eng.make_operand(pb)                             # img_init + delta_0, delta_0 = 0 (:136,144)
+        # img_init + delta_0, delta_0 = 0 (:136,144); ``clean_op``: the caller's cast of the clean image in pb.patchesT, if it has one
+        op = clean_op if (clean_op is not None and pb is pb0) else eng.make_operand(pb)
         for step in range(K):
             last = step == K - 1
             eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
@@ -87,12 +88,12 @@ class PGDAttack_bartlowtwins(PGDAttack):
     def __init__(self, config):
         super().__init__(config, "barlowtwins")
 
-    def attack_patches(self, pl_module, pb, zk, keep_prev=False):
+    def attack_patches(self, pl_module, pb, zk, keep_prev=False, clean_op=None):
         eng = pl_module.engine
         K = self.adv_steps_img
         bb = eng.bt_bufs(pb.B, "pgd")
         mode = bool(pl_module.training)           # deepcopy(pl_module.barlowtwins_head) keeps the train / eval flag (:189)
-        op = eng.make_operand(pb)                 # delta_0 = 0
+        op = clean_op if clean_op is not None else eng.make_operand(pb)                 # delta_0 = 0
         for step in range(K):
             last = step == K - 1
             eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)

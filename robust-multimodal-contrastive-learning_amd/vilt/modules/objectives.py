@@ -264,10 +264,10 @@ def compute_moco_contrastive(pl_module, batch):
         loss_num += 1
     if pl_module.image_view:                                                # :319-354
         if fuse_clean:
-            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, before_first_loss=join_key_stream, clean_out=clean)
+            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, before_first_loss=join_key_stream, clean_out=clean, clean_op=op)
             prediction_original = clean["prediction"]
         else:
-            pl_module.pgd_attacker.attack_patches(pl_module, pb, k)        # compute_pgd (:319-323)
+            pl_module.pgd_attacker.attack_patches(pl_module, pb, k, clean_op=op)        # compute_pgd (:319-323)
         check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3,
                                           pb.d.patch_k // 3, stream_ptr()), "delta_norm")
         # mean over ALL pixels of the (padded) batch image like torch.linalg.norm(delta, dim=1).mean() (:184); the pad pixels of
@@ -389,7 +389,7 @@ def compute_barlowtwins_contrastive(pl_module, batch):
         loss, loss_num = loss + v, loss_num + 1
         views.append(("txt", "text"))
     if pl_module.image_view:                                                    # :500-525
-        pl_module.pgd_attacker.attack_patches(pl_module, pb, zk)                # compute_pgd (:503)
+        pl_module.pgd_attacker.attack_patches(pl_module, pb, zk, clean_op=op)   # compute_pgd (:503)
         check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3, pb.d.patch_k // 3,
                                           stream_ptr()), "delta_norm")
         n_pix = pb.delta.numel() // 3 if pb.geom is None else pb.B * pb.geom.shape[2] * pb.geom.shape[3]
