@@ -191,6 +191,12 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                  f"(or without a torchrun environment, then bench.py starts the ranks itself)")
+    # rehearsal of the N > 1 code path on a ONE-GPU box (developer use): RMCL_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # RMCL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); never the measured configuration
+    share_gpu = os.environ.get("RMCL_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("RMCL_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     use_dist = world > 1 or os.environ.get("RMCL_BENCH_FORCE_DIST", "0") == "1"   # (1-rank rehearsal of the N > 1 code path)
@@ -200,7 +206,10 @@ def main():
         # RCCL's channel workgroups share the CUs with one-workgroup-per-CU GEMMs that leave 8 CUs free (rmcl_tune_set key 1);
         # 8 channels move the 447 MB of gradients well inside the ~12 ms backward window they overlap with
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import rmcl_pkg  # noqa: F401
     from rmcl_amd import _lib as L
@@ -263,7 +272,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
+    consistent = None
+    if use_dist and (share_gpu or backend != "nccl"):          # rehearsal: the ranks' parameters and queues must be bit-identical
+        eng = model.engine
+        mine = [float(eng.q32.double().sum()), float(eng.q32.double().abs().sum()), float(eng.queue.double().sum())]
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        consistent = all(v == allv[0] for v in allv)
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -302,6 +318,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "world_size": dist.get_world_size() if use_dist else 1,
+            **({"rehearsal": f"{backend} backend, ranks share one GPU: NOT a scaling measurement", "ranks_bit_identical": consistent}
+               if (share_gpu or backend != "nccl") else {}),
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}", "drop_rate": args.drop_rate,
                        "grad_sync": f"{args.grad_sync}/{args.grad_dtype}", "final_loss": round(final_loss, 4)},
             "roofline": {"bound": "mfma", "achieved": round(kern_tf, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",

@@ -579,3 +579,28 @@ def test_full_rmcl_three_views_bs64_bf16():
     assert not bool(changed[:, 0].any()) and not bool((changed & (batch["text_masks"] == 0)).any())
     assert int(changed.sum(1).max()) <= loops
     record("full_rmcl_bs64", loss=float(loss), txt=views[0], img=views[1], both=views[2], num_changes=float(lg["moco_attack/train/num_changes"]))
+
+
+@pytest.mark.gpu
+def test_two_rank_step_keeps_the_ranks_bit_identical():
+    """The N > 1 code path of the step on real hardware: two ranks (gloo instead of RCCL, both on cuda:0 - RCCL refuses two ranks
+    on one device) run bench.py's steps with different synthetic batches per rank: key all-gather + enqueue of the 128 gathered
+    keys, 1/world loss-gradient prescale, per-layer gradient reduction gated on the backward's events, fused AdamW.  Parameters
+    and queue must come out bit-identical on both ranks (the reference's DDP invariant, run.py:96 / objectives.py:226-248), with
+    the ring all-reduce and with the one-hop reduce-scatter / all-gather."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RMCL_BENCH_SHARE_GPU="1", RMCL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for port, algo in ((29721, "ring"), (29722, "direct")):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                              "--batch", "8", "--grad-sync", algo], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        rec = json.loads(line)
+        assert rec["world_size"] == 2 and rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16
+        assert rec["ranks_bit_identical"] is True
+        assert rec["config"]["final_loss"] == rec["config"]["final_loss"]            # finite (not NaN)
