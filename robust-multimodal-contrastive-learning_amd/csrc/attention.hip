@@ -105,6 +105,18 @@ __device__ __forceinline__ void fill_maskbias(float* mb, const int* __restrict__
   for (int j = t; j < NKP; j += nthreads) mb[j] = (j < N && mask[j] != 0) ? 0.f : -INFINITY;
 }
 
+// In-kernel phase trace (developer builds: RMCL_EXTRA_FLAGS=-DST_TRACE, tools/st_trace.py attnbwd / attnfwd), as in gemm_st.hip
+#ifdef ST_TRACE
+__device__ long long g_at_trace[2][32];
+#define AT_STAMP(i)                                                                                              \
+  if (blockIdx.x == 300 && (threadIdx.x == 0 || threadIdx.x == 320)) g_at_trace[threadIdx.x != 0][i] = wall_clock64()
+extern "C" int rmcl_debug_at_trace(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_at_trace), sizeof(long long) * 64);
+}
+#else
+#define AT_STAMP(i)
+#endif
+
 // ================================================================================== forward
 template <int NKT, int ATT_QW>
 __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
@@ -116,17 +128,23 @@ __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __r
   float* mb = reinterpret_cast<float*>(sm + 2 * NKP * 128);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
   const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * 64;
+  AT_STAMP(16);
   const long ld = 3 * D;
   const bf16_t* base = qkv + (long)b * N * ld + h * 64;
-  stage_rows<false, ATT_QW>(Kimg, base + D, ld, N, NKP, wave, lane);
-  stage_rows<true, ATT_QW>(Vimg, base + 2 * D, ld, N, NKP, wave, lane);
-  fill_maskbias(mb, mask + (long)b * N, N, NKP, t, ATT_QW * 64);
-
-  const int nqt = (N + 15) / 16;
+  // every global load of the load phase is issued before the first one is waited for: the mask row's load is consumed at once
+  // (vmcnt(0): the staging DMA has landed by then), and the Q fragments issued behind it were a second, serial HBM round trip
+  // (tools/st_trace.py attnfwd: 2.8 us of a 19.8 us workgroup)
   bf16x8 qn[2];                                              // Q fragments of the wave's NEXT tile (global-load latency off the loop's critical path)
   qn[0] = frag_row_global(base, ld, wave * 16, N, 0, lane);
   qn[1] = frag_row_global(base, ld, wave * 16, N, 1, lane);
+  stage_rows<false, ATT_QW>(Kimg, base + D, ld, N, NKP, wave, lane);
+  stage_rows<true, ATT_QW>(Vimg, base + 2 * D, ld, N, NKP, wave, lane);
+  fill_maskbias(mb, mask + (long)b * N, N, NKP, t, ATT_QW * 64);
+  AT_STAMP(17);
+  const int nqt = (N + 15) / 16;
+  AT_STAMP(18);
   __syncthreads();
+  AT_STAMP(19);
   for (int qt = wave; qt < nqt; qt += ATT_QW) {
     bf16x8 qf[2] = {qn[0], qn[1]};
     if (qt + ATT_QW < nqt) {
@@ -170,6 +188,7 @@ __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __r
       for (int dt = 0; dt < 4; ++dt) O[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr32_lds(Vimg, 32 * u, dt, lane), pa, O[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    AT_STAMP(20 + (qt >= ATT_QW ? 2 : 0));
     const float linv = 1.0f / l;
     if (q_lane < N) {
       bf16_t* o = out + ((long)b * N + q_lane) * D + h * 64 + 4 * g;
@@ -182,6 +201,11 @@ __global__ __launch_bounds__(ATT_QW * 64) void attn_fwd_kernel(const bf16_t* __r
       }
     }
   }
+#ifdef ST_TRACE
+  AT_STAMP(24);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AT_STAMP(25);
+#endif
 }
 
 // ================================================================================== backward: dQ, delta
@@ -390,18 +414,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 }
 
 
-// In-kernel phase trace (developer builds: RMCL_EXTRA_FLAGS=-DST_TRACE, tools/st_trace.py attnbwd / attnfwd), as in gemm_st.hip
-#ifdef ST_TRACE
-__device__ long long g_at_trace[2][32];
-#define AT_STAMP(i)                                                                                              \
-  if (blockIdx.x == 300 && (threadIdx.x == 0 || threadIdx.x == 320)) g_at_trace[threadIdx.x != 0][i] = wall_clock64()
-extern "C" int rmcl_debug_at_trace(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_at_trace), sizeof(long long) * 64);
-}
-#else
-#define AT_STAMP(i)
-#endif
-
 // ================================================================================== backward: ONE kernel (dQ, dK, dV)
 // One workgroup of NKT waves per (batch, head); wave w owns KEY tile w in phase 1 and QUERY tile w in phase 2.
 //   phase 0: Q, dO, K -> LDS (transposed-read images); K / V row fragments of the wave's key tile -> registers;
@@ -430,13 +442,8 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
   const bf16_t* base = qkv + (long)b * N * ld + h * 64;
   const bf16_t* dob = dout + (long)b * N * D + h * 64;
   const bf16_t* ob = out + (long)b * N * D + h * 64;
-  stage_rows<true, NW>(Qtr, base, ld, N, NKP, wave, lane);
-  stage_rows<true, NW>(Dtr, dob, D, N, NKP, wave, lane);
-  stage_rows<true, NW>(Ktr, base + D, ld, N, NKP, wave, lane);
-  AT_STAMP(1);
-  for (int j = t; j < NKP; j += NW * 64) Ls[j] = j < N ? lse[((long)blockIdx.x) * NKP + j] * LOG2E : INFINITY;
-  // this wave's key tile: K / V row fragments and the key mask stay in registers.  Issued BEFORE the delta loads are waited for: behind
-  // them they were a second HBM round trip of the load phase (tools/st_trace.py attnbwd: +2.7 us of a 22 us workgroup)
+  // this wave's key tile: K / V row fragments and the key mask stay in registers.  Issued FIRST: behind the lse load below (consumed at
+  // once, i.e. after a vmcnt(0) that also waits for the staging) they were a second, serial HBM round trip of the load phase
   bf16x8 kf[2], vf[2];
   const int* mrow = mask + (long)b * N;
   const int key = wave * 16 + (lane & 15);
@@ -448,6 +455,11 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
   bf16x8 of[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) of[s] = frag_row_global(ob, D, wave * 16, N, s, lane);
+  stage_rows<true, NW>(Qtr, base, ld, N, NKP, wave, lane);
+  stage_rows<true, NW>(Dtr, dob, D, N, NKP, wave, lane);
+  stage_rows<true, NW>(Ktr, base + D, ld, N, NKP, wave, lane);
+  AT_STAMP(1);
+  for (int j = t; j < NKP; j += NW * 64) Ls[j] = j < N ? lse[((long)blockIdx.x) * NKP + j] * LOG2E : INFINITY;
   AT_STAMP(2);
   f32x4 dK[4], dV[4];
 #pragma unroll

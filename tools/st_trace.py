@@ -1,5 +1,5 @@
 """Phase timeline of ONE workgroup of gemm_st_kernel (developer build: csrc/build.sh with RMCL_EXTRA_FLAGS=-DST_TRACE).
-Usage: python tools/st_trace.py {proj|fc2|qkv|projdx|fc1|fc2dx}   - launches the step's form of that GEMM 5x and prints the last stamps."""
+Usage: python tools/st_trace.py {proj|fc2|qkv|projdx|fc1|fc2dx|attnbwd|attnfwd}   - launches the step's form of that GEMM 5x and prints the last stamps."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -41,7 +41,7 @@ elif which in ("fc1", "fc2dx"):             # the 192x384-tile kernel (gemm_sw.h
         u = torch.randn(M, H, generator=g).to(DEV).to(torch.bfloat16)
         out = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
         run = lambda: check(lib.rmcl_gemm(P(dy), P(W), P(out), None, None, P(u), M, H, D, I64(D), I64(D), H, H, F(1.0), 16, 1, L.BF16, L.BF16, 1, 1, 0, stream()))
-elif which == "attnbwd":                    # one-kernel attention backward, B = 64, N = 185, 12 heads
+elif which in ("attnbwd", "attnfwd"):         # fused attention, B = 64, N = 185, 12 heads
     B, N, Hh = 64, 185, 12
     qkv = torch.randn(B * N, 3 * D, generator=g).to(DEV).to(torch.bfloat16)
     mask = torch.ones(B, N, dtype=torch.int32, device=DEV)
@@ -54,6 +54,8 @@ elif which == "attnbwd":                    # one-kernel attention backward, B =
     do = torch.randn(B * N, D, generator=g).to(DEV).to(torch.bfloat16)
     dqkv = torch.empty(B * N, 3 * D, dtype=torch.bfloat16, device=DEV)
     run = lambda: check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(do), P(o), P(dqkv), P(scores), P(dS), B, N, Hh, L.BF16, 0, stream()))
+    if which == "attnfwd":
+        run = lambda: check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(o), P(probs), P(scores), B, N, Hh, L.BF16, 0, stream()))
 else:                                     # plain bf16-out NT GEMM, K = 768 (proj-dX)
     A = torch.randn(M, D, generator=g).to(DEV).to(torch.bfloat16)
     W = (torch.randn(D, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
@@ -69,6 +71,13 @@ if which == "attnbwd":
     assert lib.rmcl_debug_at_trace(buf) == 0
     names = {0: "start", 1: "Q / dO / K staging issued", 2: "delta done (dO, O rows from global)", 3: "K / V fragments in registers", 4: "barrier (images landed)",
              5: "phase 1 done (12 query tiles)", 6: "dK / dV stores issued", 7: "barrier", 8: "phase 2 done (dQ)", 9: "dQ stores issued", 10: "stores drained"}
+elif which == "attnfwd":
+    assert lib.rmcl_debug_at_trace(buf) == 0
+    for w in range(2):                                           # (the forward's stamps sit at 16.. of the same array)
+        for i_ in range(16):
+            buf[w * 32 + i_] = buf[w * 32 + 16 + i_] if i_ < 10 else 0
+    names = {0: "start", 1: "K / V staging issued, mask row filled", 2: "Q fragments issued", 3: "barrier (images landed)", 4: "first query tile done",
+             6: "second query tile done", 8: "output stores issued", 9: "stores drained"}
 elif which in ("fc1", "fc2dx"):
     assert lib.rmcl_debug_sw_trace(buf) == 0
     names = {0: "start", 1: "prologue landed", 2: "k-loop done", 10: "epilogue done", 11: "stores drained"}
@@ -77,7 +86,7 @@ elif which in ("fc1", "fc2dx"):
 else:
     assert lib.rmcl_debug_st_trace(buf) == 0
     names = {0: "start", 1: "prologue landed", 2: "k-loop done", 3: "epi: vectors/rowstat", 4: "epi: barrier", 20: "epilogue done", 21: "stores drained"}
-for ch in range(3 if which not in ("fc1", "fc2dx", "attnbwd") else 0):
+for ch in range(3 if which not in ("fc1", "fc2dx", "attnbwd", "attnfwd") else 0):
     names.update({5 + 4 * ch: f"chunk{ch}: math+LDS write", 6 + 4 * ch: f"chunk{ch}: barrier", 7 + 4 * ch: f"chunk{ch}: read-back+stores issued",
                   8 + 4 * ch: f"chunk{ch}: barrier"})
 for w in range(2):
