@@ -46,8 +46,15 @@ __device__ long long g_st_trace[2][32];
 extern "C" int rmcl_debug_st_trace(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_st_trace), sizeof(long long) * 64);
 }
+__device__ long long g_dw_trace[2][32];
+#define DW_STAMP(i)                                                                                              \
+  if (blockIdx.x == ST_TRACE_WG && (threadIdx.x & 255) == 0) g_dw_trace[threadIdx.x >> 8][i] = wall_clock64()
+extern "C" int rmcl_debug_dw_trace(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dw_trace), sizeof(long long) * 64);
+}
 #else
 #define ST_STAMP(i)
+#define DW_STAMP(i)
 #endif
 
 template <int N>
@@ -306,7 +313,7 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
 // LNF = 1: LayerNorm-folded consumer (EPI_LNFOLD): v = rstd_m * (acc - mean_m * s_n) + c_n, row statistics from the
 //          producer's partials (this group's 96 rows, one thread each, into `rowstat`: 192 x (mean, rstd) in LDS)
 // LNF = 2: producer (EPI_ROWSTAT): bf16 copy of the fp32 output + per-row partial sums of this wave's 48 columns
-template <int AUX, typename TO, bool DROP, int LNF = 0>
+template <int AUX, typename TO, bool DROP, int LNF = 0, bool ACCPRE = false>
 __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const GemmArgs& g, const STTile& T, int wm, int wn, int lane, int wave,
                                                 char* scratch, float* rowstat = nullptr) {
   constexpr int ESZ = sizeof(TO), RI = ESZ == 2 ? 3 : 2, NCH = 6 / RI, ROWS = RI * 16, ROWB = 192 * ESZ, PIECES = ROWB / 16;
@@ -376,6 +383,24 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
   if constexpr (LNF == 1) {                                    // mean / rstd of this lane's six rows, read once
 #pragma unroll
     for (int i = 0; i < 6; ++i) rs[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
+  }
+  // ACCPRE (the weight-gradient launch, C += tile): the OLD values of the whole tile are fetched in ONE batch ahead of the chunk loop.
+  // Inside the store loop every iteration was "LDS read, global load, wait, add, store": 18 serial HBM round trips per tile = 22 us of
+  // epilogue behind a 176 us k-loop (tools/st_trace.py dw); one batch per chunk: 13 us.
+  constexpr int NIT = (ROWS * PIECES + 255) / 256;
+  float4 oldv[ACCPRE ? NCH : 1][ACCPRE ? NIT : 1];
+  if constexpr (ACCPRE && ESZ == 4) {
+    const int tg0 = (wave & 3) * 64 + lane;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int q = it * 256 + tg0, row = q / PIECES, cp = q - row * PIECES;
+        const int m = T.m0 + wm * 96 + ch * ROWS + row;
+        oldv[ch][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < ROWS * PIECES && m < T.m_end)
+          oldv[ch][it] = *reinterpret_cast<const float4*>(C + (long)m * g.ldc + T.n0 + (cp ^ (row & 7)) * 4);
+      }
   }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -459,7 +484,10 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
           TO* dst = C + (long)m * g.ldc + T.n0 + (cp ^ (row & 7)) * (16 / ESZ);
           if constexpr (ESZ == 4) {
             float4 o = w;
-            if (epi & EPI_ACCUM) {
+            if constexpr (ACCPRE) {
+              const float4 old = oldv[ch][q0 / 256];
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            } else if (epi & EPI_ACCUM) {
               const float4 old = *reinterpret_cast<const float4*>(dst);
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
@@ -600,6 +628,7 @@ __global__ __launch_bounds__(512) void gemm_dw_group_kernel(DwGroupArgs a) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  DW_STAMP(0);
   // ---- LayerNorm replica finish: workgroups 0 .. 3*nslots-1, 256 columns each --------------------------------------
   if ((int)blockIdx.x < a.nslots * ((a.D + 255) / 256) && t < 256) {
     const int per = (a.D + 255) / 256, si = blockIdx.x / per, c = (blockIdx.x % per) * 256 + t;
@@ -670,6 +699,7 @@ __global__ __launch_bounds__(512) void gemm_dw_group_kernel(DwGroupArgs a) {
   if (wm == 1) __builtin_amdgcn_s_barrier();                 // skew: group 1 runs one barrier behind group 0
   __builtin_amdgcn_sched_barrier(0);
 
+  DW_STAMP(1);
   f32x4 acc[6][3];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
@@ -710,15 +740,21 @@ __global__ __launch_bounds__(512) void gemm_dw_group_kernel(DwGroupArgs a) {
   if (a.bias[gi] && bias_in == 0) bias_step(smem + sc * ST_STAGE);
   st_tile<2, false, false, 1>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
 
+  DW_STAMP(2);
   STTile T{};
   T.m0 = m0; T.n0 = n0; T.m_end = m0 + ST_T; T.zoff = 0;
-  st_epilogue_lds<ST_AUX_NONE, float, false>(acc, g, T, wm, wn, lane, wave, smem + sc * ST_STAGE + wm * (ST_STAGE / 2));
+  st_epilogue_lds<ST_AUX_NONE, float, false, 0, true>(acc, g, T, wm, wn, lane, wave, smem + sc * ST_STAGE + wm * (ST_STAGE / 2));
+  DW_STAMP(3);
   if (a.bias[gi] && lane < 16) {
     float* bp = a.bias[gi] + m0 + wm * 96 + lane;
     atomicAdd(bp + bi0 * 16, accb[0][0]);
     if (bi1 < 6) atomicAdd(bp + bi1 * 16, accb[1][0]);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
+#ifdef ST_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  DW_STAMP(4);
+#endif
 }
 
 int rmcl_launch_dw_group(const DwGroupArgs& a, hipStream_t s) {

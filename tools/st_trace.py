@@ -1,11 +1,35 @@
 """Phase timeline of ONE workgroup of gemm_st_kernel (developer build: csrc/build.sh with RMCL_EXTRA_FLAGS=-DST_TRACE).
-Usage: python tools/st_trace.py {proj|fc2|qkv|projdx|fc1|fc2dx|attnbwd|attnfwd}   - launches the step's form of that GEMM 5x and prints the last stamps."""
+Usage: python tools/st_trace.py {proj|fc2|qkv|projdx|fc1|fc2dx|attnbwd|attnfwd|dw}   - launches the step's form of that GEMM 5x and prints the last stamps."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tests.gpu_util import L, lib, check, P, I64, F, stream, DEV
 
 which = sys.argv[1] if len(sys.argv) > 1 else "proj"
+if which == "dw":                          # the per-layer weight-gradient launch INSIDE a training step (beside the data-gradient chain)
+    import rmcl_pkg  # noqa: F401
+    from rmcl_amd.vilt.config import task_moco
+    from rmcl_amd.vilt.modules import ViLTransformerSS
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cfg = task_moco(per_gpu_batchsize=64, num_gpus=1, num_nodes=1, adv_steps_img=3, drop_rate=0.0, image_view=True, max_steps=1000, dense_images=True)
+    model = ViLTransformerSS(cfg, device=DEV, compute_dtype="bf16")
+    model.train()
+    (opt,), _ = model.configure_optimizers()
+    batch = bench.synthetic_batch(cfg, 64, 1, DEV)
+    for i in range(3):
+        loss = model.training_step(batch, i); loss.backward(); opt.step(); opt.zero_grad()
+    torch.cuda.synchronize()
+    buf = (ctypes.c_longlong * 64)()
+    assert lib.rmcl_debug_dw_trace(buf) == 0
+    names = {0: "start", 1: "first two k-tiles landed", 2: "k-loop done (185 k-tiles)", 3: "epilogue (+= into the gradient arena)", 4: "stores drained"}
+    for w in range(2):
+        t = [buf[w * 32 + i] for i in range(32)]
+        print(f"--- wave {4 * w} of workgroup 100 of the LAST weight-gradient launch (layer 0) of a step, us")
+        prev = t[0]
+        for i in sorted(names):
+            print(f"  {names[i]:38s} {(t[i] - t[0]) / 100:7.2f}  (+{(t[i] - prev) / 100:.2f})"); prev = t[i]
+    sys.exit(0)
 M, D = 11840, 768
 g = torch.Generator().manual_seed(0)
 if which in ("proj", "fc2"):
