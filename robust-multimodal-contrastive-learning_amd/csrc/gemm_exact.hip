@@ -247,6 +247,11 @@ __global__ __launch_bounds__(256) void gemm_tn_shortk_kernel(GemmArgs g) {
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
   }
   float* C = reinterpret_cast<float*>(g.C);
+  // C += : every old value of the tile is loaded BEFORE the first store.  "load, add, store" per element cannot be reordered by the
+  // compiler (the stores may alias the next loads for all it knows) and ran as 64 serial round trips per lane (tools/st_trace.py
+  // found the same pattern in the weight-gradient launch's epilogue)
+  float oldc[4][4][4];
+  const bool accum = (g.epi & EPI_ACCUM) != 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -254,12 +259,16 @@ __global__ __launch_bounds__(256) void gemm_tn_shortk_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + i * 16 + 4 * gq + r, col = n0 + j * 16 + c;
-        if (row < g.M && col < g.N) {
-          const long ci = (long)row * g.ldc + col;
-          float v = g.alpha * acc[i][j][r];
-          if (g.epi & EPI_ACCUM) v += C[ci];
-          C[ci] = v;
-        }
+        oldc[i][j][r] = (accum && row < g.M && col < g.N) ? C[(long)row * g.ldc + col] : 0.f;
+      }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + i * 16 + 4 * gq + r, col = n0 + j * 16 + c;
+        if (row < g.M && col < g.N) C[(long)row * g.ldc + col] = g.alpha * acc[i][j][r] + oldc[i][j][r];
       }
 }
 
@@ -456,21 +465,34 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g)
       for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * gq + r][ct * 16 + c] = acc[rt][ct][r];
   __syncthreads();
   float* C = reinterpret_cast<float*>(g.C);
-  for (int i = threadIdx.x; i < 64 * NT; i += 64 * NW) {
-    const int rl = i / NT, cl = i % NT, row = m0 + rl, n = n0 + cl;
+  // every global operand of the epilogue (bias, aux, old C) is loaded for ALL of the thread's elements before the first store: in
+  // "load, compute, store" order per element the loads of element i + 1 cannot pass the store of element i (possible alias)
+  constexpr int ITER = NT / NW;                                // 64 * NT elements over 64 * NW threads
+  float bia[ITER], aux[ITER], oldc[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int i = threadIdx.x + it * 64 * NW, rl = i / NT, cl = i % NT, row = m0 + rl, n = n0 + cl;
+    const bool live = row < g.M && n < g.N;
+    bia[it] = (live && (g.epi & EPI_BIAS)) ? g.bias[n] : 0.f;
+    aux[it] = (live && (g.epi & (EPI_DGELU | EPI_RESIDUAL))) ? reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n] : 0.f;
+    oldc[it] = (live && (g.epi & EPI_ACCUM)) ? C[(long)row * g.ldc + n] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const int i = threadIdx.x + it * 64 * NW, rl = i / NT, cl = i % NT, row = m0 + rl, n = n0 + cl;
     if (row >= g.M || n >= g.N) continue;
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) v += red[w][rl][cl];                                              // k order: wave 0 .. NW-1
     v *= g.alpha;
-    if (g.epi & EPI_BIAS) v += g.bias[n];
+    if (g.epi & EPI_BIAS) v += bia[it];
     const long ci = (long)row * g.ldc + n;
     if (g.epi & EPI_SAVE_PREACT) reinterpret_cast<float*>(g.C2)[ci] = v;
     if (g.epi & EPI_GELU) v = gelu_erf(v);
     if (g.epi & EPI_TANH) v = tanhf(v);
-    if (g.epi & EPI_DGELU) v *= gelu_erf_grad(reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n]);
-    if (g.epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n];
-    if (g.epi & EPI_ACCUM) v += C[ci];
+    if (g.epi & EPI_DGELU) v *= gelu_erf_grad(aux[it]);
+    if (g.epi & EPI_RESIDUAL) v += aux[it];
+    if (g.epi & EPI_ACCUM) v += oldc[it];
     C[ci] = v;
   }
 }
