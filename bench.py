@@ -32,6 +32,10 @@ InfoNCE logits, 7F per pair, SURVEY 8d Config 2).
 --gpus N > 1 without a torchrun environment: bench.py launches the N ranks itself (torch.distributed.run as a child
 process, before anything touches the GPU) and exits with the child's code.  A WORLD_SIZE that disagrees with --gpus is an
 error.  The JSON carries the process group's actual size (`world_size`).
+
+Developer switches (never the measured configuration): RMCL_BENCH_SHARE_GPU=1 + RMCL_BENCH_BACKEND=gloo rehearse the N > 1 code
+path with all ranks on cuda:0 (the JSON is marked `rehearsal` and reports `ranks_bit_identical`); RMCL_BENCH_FORCE_DIST=1 runs the
+1-rank RCCL group; RMCL_LIB=<path> loads another build of the library (A/B runs, tools/ab_bench.sh).
 """
 import argparse
 import ctypes as C
