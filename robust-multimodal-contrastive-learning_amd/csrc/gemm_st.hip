@@ -822,7 +822,10 @@ static int launch_st3(const GemmArgs& g, hipStream_t s) {
   const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = A_KC ? cdiv(g.M, tm) : ST_T;
   const int items = tm * tn * (g.splitk > 1 ? g.splitk : 1);
   // M = 64 * 185 gives 62 row tiles: 248 x {1, 3, 4} tiles for N = 768 / 2304 / 3072, so a 248-workgroup grid loses nothing
-  const int grid = min(items, max(8, st_num_cus() - (A_KC ? g_st_reserve_cus : 0)));
+  // the reserved CUs are given up only while that costs no extra round (the patch-embedding data gradient has 768 tiles: 3 rounds of
+  // 256 workgroups, 4 of 248)
+  const int ncu = st_num_cus(), gres = max(8, ncu - (A_KC ? g_st_reserve_cus : 0));
+  const int grid = min(items, cdiv(items, gres) > cdiv(items, ncu) ? ncu : gres);
   // one phase per k-tile measures 4-5 % faster with transposed-read operands (dX, dW), two phases 1.5 % faster for [rows][K] x [cols][K]
   const bool one_phase = ((g_st_xflags & 4) != 0) != (!A_KC || !B_KC);
   if (one_phase) RMCL_LAUNCH((gemm_st_kernel<A_KC, B_KC, AUX, TO, DROP, 1>), dim3(grid), dim3(512), ST_LDS, s, g, tm, tn, rows, g_st_xflags);
