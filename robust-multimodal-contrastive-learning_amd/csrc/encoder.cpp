@@ -441,16 +441,15 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
       // of the buffers the dense path would have filled (x_mid, u, h, ln2, x_final, the LN statistics) - the backward with
       // cls_only = 2 reads them there.
       float* ao_c = reinterpret_cast<float*>(w.dao);          // backward scratch, free during a forward
-      float* x_c = w.dln;
       float* ln2_c = reinterpret_cast<float*>(full ? ls.ln2 : w.ln);
       float* u_c = reinterpret_cast<float*>(keep ? ls.u : w.u);
       float* h_c = reinterpret_cast<float*>(full ? ls.h : w.h);
       float* xo_c = keep ? st.x_final : x_out;
       RMCL_TRY(rmcl_rows_gather_cast(ao, dt, ao_c, B, D, N, 0, s));
-      RMCL_TRY(rmcl_gather_rows(x, x_c, B, D, 1, N, 0, s));
       {
+        // residual operand: the cls rows of the dense residual stream, read in place (row b at b * N * D: no gather launch)
         GemmArgs g = gemm_args(ao_c, c.V(c.L(l, y.proj_w)), x_mid, B, D, D, D, D, D);
-        g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x_c; g.ld_aux = D;
+        g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = N * D;
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
       }
       RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2_c, D, RMCL_F32, m2, r2, B, D, 0, s));
