@@ -134,11 +134,15 @@ int rmcl_heads_forward(const rmcl_dims* d, const float* pool32, const float* hea
   RMCL_TRY(rmcl_gather_rows(xn, h.cls_in, B, D, 1, N, 0, s));                      // hidden_states[:, 0] (heads.py:17)
   {
     GemmArgs g = ga(h.cls_in, pool32 + y.pool_w, h.pooled, B, D, D, D, D, D);
-    g.epi = EPI_BIAS | EPI_TANH; g.bias = pool32 + y.pool_b;
+    g.epi = EPI_BIAS | EPI_TANH | EPI_DUP; g.bias = pool32 + y.pool_b; g.C2 = cls_feats;   // (cls_feats: written by the GEMM, no copy launch)
+    const bool dup = rmcl_gemm_skinny_supported(g, RMCL_F32, RMCL_F32, 1);                  // (only the skinny kernels know EPI_DUP)
+    if (!dup) { g.epi &= ~EPI_DUP; g.C2 = nullptr; }
     RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
+    if (!dup) {
+      hipError_t e = hipMemcpyAsync(cls_feats, h.pooled, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s);
+      if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+    }
   }
-  hipError_t e = hipMemcpyAsync(cls_feats, h.pooled, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s);
-  if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
   if (!q) return 0;
   RMCL_REQUIRE(head32, "heads_forward: head arena is NULL");
   {
@@ -151,9 +155,7 @@ int rmcl_heads_forward(const rmcl_dims* d, const float* pool32, const float* hea
     GemmArgs g = ga(h.h2r, head32 + y.mh3_w, h.z, B, d->proj, D, D, D, d->proj);
     RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
   }
-  RMCL_TRY(rmcl_l2norm_fwd(h.z, h.q, h.nrm, B, d->proj, 1e-12f, s));
-  e = hipMemcpyAsync(q, h.q, (size_t)B * d->proj * 4, hipMemcpyDeviceToDevice, s);
-  if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
+  RMCL_TRY(rmcl_l2norm_fwd(h.z, h.q, h.nrm, B, d->proj, 1e-12f, s, q));
   return 0;
 }
 

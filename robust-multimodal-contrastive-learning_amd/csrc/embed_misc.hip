@@ -709,16 +709,21 @@ int rmcl_enqueue(float* queue, const float* keys, int n, int Pd, long Kq, long p
 // ---------------------------------------------------------------------------------------------
 // Row L2 normalise (F.normalize eps 1e-12) forward / backward, ReLU/tanh backward multiplies
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict__ z, float* __restrict__ q, float* __restrict__ nrm, int D, float eps) {
+__global__ __launch_bounds__(64) void l2norm_fwd_kernel(const float* __restrict__ z, float* __restrict__ q, float* __restrict__ nrm, int D, float eps,
+                                                         float* __restrict__ q2) {
   const int r = blockIdx.x, lane = threadIdx.x;
   float s = 0.f;
   for (int c = lane; c < D; c += 64) { const float v = z[(long)r * D + c]; s += v * v; }
   const float n = fmaxf(sqrtf(wave_sum(s)), eps);
   if (lane == 0 && nrm) nrm[r] = n;
-  for (int c = lane; c < D; c += 64) q[(long)r * D + c] = z[(long)r * D + c] / n;
+  for (int c = lane; c < D; c += 64) {
+    const float v = z[(long)r * D + c] / n;
+    q[(long)r * D + c] = v;
+    if (q2) q2[(long)r * D + c] = v;                         // (second copy: the caller's output next to the stash, no memcpy launch)
+  }
 }
-int rmcl_l2norm_fwd(const float* z, float* q, float* nrm, int R, int D, float eps, hipStream_t s) {
-  RMCL_LAUNCH(l2norm_fwd_kernel, dim3(R), dim3(64), 0, s, z, q, nrm, D, eps);
+int rmcl_l2norm_fwd(const float* z, float* q, float* nrm, int R, int D, float eps, hipStream_t s, float* q2) {
+  RMCL_LAUNCH(l2norm_fwd_kernel, dim3(R), dim3(64), 0, s, z, q, nrm, D, eps, q2);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

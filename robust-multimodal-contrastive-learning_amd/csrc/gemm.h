@@ -28,6 +28,7 @@ enum {
   // LayerNorm folded into the GEMM that consumes it (bf16 192x192 / 192x384 kernels only, N_in = ln_cols):
   //   y = LN(x) W^T + b  =  rstd_m * (bf16(x) W'^T - mean_m * s_n) + c_n,  W' = W * gamma (columns), s_n = sum_k W'_nk, c_n = W beta + b
   EPI_LNFOLD = 2048,    // consumer: A = bf16 copy of the residual stream, B = W'; row statistics from ln_part; per-column ln_s / ln_c
+  EPI_DUP = 8192,       // skinny fp32 GEMMs: the final value is also stored to C2 (same ld as C) - a second consumer's copy without a memcpy launch
   EPI_ROWSTAT = 4096,   // producer (fp32 output = the residual stream): also store its bf16 copy to C2 and per-row partial
                         // (sum, sum of squares) of this tile's columns to ln_part[m][tile_n * 4 + wave column]
 };

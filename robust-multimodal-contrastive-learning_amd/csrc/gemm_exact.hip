@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
       if (g.epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n];
       if (g.epi & EPI_ACCUM) v += C[ci];
       C[ci] = v;
+      if (g.epi & EPI_DUP) reinterpret_cast<float*>(g.C2)[ci] = v;
     }
   }
 }
@@ -494,12 +495,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g)
     if (g.epi & EPI_RESIDUAL) v += aux[it];
     if (g.epi & EPI_ACCUM) v += oldc[it];
     C[ci] = v;
+    if (g.epi & EPI_DUP) reinterpret_cast<float*>(g.C2)[ci] = v;
   }
 }
 
 bool rmcl_gemm_skinny_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc) {
   return a_kc && dt_in == RMCL_F32 && dt_out == RMCL_F32 && g.M <= 1024 && g.K % 16 == 0 && g.K >= 64 && g.splitk <= 1 &&
-         g.nb1 * g.nb2 == 1 && (g.epi & ~(EPI_BIAS | EPI_TANH | EPI_ACCUM | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_RESIDUAL)) == 0 &&
+         g.nb1 * g.nb2 == 1 && (g.epi & ~(EPI_BIAS | EPI_TANH | EPI_ACCUM | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_RESIDUAL | EPI_DUP)) == 0 &&
+         !((g.epi & EPI_DUP) && (g.epi & EPI_SAVE_PREACT)) &&
          !((g.epi & EPI_DGELU) && (g.epi & EPI_RESIDUAL)) && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
          ((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0;
 }
