@@ -250,7 +250,8 @@ int64_t rmcl_infonce_ws_bytes(int B, int64_t Kq);
 int rmcl_infonce_f32(const float* q, const float* k, const float* queue, int B, int proj, int64_t Kq, float temperature,
                      float grad_scale, float* dq, float* rows_out, float* loss_sum, void* workspace, void* stream);
 
-/* PGD ascent step in patch layout (attack/pgd_attack_vilt.py:162-173).  amax_scratch: B uint32.  */
+/* PGD ascent step in patch layout (attack/pgd_attack_vilt.py:162-173).  amax_scratch: 64 * B uint32 (per-block partial maxima of
+ * |grad| per sample; need not be cleared).                                                          */
 int rmcl_pgd_step(const void* grad, int dtype, float* delta, uint32_t* amax_scratch, int B, int64_t per_sample,
                   float lr, float eps, void* stream);
 /* The same step fused with the loop's next operand (attack/pgd_attack_vilt.py:144,162-173): delta is updated in place and, when

@@ -532,14 +532,25 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ g, un
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0)                                      // one atomic per block; non-negative floats order like uints
-    atomicMax(amax_bits + b, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  if (threadIdx.x == 0)                                      // per-block partial (slot blockIdx.x of the sample's 64): no atomics, so
+    amax_bits[b * 64 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));   // no memset launch ahead of it
+}
+// max over the sample's partials (gridDim.x <= 64 of them), floored like pgd_attack_vilt.py:166; every thread of the block calls it
+__device__ __forceinline__ float pgd_den(const unsigned* __restrict__ part, int b, int nb) {
+  __shared__ float sden;
+  if (threadIdx.x < 64) {
+    float m = (int)threadIdx.x < nb ? __uint_as_float(part[b * 64 + threadIdx.x]) : 0.f;
+    m = wave_max(m);
+    if (threadIdx.x == 0) sden = m;
+  }
+  __syncthreads();
+  return fmaxf(sden, 1e-8f);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void pgd_update_kernel(const T* __restrict__ g, const unsigned* __restrict__ amax_bits,
                                                          float* __restrict__ delta, long per_sample, float lr, float eps) {
   const int b = blockIdx.y;
-  const float den = fmaxf(__uint_as_float(amax_bits[b]), 1e-8f);
+  const float den = pgd_den(amax_bits, b, gridDim.x);
   const T* p = g + (long)b * per_sample;
   float* d = delta + (long)b * per_sample;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 1024) {
@@ -555,8 +566,6 @@ __global__ __launch_bounds__(256) void pgd_update_kernel(const T* __restrict__ g
 }
 int rmcl_pgd_update(const void* g, int dt, float* delta, unsigned* amax_bits, int B, long per_sample, float lr, float eps, hipStream_t s) {
   RMCL_REQUIRE(per_sample % 4 == 0, "pgd_update: per_sample%4");
-  hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned) * B, s);
-  if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
   dim3 grid(std::min<long>(cdiv(per_sample, 1024), 64), B);
   if (dt == RMCL_F32) {
     RMCL_LAUNCH(absmax_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, per_sample);
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(256) void pgd_update_fused_kernel(const T* __restri
                                                                float* __restrict__ delta, const float* __restrict__ base,
                                                                TO* __restrict__ out, long per_sample, float lr, float eps) {
   const int b = blockIdx.y;
-  const float den = fmaxf(__uint_as_float(amax_bits[b]), 1e-8f);
+  const float den = pgd_den(amax_bits, b, gridDim.x);
   const long off = (long)b * per_sample;
   for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * 1024) {
     float old[4] = {0.f, 0.f, 0.f, 0.f};
@@ -620,8 +629,6 @@ int rmcl_pgd_update_fused(const void* g, int dt, float* delta, unsigned* amax_bi
                           const float* base, void* out, int dt_out, int flags, hipStream_t s) {
   RMCL_REQUIRE(per_sample % 4 == 0, "pgd_update: per_sample%4");
   RMCL_REQUIRE(!out || base, "pgd_update: an operand output needs the base image");
-  hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned) * B, s);
-  if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
   dim3 grid(std::min<long>(cdiv(per_sample, 1024), 64), B);
   if (dt == RMCL_F32) RMCL_LAUNCH(absmax_kernel<float>, grid, dim3(256), 0, s, (const float*)g, amax_bits, per_sample);
   else RMCL_LAUNCH(absmax_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, amax_bits, per_sample);

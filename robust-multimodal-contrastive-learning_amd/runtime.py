@@ -143,14 +143,16 @@ class PassBuffers:
         self.gpatch = torch.empty(B * d.P, d.patch_k, dtype=tdt, device=dev)
         self.delta = f32(B * d.P, d.patch_k)
         self.delta_prev = f32(B * d.P, d.patch_k)
-        self.amax = torch.empty(B, dtype=torch.int32, device=dev)
+        self.amax = torch.empty(64 * B, dtype=torch.int32, device=dev)      # include/rmcl.h rmcl_pgd_step: 64 partial maxima per sample
         self.cls = f32(B, d.D)
         self.q = f32(B, d.proj)
         self.k = f32(B, d.proj)
         self.dq = f32(B, d.proj)
         self.dcls = f32(B, d.D)
         self.rows = f32(B, 10)
-        self.loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss_ring = torch.zeros(32, dtype=torch.float32, device=dev)    # zeroed scalars for the kernels that ACCUMULATE a loss / norm:
+        self.loss_i = 0                                                      # one fill per 32 uses instead of one per use (zero_scalar)
+        self.loss_sum = self.loss_ring[0:1]
         self.nce_ws = u8(lib.rmcl_infonce_ws_bytes(B, I64(eng.num_negative)))
         self.text_ids = None
         self.text_mask = None
@@ -448,8 +450,19 @@ class Engine:
         check(lib.rmcl_heads_forward(C.byref(pb.d), P(self.q32), P(head), P(pb.xn), P(hst), P(pb.cls), P(out_q),
                                      stream_ptr()), "heads_forward")
 
+    @staticmethod
+    def zero_scalar(pb: PassBuffers) -> torch.Tensor:
+        """A zeroed 1-element fp32 tensor for a kernel that accumulates into it (``pb.loss_sum`` afterwards): the next slot of a
+        pre-zeroed ring - every tiny fill launch on the step's critical path costs ~20 us."""
+        if pb.loss_i == pb.loss_ring.numel():
+            pb.loss_ring.zero_()
+            pb.loss_i = 0
+        pb.loss_sum = pb.loss_ring[pb.loss_i:pb.loss_i + 1]
+        pb.loss_i += 1
+        return pb.loss_sum
+
     def infonce(self, pb: PassBuffers, grad_scale: float, want_dq: bool):
-        pb.loss_sum.zero_()
+        self.zero_scalar(pb)
         check(lib.rmcl_infonce_f32(P(pb.q), P(pb.k), P(self.queue), pb.B, 128, I64(self.num_negative),
                                    F(self.cfg["temperature"]), F(grad_scale), P(pb.dq if want_dq else None), P(pb.rows),
                                    P(pb.loss_sum), P(pb.nce_ws), stream_ptr()), "infonce")

@@ -268,7 +268,7 @@ def compute_moco_contrastive(pl_module, batch):
             prediction_original = clean["prediction"]
         else:
             pl_module.pgd_attacker.attack_patches(pl_module, pb, k, clean_op=op)        # compute_pgd (:319-323)
-        check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3,
+        check(lib.rmcl_delta_channel_norm(P(pb.delta), P(eng.zero_scalar(pb)), I64(pb.delta.shape[0]), 3,
                                           pb.d.patch_k // 3, stream_ptr()), "delta_norm")
         # mean over ALL pixels of the (padded) batch image like torch.linalg.norm(delta, dim=1).mean() (:184); the pad pixels of
         # a zero-padded batch carry delta = 0 and are not stored in the patch layout
@@ -390,7 +390,7 @@ def compute_barlowtwins_contrastive(pl_module, batch):
         views.append(("txt", "text"))
     if pl_module.image_view:                                                    # :500-525
         pl_module.pgd_attacker.attack_patches(pl_module, pb, zk, clean_op=op)   # compute_pgd (:503)
-        check(lib.rmcl_delta_channel_norm(P(pb.delta), P(pb.loss_sum.zero_()), I64(pb.delta.shape[0]), 3, pb.d.patch_k // 3,
+        check(lib.rmcl_delta_channel_norm(P(pb.delta), P(eng.zero_scalar(pb)), I64(pb.delta.shape[0]), 3, pb.d.patch_k // 3,
                                           stream_ptr()), "delta_norm")
         n_pix = pb.delta.numel() // 3 if pb.geom is None else pb.B * pb.geom.shape[2] * pb.geom.shape[3]
         pl_module.log(f"barlowtwins_attack/{phase}/delta", _scalar(pb.loss_sum / float(n_pix)))

@@ -198,7 +198,7 @@ def test_pgd_step(dt):
     g[2] = 0                                                       # all-zero gradient: 1e-8 floor, delta unchanged
     delta0 = (rnd(B, per, seed=2) * 0.002).clamp(-0.005, 0.005)
     delta = delta0.clone()
-    amax = torch.empty(B, dtype=torch.int32, device=DEV)
+    amax = torch.empty(64 * B, dtype=torch.int32, device=DEV)
     check(lib.rmcl_pgd_step(P(g), dt, P(delta), P(amax), B, I64(per), F(0.05), F(0.005), stream()))
     gf = g.float()
     den = gf.abs().amax(dim=1, keepdim=True).clamp_min(1e-8)
@@ -215,7 +215,7 @@ def test_pgd_step_fused(dt, odt):
     g[2] = 0
     base = rnd(B, per, seed=3)
     delta0 = (rnd(B, per, seed=2) * 0.002).clamp(-0.005, 0.005)
-    amax = torch.empty(B, dtype=torch.int32, device=DEV)
+    amax = torch.empty(64 * B, dtype=torch.int32, device=DEV)
     ref = delta0.clone()
     check(lib.rmcl_pgd_step(P(g), dt, P(ref), P(amax), B, I64(per), F(0.05), F(0.005), stream()))
     for flags in (0, L.PGD_SUM_PREV, L.PGD_DELTA_ZERO, L.PGD_DELTA_ZERO | L.PGD_SUM_PREV):
