@@ -207,6 +207,7 @@ def compute_moco_contrastive(pl_module, batch):
     # are independent: they run on two HIP streams so each fills the other's tile-quantisation tails.
     pk = eng.twin(pb, "key")
     pk.text_ids, pk.text_mask = pb.text_ids, pb.text_mask
+    pk.k = pb.k                            # the key head writes the keys where the query passes read them (no copy launch after the join)
     main = torch.cuda.current_stream()
     side = eng.side_stream
     if eng.lp_stale:                       # (after a checkpoint load / manual weight edit) refresh the bf16 shadows on the MAIN
@@ -222,9 +223,8 @@ def compute_moco_contrastive(pl_module, batch):
 
     def join_key_stream():
         main.wait_stream(side)
-        pb.k.copy_(pk.k)
-        # asynchronous key all-gather (RCCL's own stream): overlaps everything until the enqueue
-        gather_box["g"] = dist_utils.KeyGather(pb.k.clone()) if pl_module.training else None
+        # asynchronous key all-gather (RCCL's own stream): overlaps everything until the enqueue (one rank: the keys themselves)
+        gather_box["g"] = dist_utils.KeyGather(pb.k.clone() if dist_utils.world_size() > 1 else pb.k) if pl_module.training else None
 
     k = pb.k
     # PGD step 0 runs the query encoder on img + delta_0 = img: with dropout off that IS the clean query forward
