@@ -78,8 +78,9 @@ def _attacked_view(pl_module, pv, op, k, suffix, success_name, prediction_origin
     rows = pv.rows
     if phase == "train" and success_name is not None:
         pl_module.log(f"moco_attack/{success_name}", (rows[:, 1] != prediction_original).float().mean())
+    means = rows.mean(dim=0)                           # one reduction launch for the six batch means (the values are views of it)
     for j, name in ((3, "pos_dist"), (4, "pos_cosine"), (5, "pos_dot"), (6, "neg_dist"), (7, "neg_cosine"), (8, "neg_dot")):
-        ret[f"{name}_attacked_{suffix}"] = rows[:, j].mean()
+        ret[f"{name}_attacked_{suffix}"] = means[j]
     ret[f"q_{suffix}_attack"] = pv.q.clone()
     value = _scalar(pv.loss_sum.clone())
     if not need_grad:
