@@ -238,6 +238,11 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
  * moco head (query or momentum).  Outputs cls_feats [B,D] and q [B,proj] (f32).                  */
 int rmcl_heads_forward(const rmcl_dims* d, const float* pool32, const float* head32, const float* xn,
                        void* hstash, float* cls_feats, float* q, void* stream);
+/* The same with flags.  RMCL_HEADS_NO_WGRAD: the matching rmcl_heads_backward will be called with grads32 = NULL (key pass, PGD
+ * and text-attack passes: data gradients only) - the pooler input is then not stashed and one launch less is issued.         */
+#define RMCL_HEADS_NO_WGRAD 1
+int rmcl_heads_forward2(const rmcl_dims* d, const float* pool32, const float* head32, const float* xn,
+                        void* hstash, float* cls_feats, float* q, int flags, void* stream);
 /* dq [B,proj] (may be NULL) and dcls_extra [B,D] (may be NULL, e.g. from the ITM head) -> dcls [B,D];
  * grads32 (may be NULL) accumulates pooler and moco-head weight gradients.                       */
 int rmcl_heads_backward(const rmcl_dims* d, const float* pool32, const float* head32, void* hstash,

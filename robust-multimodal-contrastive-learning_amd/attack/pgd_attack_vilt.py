@@ -49,7 +49,7 @@ class PGDAttack_moco(PGDAttack):
         for step in range(K):
             last = step == K - 1
             eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
-            eng.heads_forward(pb, key=False)
+            eng.heads_forward(pb, key=False, wgrad=False)
             if step == 0 and before_first_loss is not None:
                 before_first_loss()
             # CE(label 0) / K, mean over the batch (:152-158); gradient wrt q only
@@ -97,7 +97,7 @@ class PGDAttack_bartlowtwins(PGDAttack):
         for step in range(K):
             last = step == K - 1
             eng.encoder_forward(pb, key=False, mode=L.MODE_DATA, patchesT=op, cls_tail=True)
-            eng.heads_forward(pb, key=False, want_q=False)
+            eng.heads_forward(pb, key=False, want_q=False, wgrad=False)
             eng.bt_forward(bb, pb.cls, training=mode, track=False)
             eng.bt_loss(bb, zk, float(pb.B), pl_module.adv_lr, 1.0 / K, want_dz=True)
             dcls = eng.bt_backward(bb, bb.dz, training=mode, with_grads=False)

@@ -124,16 +124,25 @@ int64_t rmcl_heads_stash_bytes(const rmcl_dims* d) { return (int64_t)carve_heads
 
 int rmcl_heads_forward(const rmcl_dims* d, const float* pool32, const float* head32, const float* xn, void* hstash,
                        float* cls_feats, float* q, void* stream) {
+  return rmcl_heads_forward2(d, pool32, head32, xn, hstash, cls_feats, q, 0, stream);
+}
+int rmcl_heads_forward2(const rmcl_dims* d, const float* pool32, const float* head32, const float* xn, void* hstash,
+                        float* cls_feats, float* q, int flags, void* stream) {
   RMCL_REQUIRE(d && pool32 && xn && hstash && cls_feats, "heads_forward: NULL argument");
+  RMCL_REQUIRE((flags & ~RMCL_HEADS_NO_WGRAD) == 0, "heads_forward: unknown flag");
   rmcl_layout y;
   rmcl_param_layout(d, &y);
   HeadStash h;
   carve_heads(*d, hstash, &h);
   hipStream_t s = (hipStream_t)stream;
   const int B = d->B, D = d->D, N = d->L + 1 + d->P;
-  RMCL_TRY(rmcl_gather_rows(xn, h.cls_in, B, D, 1, N, 0, s));                      // hidden_states[:, 0] (heads.py:17)
+  // hidden_states[:, 0] (heads.py:17): a compact copy for the pooler's weight gradient - or, when the matching backward forms none
+  // (key pass, PGD passes), the pooler GEMM reads the rows in place (row stride N * D) and the gather launch is not issued
+  const bool stash_in = !(flags & RMCL_HEADS_NO_WGRAD);
+  if (stash_in) RMCL_TRY(rmcl_gather_rows(xn, h.cls_in, B, D, 1, N, 0, s));
   {
-    GemmArgs g = ga(h.cls_in, pool32 + y.pool_w, h.pooled, B, D, D, D, D, D);
+    GemmArgs g = stash_in ? ga(h.cls_in, pool32 + y.pool_w, h.pooled, B, D, D, D, D, D)
+                          : ga(xn, pool32 + y.pool_w, h.pooled, B, D, D, N * D, D, D);
     g.epi = EPI_BIAS | EPI_TANH | EPI_DUP; g.bias = pool32 + y.pool_b; g.C2 = cls_feats;   // (cls_feats: written by the GEMM, no copy launch)
     const bool dup = rmcl_gemm_skinny_supported(g, RMCL_F32, RMCL_F32, 1);                  // (only the skinny kernels know EPI_DUP)
     if (!dup) { g.epi &= ~EPI_DUP; g.C2 = nullptr; }

@@ -443,12 +443,15 @@ class Engine:
                                        self.fold_of(key) if (mode != L.MODE_FULL and pb.dtype == L.BF16) else None, stream_ptr()),
               "encoder_forward")
 
-    def heads_forward(self, pb: PassBuffers, key: bool, want_q: bool = True):
+    def heads_forward(self, pb: PassBuffers, key: bool, want_q: bool = True, wgrad: bool = True):
+        """wgrad=False: the matching heads_backward runs with_grads=False (or not at all): the pooler input is not stashed."""
         head = self.k32 if key else self.q32
         hst = pb.hstash_k if key else pb.hstash_q
         out_q = (pb.k if key else pb.q) if want_q else None
-        check(lib.rmcl_heads_forward(C.byref(pb.d), P(self.q32), P(head), P(pb.xn), P(hst), P(pb.cls), P(out_q),
-                                     stream_ptr()), "heads_forward")
+        if not key:
+            pb.heads_wgrad = bool(wgrad)
+        check(lib.rmcl_heads_forward2(C.byref(pb.d), P(self.q32), P(head), P(pb.xn), P(hst), P(pb.cls), P(out_q),
+                                      0 if wgrad else L.HEADS_NO_WGRAD, stream_ptr()), "heads_forward")
 
     @staticmethod
     def zero_scalar(pb: PassBuffers) -> torch.Tensor:
@@ -468,6 +471,8 @@ class Engine:
                                    P(pb.loss_sum), P(pb.nce_ws), stream_ptr()), "infonce")
 
     def heads_backward(self, pb: PassBuffers, dq, dcls_extra, with_grads: bool):
+        if with_grads and not getattr(pb, "heads_wgrad", True):
+            raise L.RmclError("heads_backward(with_grads=True) after heads_forward(wgrad=False): the pooler input was not stashed")
         check(lib.rmcl_heads_backward(C.byref(pb.d), P(self.q32), P(self.q32), P(pb.hstash_q), P(dq), P(dcls_extra),
                                       P(pb.dcls), P(self.g32 if with_grads else None), P(pb.workspace), stream_ptr()),
               "heads_backward")

@@ -219,7 +219,7 @@ def compute_moco_contrastive(pl_module, batch):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op, cls_tail=True)
-        eng.heads_forward(pk, key=True)
+        eng.heads_forward(pk, key=True, wgrad=False)
     gather_box = {}
 
     def join_key_stream():
