@@ -199,8 +199,10 @@ int rmcl_heads_backward(const rmcl_dims* d, const float* pool32, const float* he
     if (G) {
       GemmArgs g = ga(t2, h.pooled, G + y.mh0_w, D, D, B, D, D, D);                      // dW0 += dh1^T pooled
       g.epi = EPI_ACCUM;
+      const bool cs = rmcl_gemm_tn_shortk_takes(g);                                      // bias gradient as a by-product of the same launch
+      if (cs) { g.epi |= EPI_COLSUM; g.colsum = G + y.mh0_b; }
       RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
-      RMCL_TRY(rmcl_colsum(t2, D, RMCL_F32, G + y.mh0_b, B, D, s));
+      if (!cs) RMCL_TRY(rmcl_colsum(t2, D, RMCL_F32, G + y.mh0_b, B, D, s));
     }
     {
       GemmArgs g = ga(t2, head32 + y.mh0_w, t0, B, D, D, D, D, D);                       // dpooled = dh1 W0
@@ -216,8 +218,10 @@ int rmcl_heads_backward(const rmcl_dims* d, const float* pool32, const float* he
   if (G) {
     GemmArgs g = ga(t0, h.cls_in, G + y.pool_w, D, D, B, D, D, D);                        // dWp += dpre^T cls_in
     g.epi = EPI_ACCUM;
+    const bool cs = rmcl_gemm_tn_shortk_takes(g);
+    if (cs) { g.epi |= EPI_COLSUM; g.colsum = G + y.pool_b; }
     RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
-    RMCL_TRY(rmcl_colsum(t0, D, RMCL_F32, G + y.pool_b, B, D, s));
+    if (!cs) RMCL_TRY(rmcl_colsum(t0, D, RMCL_F32, G + y.pool_b, B, D, s));
   }
   {
     GemmArgs g = ga(t0, pool32 + y.pool_w, dcls, B, D, D, D, D, D);                       // dcls = dpre Wp

@@ -601,8 +601,10 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       if (full) {
         GemmArgs g = gemm_args(dxc, h_c, Gp(c.L(l, y.fc2_w)), D, mlp, B, D, mlp, mlp);                   // dW2 += dx^T h
         g.epi = EPI_ACCUM;
+        const bool cs = rmcl_gemm_tn_shortk_takes(g);                                                    // bias gradient from the same launch
+        if (cs) { g.epi |= EPI_COLSUM; g.colsum = Gp(c.L(l, y.fc2_b)); }
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
-        RMCL_TRY(rmcl_colsum(dxc, D, RMCL_F32, Gp(c.L(l, y.fc2_b)), B, D, s));
+        if (!cs) RMCL_TRY(rmcl_colsum(dxc, D, RMCL_F32, Gp(c.L(l, y.fc2_b)), B, D, s));
       }
       {
         GemmArgs g = gemm_args(du_c, c.V(c.L(l, y.fc1_w)), dln_c, B, D, mlp, mlp, D, D);                 // dln2 = du W1
@@ -611,8 +613,10 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       if (full) {
         GemmArgs g = gemm_args(du_c, ln2_c, Gp(c.L(l, y.fc1_w)), mlp, D, B, mlp, D, D);                  // dW1 += du^T ln2
         g.epi = EPI_ACCUM;
+        const bool cs = rmcl_gemm_tn_shortk_takes(g);
+        if (cs) { g.epi |= EPI_COLSUM; g.colsum = Gp(c.L(l, y.fc1_b)); }
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
-        RMCL_TRY(rmcl_colsum(du_c, mlp, RMCL_F32, Gp(c.L(l, y.fc1_b)), B, mlp, s));
+        if (!cs) RMCL_TRY(rmcl_colsum(du_c, mlp, RMCL_F32, Gp(c.L(l, y.fc1_b)), B, mlp, s));
       }
       RMCL_TRY(rmcl_ln_bwd(dln_c, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), dxc, D, 1,
                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, B, D, 0, s));   // dxc = d x_mid
@@ -624,8 +628,10 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
         RMCL_TRY(rmcl_rows_gather_cast(ls.ao, dt, ao_c, B, D, N, 0, s));
         GemmArgs g = gemm_args(dxc, ao_c, Gp(c.L(l, y.proj_w)), D, D, B, D, D, D);                       // dWproj += dx^T ao
         g.epi = EPI_ACCUM;
+        const bool cs = rmcl_gemm_tn_shortk_takes(g);
+        if (cs) { g.epi |= EPI_COLSUM; g.colsum = Gp(c.L(l, y.proj_b)); }
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
-        RMCL_TRY(rmcl_colsum(dxc, D, RMCL_F32, Gp(c.L(l, y.proj_b)), B, D, s));
+        if (!cs) RMCL_TRY(rmcl_colsum(dxc, D, RMCL_F32, Gp(c.L(l, y.proj_b)), B, D, s));
       }
       HIP_TRY(hipMemsetAsync(w.dx, 0, (size_t)M * D * sizeof(float), s));
       RMCL_TRY(rmcl_scatter_rows(dxc, w.dx, B, D, 1, N, 0, 0, s));

@@ -226,6 +226,10 @@ __global__ __launch_bounds__(256) void gemm_tn_shortk_kernel(GemmArgs g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // EPI_COLSUM: column sums of A over k (= the bias gradient that goes with this weight gradient) as a by-product of the operand
+  // loads, written by the waves of the first column block (n0 == 0: one writer per column m) - no separate column-sum launch
+  const bool want_cs = (g.epi & EPI_COLSUM) && n0 == 0;
+  float sa[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < g.K; k0 += 8) {                    // two 4-k steps per trip, all 16 loads in flight before the MFMAs
     float a[2][4], b[2][4];
 #pragma unroll
@@ -245,6 +249,18 @@ __global__ __launch_bounds__(256) void gemm_tn_shortk_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sa[t] += a[0][t] + a[1][t];     // (rows past K were loaded as 0)
+  }
+  if (want_cs) {                                             // lane (c, gq) holds the rows k = gq (mod 4): sum over the four lane groups
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float v = sa[t];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int m = m0 + t * 16 + c;
+      if (gq == 0 && m < g.M) g.colsum[m] += v;
+    }
   }
   float* C = reinterpret_cast<float*>(g.C);
   // C += : every old value of the tile is loaded BEFORE the first store.  "load, add, store" per element cannot be reordered by the
@@ -272,10 +288,16 @@ __global__ __launch_bounds__(256) void gemm_tn_shortk_kernel(GemmArgs g) {
       }
 }
 
+// true when rmcl_launch_gemm_exact(g, f32, f32, a_kc = 0, b_kc = 0) runs the short-K kernel, the only one that knows EPI_COLSUM
+bool rmcl_gemm_tn_shortk_takes(const GemmArgs& g) {
+  return g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K >= 1 && g.K <= 256 && g.splitk <= 1 && g.nb1 * g.nb2 == 1 &&
+         (g.epi & ~(EPI_ACCUM | EPI_COLSUM)) == 0 && g_skinny_form != 0;
+}
+
 int rmcl_launch_gemm_exact(const GemmArgs& g, int dt_in, int dt_out, int a_kc, int b_kc, hipStream_t s) {
   if (g.A && g.B && g.C && g.M > 0 && g.N > 0 && rmcl_gemm_skinny_supported(g, dt_in, dt_out, a_kc)) return rmcl_launch_gemm_skinny(g, b_kc, s);
   if (g.A && g.B && g.C && g.M > 0 && g.N > 0 && !a_kc && !b_kc && dt_in == RMCL_F32 && dt_out == RMCL_F32 && g.K >= 1 && g.K <= 256 &&
-      g.splitk <= 1 && g.nb1 * g.nb2 == 1 && (g.epi & ~EPI_ACCUM) == 0 && g_skinny_form != 0) {
+      g.splitk <= 1 && g.nb1 * g.nb2 == 1 && (g.epi & ~(EPI_ACCUM | EPI_COLSUM)) == 0 && (!(g.epi & EPI_COLSUM) || g.colsum) && g_skinny_form != 0) {
     RMCL_LAUNCH(gemm_tn_shortk_kernel, dim3(cdiv(g.N, 128), cdiv(g.M, 128)), dim3(256), 0, s, g);
     RMCL_CHECK_LAUNCH();
     return 0;

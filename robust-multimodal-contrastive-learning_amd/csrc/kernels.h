@@ -87,6 +87,7 @@ int rmcl_pgd_update_fused(const void* g, int dt, float* delta, unsigned* amax_bi
 int rmcl_delta_chan_norm(const float* d, float* out, long rows, int C, int pp, hipStream_t s);
 int rmcl_ema(float* k, const float* q, void* k_lp, float m, long n, hipStream_t s);
 int rmcl_enqueue(float* queue, const float* keys, int n, int Pd, long Kq, long ptr, hipStream_t s);
+bool rmcl_gemm_tn_shortk_takes(const GemmArgs& g);                                              // (gemm_exact.hip)
 bool rmcl_gemm_skinny_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc);     // (gemm_exact.hip)
 int rmcl_l2norm_fwd(const float* z, float* q, float* nrm, int R, int D, float eps, hipStream_t s, float* q2 = nullptr);
 int rmcl_l2norm_bwd(const float* dq, const float* q, const float* nrm, float* dz, int R, int D, hipStream_t s);
