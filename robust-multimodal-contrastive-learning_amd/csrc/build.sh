@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT" obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast $RMCL_EXTRA_FLAGS"   # (developer builds: e.g. RMCL_EXTRA_FLAGS=-DST_TRACE, tools/st_trace.py)
-SRCS="gemm_exact.hip gemm_fast.hip gemm_big.hip gemm_pp.hip gemm_st.hip gemm_sw.hip norm_softmax.hip embed_misc.hip infonce.hip ipot.hip itm.hip attention.hip barlow.hip encoder.cpp api.cpp"
+SRCS="gemm_exact.hip gemm_fast.hip gemm_big.hip gemm_pp.hip gemm_st.hip gemm_sw.hip gemm_dp.hip norm_softmax.hip embed_misc.hip infonce.hip ipot.hip itm.hip attention.hip barlow.hip encoder.cpp api.cpp"
 pids=()
 objs=()
 for f in $SRCS; do

@@ -327,7 +327,12 @@ int rmcl_launch_gemm_big(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipS
 
 // true when rmcl_launch_gemm_fast sends this GEMM to the 192x384 or the 192x192 kernel (the only ones that implement the
 // LayerNorm-folded epilogues EPI_LNFOLD / EPI_ROWSTAT)
+int rmcl_launch_gemm_dp(const GemmArgs& g, int dt_out, hipStream_t s);
+bool rmcl_gemm_dp_supported(const GemmArgs& g, int a_kc, int b_kc);
+double rmcl_gemm_dp_fill(const GemmArgs& g, int cus);
+
 bool rmcl_gemm_routes_to_tile192(const GemmArgs& g, int a_kc, int b_kc) {
+  if (g_gemm_cfg == 80 && rmcl_gemm_dp_supported(g, a_kc, b_kc)) return true;
   if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc)) return true;
   if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc)) return true;
   return false;
@@ -337,6 +342,8 @@ int rmcl_launch_gemm_fast(const GemmArgs& g0, int dt_out, int a_kc, int b_kc, hi
   GemmArgs g = g0;
   RMCL_REQUIRE(!(g.epi & (EPI_LNFOLD | EPI_ROWSTAT)) || rmcl_gemm_routes_to_tile192(g, a_kc, b_kc),
                "gemm: the LayerNorm-folded epilogues exist in the 192-row tile kernels only");
+  // 192x192x32 tiles, two 4-wave workgroups per CU (gemm_dp.hip)
+  if (g_gemm_cfg == 80 && rmcl_gemm_dp_supported(g, a_kc, b_kc) && !((g.epi & EPI_RESIDUAL) && dt_out != RMCL_F32)) return rmcl_launch_gemm_dp(g, dt_out, s);
   // 192x384 tiles where they make exact rounds (N = 3072 at M = 64*185: 496 tiles = 2 x 248)
   if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc))
     return rmcl_launch_gemm_sw(g, dt_out, b_kc, s);

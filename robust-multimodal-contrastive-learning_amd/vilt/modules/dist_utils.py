@@ -13,6 +13,47 @@ import torch
 import torch.distributed as dist
 
 
+class StepTimers:
+    """Event brackets around the step's two waits on communication (bench.py --gpus N reports them per step so that a scaling
+    run explains itself): `comm_exposed` = how long the main stream stood still in the optimizer's wait for the gradient
+    all-reduces, `key_gather_wait` = the same for the key all-gather at the enqueue.  Off unless bench.py switches it on; CUDA
+    streams only (two event records per wait, no host synchronisation)."""
+    enabled = False
+    pairs: dict = {}
+    info: dict = {}
+
+    @classmethod
+    def reset(cls):
+        cls.pairs = {}
+
+    class _Bracket:
+        def __init__(self, name):
+            self.name = name
+            self.e0 = None
+
+        def __enter__(self):
+            if StepTimers.enabled and torch.cuda.is_available():
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.e0 is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                StepTimers.pairs.setdefault(self.name, []).append((self.e0, e1))
+            return False
+
+    @classmethod
+    def bracket(cls, name):
+        return cls._Bracket(name)
+
+    @classmethod
+    def totals_ms(cls) -> dict:
+        """Sum of the bracketed stream time per name (call after a device synchronise)."""
+        return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in cls.pairs.items()}
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -40,7 +81,8 @@ class KeyGather:
 
     def wait(self) -> torch.Tensor:
         if self.work is not None:
-            self.work.wait()
+            with StepTimers.bracket("key_gather_wait"):
+                self.work.wait()
             self.work = None
         return self.out
 
@@ -185,6 +227,9 @@ class GradSync:
         self.works = []
         self.unpack = []                       # (bf16 buffer, fp32 destination) pairs copied back in wait()
         self.comm_stream = comm_stream if flat.is_cuda else None
+        StepTimers.info["grad_sync"] = {"mode": "overlapped per-layer buckets", "algo": algo, "wire": compress or "f32", "buckets": len(buckets),
+                                        "bucket_bytes_max": 4 * max((e - s) for _, s, e in buckets) if buckets else 0,
+                                        "bytes_total": 4 * sum((e - s) for _, s, e in buckets)}
         if not (dist.is_available() and dist.is_initialized()):
             return
         ws = world_size()
@@ -256,7 +301,13 @@ class StepGradSync:
         return 1.0 / world_size()
 
     def closure_done(self, flat: torch.Tensor, enabled: bool = True, overlap=None):
-        self.open = max(0, self.open - 1)
+        if self.open <= 0:
+            # two forwards before their backwards: begin_step() of the second forgot the first one's closure, the first backward
+            # has already reduced the arena, and this one would add the summed arena over the ranks again (gradients x world size)
+            raise RuntimeError("StepGradSync: a deferred backward ran that the current step did not register - a loss of an EARLIER "
+                               "forward was back-propagated after the next forward began; run every loss.backward() of a step before "
+                               "the next training_step (or accumulate with sync_grads=False)")
+        self.open -= 1
         if self.open > 0 or not enabled:
             return
         if not (dist.is_available() and dist.is_initialized()):
@@ -265,10 +316,14 @@ class StepGradSync:
         if overlap is not None and self.created == 1:
             self.handle = overlap()
         else:
-            allreduce_sum_(flat, force=True, algo=self.algo,
-                           wire=torch.bfloat16 if (self.algo == "direct" and self.compress == "bf16") else None)
+            StepTimers.info["grad_sync"] = {"mode": "one blocking pass", "algo": self.algo, "wire": self.compress or "f32",
+                                            "buckets": -(-flat.numel() // (32 * 1024 * 1024)), "bytes_total": 4 * flat.numel()}
+            with StepTimers.bracket("comm_exposed"):         # blocking pass on the compute stream: all of it is exposed
+                allreduce_sum_(flat, force=True, algo=self.algo,
+                               wire=torch.bfloat16 if (self.algo == "direct" and self.compress == "bf16") else None)
 
     def wait(self):
         if self.handle is not None:
-            self.handle.wait()
+            with StepTimers.bracket("comm_exposed"):
+                self.handle.wait()
             self.handle = None

@@ -435,6 +435,74 @@ def test_gemm_pingpong_kernels_are_run_to_run_deterministic(cfg, N):
         lib.rmcl_tune_set(0, -1)
 
 
+def test_gemm_dual_tile_epilogues_match_exact_kernel():
+    """The 192x192x32 kernel with two 4-wave workgroups per CU (gemm_dp.hip, tune cfg 80) against the exact-f32 kernel: every
+    epilogue it takes, ragged last row tile (M = 2 * 185 + 7), K = 320 = 10 k-steps of 32."""
+    M, N, K = 377, 384, 320
+    X, W, b = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2, scale=0.1).to(torch.bfloat16), rnd(N, seed=3)
+    R = rnd(M, N, seed=4)
+    U = rnd(M, N, seed=6).to(torch.bfloat16)
+    cases = [(0, dict(), (L.F32, L.BF16)), (1, dict(bias=b), (L.F32, L.BF16)), (1 | 2 | 4, dict(bias=b, want_c2=True), (L.F32, L.BF16)),
+             (1 | 8, dict(bias=b, aux=R, ld_aux=N), (L.F32,)), (16, dict(aux=U, ld_aux=N), (L.F32, L.BF16))]
+    try:
+        for epi, kw, dtos in cases:
+            for dto in dtos:
+                lib.rmcl_tune_set(0, -1)
+                a = gemm(X, W, M, N, K, 1, 1, L.BF16, dto, epi=epi, exact=1, **kw)
+                lib.rmcl_tune_set(0, 80)
+                f = gemm(X, W, M, N, K, 1, 1, L.BF16, dto, epi=epi, exact=0, **kw)
+                a, f = (a, f) if isinstance(a, tuple) else ((a,), (f,))
+                tol = 2e-4 if epi & (2 | 16) else 2e-5
+                for x, y in zip(a, f):
+                    assert rel_err(y, x) < (tol if dto == L.F32 else 1e-2), (epi, dto)
+    finally:
+        lib.rmcl_tune_set(0, -1)
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_gemm_dual_tile_random_shapes(seed):
+    """gemm_dp.hip (cfg 80) on random shapes: ragged row tiles (any M >= 1), the shortest k-loops (K = 64: two k-steps), one tile,
+    fewer tiles than workgroups, and several tiles per workgroup (the k-step stream across tiles); fp64 reference."""
+    import random
+    rng = random.Random(2000 + seed)
+    M = rng.choice([1, 7, 185, 191, 192, 193, 370, 555, 1000, 2368, rng.randint(1, 3000)])
+    N = 192 * rng.choice([1, 2, 4, 6, 8, 12])
+    K = 32 * rng.choice([2, 3, 4, 5, 12, 13, 24, 25])
+    if seed % 3 == 2:
+        M = 192 * rng.choice([40, 62, 70])
+        N = 192 * rng.choice([8, 12, 16])
+        K = 32 * rng.choice([2, 3, 8])
+    X = rnd(M, K, seed=seed).to(torch.bfloat16)
+    W = rnd(N, K, seed=seed + 50, scale=0.05).to(torch.bfloat16)
+    b = rnd(N, seed=seed + 99)
+    ref = X.double() @ W.double().t() + b.double()
+    try:
+        lib.rmcl_tune_set(0, 80)
+        out = gemm(X, W, M, N, K, 1, 1, L.BF16, L.F32, bias=b, epi=1, exact=0)
+        assert rel_err(out, ref) < 2e-5, ("f32", M, N, K)
+        out = gemm(X, W, M, N, K, 1, 1, L.BF16, L.BF16, bias=b, epi=1, exact=0)
+        assert rel_err(out, ref) < 1e-2, ("bf16", M, N, K)
+    finally:
+        lib.rmcl_tune_set(0, -1)
+
+
+@pytest.mark.parametrize("N,K", [(2304, 768), (3072, 768), (768, 3072)])
+def test_gemm_dual_tile_is_run_to_run_deterministic(N, K):
+    """Counted vmcnt + one barrier per k-step order the LDS-DMA against the fragment reads; a mis-placed wait shows as rare torn
+    tiles, and here two workgroups per CU drift against each other: the step's launches repeated, bitwise identical every time."""
+    M = 11840
+    X = rnd(M, K, seed=3).to(torch.bfloat16)
+    W = rnd(N, K, seed=4, scale=0.05).to(torch.bfloat16)
+    try:
+        lib.rmcl_tune_set(0, 80)
+        first = gemm(X, W, M, N, K, 1, 1, L.BF16, L.BF16, exact=0)
+        for _ in range(15):
+            assert torch.equal(first, gemm(X, W, M, N, K, 1, 1, L.BF16, L.BF16, exact=0))
+        assert rel_err(first, X.double() @ W.double().t()) < 1e-2
+    finally:
+        lib.rmcl_tune_set(0, -1)
+
+
 def test_grad_ready_wait_rejects_bad_layers():
     """rmcl_grad_ready_wait: error codes, never a crash (layers beyond the last backward's depth / negative)."""
     import ctypes as C
@@ -488,12 +556,14 @@ def test_gemm_skinny_epilogues_and_forms(form):
 
 
 # ------------------------------------------------------------------------- LayerNorm folded into the consuming GEMM
+@pytest.mark.parametrize("cfg", [-1, 80])
 @pytest.mark.parametrize("N2,gelu", [(2304, 0), (3072, 1)])
-def test_layernorm_fold_gemm_pair_matches_layernorm_then_linear(N2, gelu):
+def test_layernorm_fold_gemm_pair_matches_layernorm_then_linear(N2, gelu, cfg):
     """Producer (fp32 output + residual, bf16 copy, per-row partial sums) and consumer (rstd * (xb W'^T - mean * s) + c) of
     the LayerNorm fold at the step's shapes, against  LN(y) W2^T + b2  (then GELU) computed in fp64 from the producer's
     own fp32 output."""
     M, D, K1 = 11840, 768, 768
+    lib.rmcl_tune_set(0, cfg)                                    # 80: both GEMMs on gemm_dp.hip (two 4-wave workgroups per CU)
     A = rnd(M, K1, seed=1).to(torch.bfloat16)
     W1 = rnd(D, K1, seed=2, scale=0.05).to(torch.bfloat16)
     b1 = rnd(D, seed=3)
@@ -519,6 +589,7 @@ def test_layernorm_fold_gemm_pair_matches_layernorm_then_linear(N2, gelu):
     mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
     check(lib.rmcl_linear_lnfold(P(outb), P(wf), P(s), P(c), P(part), nparts, P(o2), P(pre), M, N2, D, gelu, F(1e-6), P(mean), P(rstd),
                                  stream()))
+    lib.rmcl_tune_set(0, -1)
     yd = out.double()
     mu, var = yd.mean(1, keepdim=True), yd.var(1, unbiased=False, keepdim=True)
     ln = (yd - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()
