@@ -308,6 +308,10 @@ int rmcl_itm_bwd(const float* dlogits, const float* cls, const float* W, float* 
 int rmcl_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K,
               int64_t lda, int64_t ldb, int ldc, int ld_aux, float alpha, int epi, int splitk, int dt_in, int dt_out,
               int a_kc, int b_kc, int exact, void* stream);
+/* rmcl_gemm with bf16 operands stored K-BLOCKED, [K/32][rows][32] (kblk bit 0: A, bit 1: B): the layout the two-workgroups-per-CU
+ * kernel (csrc/gemm_dp.hip) streams as whole 128-byte lines; A [M,K] x B [N,K]^T only; fails when no kernel takes the layout  */
+int rmcl_gemm_kblk(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K,
+                   int ldc, int ld_aux, int epi, int dt_out, int kblk, void* stream);
 int rmcl_layernorm_fwd(const float* x, const float* w, const float* b, float eps, void* y, int dt_out, float* mean,
                        float* rstd, int M, int D, int relu, void* stream);
 int rmcl_layernorm_bwd(const void* dy, int dt_dy, const float* x, const float* mean, const float* rstd, const float* w,

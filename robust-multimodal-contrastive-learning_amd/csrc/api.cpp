@@ -108,7 +108,9 @@ extern bool g_attn_fused_bwd;
 extern bool g_dw_grouped;
 extern int g_attn_fwd_waves;
 extern int g_infonce_fold;
+extern int g_dp_stagger;
 int rmcl_tune_set(int key, int value) {
+  if (key == 7) { g_dp_stagger = value < 0 ? 0 : value; return 0; }                                  // gemm_dp: start delay of every CU's second workgroup (10 ns ticks)
   if (key == 6) { rmcl_gemm_skinny_set_form(value); return 0; }                                   // 0: skinny GEMMs in the row-split form only
   if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }
   if (key == 1) { g_st_reserve_cus = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }   // CUs left free by the activation GEMMs
@@ -380,6 +382,16 @@ int rmcl_gemm(const void* A, const void* B, void* C, void* C2, const float* bias
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ld_aux = ld_aux;
   g.alpha = alpha; g.epi = epi; g.splitk = splitk < 1 ? 1 : splitk; g.nb1 = 1; g.nb2 = 1;
   return rmcl_launch_gemm(g, dt_in, dt_out, a_kc, b_kc, exact, (hipStream_t)stream);
+}
+int rmcl_gemm_kblk(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K, int ldc,
+                   int ld_aux, int epi, int dt_out, int kblk, void* stream) {
+  RMCL_REQUIRE(A && B && C, "gemm_kblk: NULL operand");
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C; g.C2 = C2; g.bias = bias; g.aux = aux;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = ldc; g.ld_aux = ld_aux;
+  g.alpha = 1.0f; g.epi = epi; g.splitk = 1; g.nb1 = 1; g.nb2 = 1; g.kblk = kblk & 3;
+  RMCL_REQUIRE(rmcl_gemm_dp_supported(g, 1, 1) && !((epi & EPI_RESIDUAL) && dt_out != RMCL_F32), "gemm_kblk: shape / epilogue not taken by gemm_dp");
+  return rmcl_launch_gemm_dp(g, dt_out, (hipStream_t)stream);
 }
 int rmcl_layernorm_fwd(const float* x, const float* w, const float* b, float eps, void* y, int dt_out, float* mean, float* rstd,
                        int M, int D, int relu, void* stream) {

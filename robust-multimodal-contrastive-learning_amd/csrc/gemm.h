@@ -66,6 +66,8 @@ struct GemmArgs {
   int ln_nparts;                     // partials per row (4 per 192-column tile of the producer)
   int ln_cols;                       // row width of the LN input (768)
   float ln_eps;
+  int kblk;                          // gemm_dp.hip only: bit 0 / 1 = A / B stored k-blocked [K/32][rows][32] (a k-step of an operand tile is then
+                                     // 12 KiB of whole 128-byte lines instead of 192 half lines); bit 2 = the EPI_ROWSTAT producer writes C2 k-blocked
 };
 
 #ifdef __cplusplus

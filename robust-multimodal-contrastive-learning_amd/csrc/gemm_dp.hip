@@ -33,12 +33,13 @@ struct DPCtx {
   const bf16_t* A;
   const bf16_t* B;
   uint32_t oa[3], ob[3];
+  long ksa, ksb;                            // element stride of one k-step: 32 ([rows][K] operand) or rows * 32 (k-blocked operand)
   int aoff, boff;                           // lane part of the fragment read address (A: + i * 1024; B: wave column included, + j * 1024)
   int wave;
 };
 
 // one operand unit = 12 wave-instructions of 1 KiB (8 virtual rows); this wave issues instructions wave*3 .. wave*3+2
-__device__ __forceinline__ void dp_stage_unit(const bf16_t* base, const uint32_t (&off)[3], int k0, char* lds_unit, int wave) {
+__device__ __forceinline__ void dp_stage_unit(const bf16_t* base, const uint32_t (&off)[3], long k0, char* lds_unit, int wave) {
 #pragma unroll
   for (int q = 0; q < 3; ++q)
     __builtin_amdgcn_global_load_lds((glb_void*)(base + k0 + off[q]), (lds_void*)(lds_unit + (wave * 3 + q) * 1024), 16, 0, 0);
@@ -48,11 +49,11 @@ __device__ __forceinline__ void dp_stage_unit(const bf16_t* base, const uint32_t
 // vmcnt(6) after the MFMAs (k-step s+1 has landed, s+2 may be in flight); otherwise vmcnt(0).  ONE code path for every k-step of
 // the stream: the 144 accumulator registers then flow through a single loop body (separate tail steps on the two sides of a branch
 // made the register allocator copy the whole accumulator tile through scratch).
-__device__ __forceinline__ void dp_step(f32x4 (&acc)[2][6][3], const DPCtx& c, const char* cur, char* nxt2, int k2, bool stage) {
+__device__ __forceinline__ void dp_step(f32x4 (&acc)[2][6][3], const DPCtx& c, const char* cur, char* nxt2, int k2, bool stage) {   // k2: index of the k-step to stage
   if (stage) {
     // the slot of k-step s+2 held k-step s-1: every wave retired its reads of it before the barrier that ended k-step s-1
-    dp_stage_unit(c.A, c.oa, k2, nxt2, c.wave);
-    dp_stage_unit(c.B, c.ob, k2, nxt2 + DP_UNIT, c.wave);
+    dp_stage_unit(c.A, c.oa, k2 * c.ksa, nxt2, c.wave);
+    dp_stage_unit(c.B, c.ob, k2 * c.ksb, nxt2 + DP_UNIT, c.wave);
   }
   __builtin_amdgcn_sched_barrier(0);
   // A fragments stream through a few registers (144 accumulator registers leave room for ~60 more): the three B fragments and
@@ -106,13 +107,13 @@ __device__ __forceinline__ void dp_tile_setup(STTile& T, const GemmArgs& g, int 
     const int v = (wave * 3 + q) * 8 + (lane >> 3);            // virtual row of the unit
     const int lc = (lane & 7) ^ (v & 7);                       // logical chunk stored at physical chunk lane & 7
     const int row = 2 * v + (lc >> 2), kc = lc & 3;
-    T.oa[q] = (uint32_t)min(T.m0 + row, g.M - 1) * (uint32_t)g.lda + kc * 8;
-    T.ob[q] = (uint32_t)min(T.n0 + row, g.N - 1) * (uint32_t)g.ldb + kc * 8;
+    T.oa[q] = (uint32_t)min(T.m0 + row, g.M - 1) * ((g.kblk & 1) ? 32u : (uint32_t)g.lda) + kc * 8;
+    T.ob[q] = (uint32_t)min(T.n0 + row, g.N - 1) * ((g.kblk & 2) ? 32u : (uint32_t)g.ldb) + kc * 8;
   }
 }
 
 template <int AUX, typename TO, int LNF>
-__global__ __launch_bounds__(256, 2) void gemm_dp_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile) {
+__global__ __launch_bounds__(256, 2) void gemm_dp_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dp_kernel(GemmArgs g, int tiles_m
   c.A = reinterpret_cast<const bf16_t*>(g.A);
   c.B = reinterpret_cast<const bf16_t*>(g.B);
   c.wave = wave;
+  c.ksa = (g.kblk & 1) ? (long)g.M * 32 : 32;
+  c.ksb = (g.kblk & 2) ? (long)g.N * 32 : 32;
   {
     const int vr = (lane & 15) >> 1;                           // virtual row & 7 of this lane's fragment row
     const int lp = ((((lane & 1) << 2) | (lane >> 4)) ^ vr) * 16 + vr * 128;
@@ -131,6 +134,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dp_kernel(GemmArgs g, int tiles_m
 
   int id = st_tile_id(bidx, 0, G, ntiles);
   if (id < 0) return;                                          // (whole workgroup: id is uniform)
+  // Two workgroups that start together on a CU run the same number of k-steps and would reach their epilogues together: the second
+  // half of the grid (observed placement: block b and b + #CUs share a CU; speed only) starts `stagger` ticks of the 100 MHz clock late
+  if (stagger > 0 && bidx >= (G + 1) / 2) {
+    const long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < stagger) __builtin_amdgcn_s_sleep(16);
+  }
   STTile cur, nxt;
   dp_tile_setup(cur, g, id, tiles_m, tiles_n, rows_per_tile, wave, lane);
 #pragma unroll
@@ -139,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dp_kernel(GemmArgs g, int tiles_m
   // prologue: the first two k-steps of the first tile
   dp_stage_unit(c.A, c.oa, 0, smem, wave);
   dp_stage_unit(c.B, c.ob, 0, smem + DP_UNIT, wave);
-  dp_stage_unit(c.A, c.oa, 32, smem + DP_STAGE, wave);
-  dp_stage_unit(c.B, c.ob, 32, smem + DP_STAGE + DP_UNIT, wave);
+  dp_stage_unit(c.A, c.oa, c.ksa, smem + DP_STAGE, wave);
+  dp_stage_unit(c.B, c.ob, c.ksb, smem + DP_STAGE + DP_UNIT, wave);
   dp_wait_vm<6>();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dp_kernel(GemmArgs g, int tiles_m
 #pragma unroll
         for (int q = 0; q < 3; ++q) { c.oa[q] = nxt.oa[q]; c.ob[q] = nxt.ob[q]; }
       }
-      dp_step(acc, c, smem + sc * DP_STAGE, smem + sn * DP_STAGE, (ahead < 0 ? it + 2 : ahead) * 32, ahead < 0 || nid >= 0);
+      dp_step(acc, c, smem + sc * DP_STAGE, smem + sn * DP_STAGE, ahead < 0 ? it + 2 : ahead, ahead < 0 || nid >= 0);
       sc = sc == 2 ? 0 : sc + 1;
       sn = sn == 2 ? 0 : sn + 1;
     }
@@ -199,6 +208,7 @@ double rmcl_gemm_dp_fill(const GemmArgs& g, int cus) {
 }
 
 extern int g_st_reserve_cus;
+int g_dp_stagger = 0;                 // rmcl_tune_set key 7: start delay of the second workgroup of every CU, 100 MHz ticks
 
 template <int AUX, typename TO, int LNF>
 static int launch_dp3(const GemmArgs& g, hipStream_t s) {
@@ -215,7 +225,7 @@ static int launch_dp3(const GemmArgs& g, hipStream_t s) {
   }
   const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = cdiv(g.M, tm);
   const int grid = std::min(tm * tn, 2 * std::max(8, ncu - g_st_reserve_cus));
-  RMCL_LAUNCH((gemm_dp_kernel<AUX, TO, LNF>), dim3(grid), dim3(256), LDS, s, g, tm, tn, rows);
+  RMCL_LAUNCH((gemm_dp_kernel<AUX, TO, LNF>), dim3(grid), dim3(256), LDS, s, g, tm, tn, rows, g_dp_stagger);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

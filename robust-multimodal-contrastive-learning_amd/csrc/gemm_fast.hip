@@ -327,10 +327,6 @@ int rmcl_launch_gemm_big(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipS
 
 // true when rmcl_launch_gemm_fast sends this GEMM to the 192x384 or the 192x192 kernel (the only ones that implement the
 // LayerNorm-folded epilogues EPI_LNFOLD / EPI_ROWSTAT)
-int rmcl_launch_gemm_dp(const GemmArgs& g, int dt_out, hipStream_t s);
-bool rmcl_gemm_dp_supported(const GemmArgs& g, int a_kc, int b_kc);
-double rmcl_gemm_dp_fill(const GemmArgs& g, int cus);
-
 bool rmcl_gemm_routes_to_tile192(const GemmArgs& g, int a_kc, int b_kc) {
   if (g_gemm_cfg == 80 && rmcl_gemm_dp_supported(g, a_kc, b_kc)) return true;
   if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc)) return true;

@@ -16,6 +16,10 @@ bool rmcl_gemm_routes_to_tile192(const GemmArgs& g, int a_kc, int b_kc);
 // LayerNorm fold (gemm.h EPI_LNFOLD): per layer W' = bf16(W * gamma) for qkv (3D rows) then fc1 (mlp rows), and s / c vectors
 int rmcl_ln_fold_launch(const float* p32, long layer0, long stride, int layers, long ln1_w, long ln1_b, long qkv_w, long qkv_b, long ln2_w,
                         long ln2_b, long fc1_w, long fc1_b, int D, int mlp, unsigned short* wf, float* sc, hipStream_t s);
+// gemm_dp.hip: 192x192x32 tiles, two 4-wave workgroups per CU
+int rmcl_launch_gemm_dp(const GemmArgs& g, int dt_out, hipStream_t s);
+bool rmcl_gemm_dp_supported(const GemmArgs& g, int a_kc, int b_kc);
+double rmcl_gemm_dp_fill(const GemmArgs& g, int cus);
 bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc);
 int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s);
 int rmcl_launch_gemm_st_slab(const GemmArgs& g, float* slab, float* out, hipStream_t s);

@@ -486,6 +486,19 @@ def test_gemm_dual_tile_random_shapes(seed):
         lib.rmcl_tune_set(0, -1)
 
 
+@pytest.mark.parametrize("kblk", [1, 2, 3])
+def test_gemm_dual_tile_k_blocked_operands(kblk):
+    """gemm_dp.hip with operands stored k-blocked [K/32][rows][32] (whole 128-byte lines per k-step): same result as row-major."""
+    M, N, K = 1111, 576, 416
+    X, W, b = rnd(M, K, seed=1).to(torch.bfloat16), rnd(N, K, seed=2, scale=0.1).to(torch.bfloat16), rnd(N, seed=3)
+    blk = lambda t: t.view(t.shape[0], K // 32, 32).permute(1, 0, 2).contiguous()
+    A = blk(X) if kblk & 1 else X
+    Bw = blk(W) if kblk & 2 else W
+    out = torch.empty(M, N, device=DEV)
+    check(lib.rmcl_gemm_kblk(P(A), P(Bw), P(out), None, P(b), None, M, N, K, N, 0, 1, L.F32, kblk, stream()))
+    assert rel_err(out, X.double() @ W.double().t() + b.double()) < 2e-5
+
+
 @pytest.mark.parametrize("N,K", [(2304, 768), (3072, 768), (768, 3072)])
 def test_gemm_dual_tile_is_run_to_run_deterministic(N, K):
     """Counted vmcnt + one barrier per k-step order the LDS-DMA against the fragment reads; a mis-placed wait shows as rare torn

@@ -50,6 +50,21 @@ def make_cases():
         U = rnd(M, N, seed=12, dt=bf) if aux else None
         cases[name] = (2.0 * M * N * K, lambda: check(lib.rmcl_gemm(P(A), P(W), P(Cm), None, P(b), P(U), M, N, K, I64(K), I64(K), N, N if aux else 0,
                                                                      F(1.0), epi, 1, L.BF16, dto, 1, 1, 0, stream())))
+    def blocked(name, N, K, epi, dto, aux=None):
+        """the same GEMM on gemm_dp with BOTH operands k-blocked [K/32][rows][32] (only cfg 80 differs from the row-major case)"""
+        A = rnd(M, K, seed=9, dt=bf).view(M, K // 32, 32).permute(1, 0, 2).contiguous()
+        W = rnd(N, K, seed=10, scale=0.05, dt=bf).view(N, K // 32, 32).permute(1, 0, 2).contiguous()
+        b = rnd(N, seed=11)
+        Cm = torch.empty(M, N, dtype=torch.float32 if dto == L.F32 else bf, device=DEV)
+        C2 = torch.empty(M, N, dtype=bf, device=DEV) if epi & 4 else None
+        U = rnd(M, N, seed=12, dt=bf) if aux else None
+        cases[name] = (2.0 * M * N * K, lambda: check(lib.rmcl_gemm_kblk(P(A), P(W), P(Cm), P(C2), P(b), P(U), M, N, K, N, N if aux else 0, epi, dto, 3,
+                                                                          stream())))
+    blocked("KBLK qkv bias", 3 * D, D, 1, L.BF16)
+    blocked("KBLK fc1 bias+gelu+stash", MLP, D, 1 | 2 | 4, L.BF16)
+    blocked("KBLK fc2-dX gelu'", MLP, D, 16, L.BF16, aux=True)
+    blocked("KBLK fc2 bias f32", D, MLP, 1, L.F32)
+    blocked("KBLK proj bias f32", D, D, 1, L.F32)
     plain("qkv bias (FULL fwd)", 3 * D, D, 1, L.BF16)
     plain("fc2-dX gelu'", MLP, D, 16, L.BF16, aux=True, bias=False)
     plain("fc1-dX", D, MLP, 0, L.BF16, bias=False)
@@ -59,20 +74,26 @@ def make_cases():
 
 
 def main():
-    cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1, 80]
+    # variants: "cfg" or "cfg:stagger" (stagger = tune key 7: start delay of every CU's second gemm_dp workgroup, 10 ns ticks)
+    cfgs = [c for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else ["-1", "80"]
+
+    def select(c):
+        cfg, _, stg = c.partition(":")
+        lib.rmcl_tune_set(0, int(cfg))
+        lib.rmcl_tune_set(7, int(stg or 0))
     cases = make_cases()
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
     rounds, hot_n = 7, 10
     for name, (flops, run) in cases.items():
         res = {c: {"hot": [], "cold": []} for c in cfgs}
         for c in cfgs:
-            lib.rmcl_tune_set(0, c)
+            select(c)
             for _ in range(2):
                 run()
         torch.cuda.synchronize()
         for _ in range(rounds):
             for c in cfgs:
-                lib.rmcl_tune_set(0, c)
+                select(c)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(hot_n):
@@ -91,9 +112,10 @@ def main():
         for c in cfgs:
             h, k = sorted(res[c]["hot"]), sorted(res[c]["cold"])
             hm, km = h[len(h) // 2], k[len(k) // 2]
-            line += f" | cfg{c:3d}: hot {hm:6.1f} us ({flops / hm / 1e6:6.0f} TF) cold {km:6.1f} us ({flops / km / 1e6:6.0f} TF)"
+            line += f" | {c:>7s}: hot {hm:6.1f} us ({flops / hm / 1e6:6.0f} TF) cold {km:6.1f} us ({flops / km / 1e6:6.0f} TF)"
         print(line, flush=True)
     lib.rmcl_tune_set(0, -1)
+    lib.rmcl_tune_set(7, 0)
 
 
 if __name__ == "__main__":
