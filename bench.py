@@ -155,15 +155,36 @@ def self_launch(args):
     return subprocess.call(cmd)
 
 
+ROOFLINE_KERNEL_SOURCES = ("gemm_st.hip", "gemm_sw.hip", "gemm_st_epi.h", "gemm_fast.hip", "gemm.h", "rmcl_common.h")
+
+
+def roofline_kernel_build_id():
+    """Identity of the code the roofline kernels are built from: sha256 over the sources of the two GEMM kernels and their routing
+    (tools/pmc_traffic.py stores the same value with the PMC record it writes)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ROOFLINE_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "robust-multimodal-contrastive-learning_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def traffic_record(kernel_key):
     """HBM-side bytes per launch of the roofline kernel from the committed PMC passes (profiles/roofline_traffic.json,
     written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload,
-    gfx950 correction applied: FETCH_SIZE x 2).  None when no record matches."""
+    gfx950 correction applied: FETCH_SIZE x 2).  The record is used only when it was measured on THIS build of the kernels
+    (`kernel_build_id`); otherwise (None, reason)."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
-        return rec.get(kernel_key)
     except Exception:
-        return None
+        return None, "no PMC record (profiles/roofline_traffic.json)"
+    r = rec.get(kernel_key)
+    if r is None:
+        return None, "no PMC record for this kernel"
+    have, want = rec.get("kernel_build_id"), roofline_kernel_build_id()
+    if have != want:
+        return None, f"PMC record is stale: measured on kernel build {have}, this build is {want} (re-run tools/pmc_traffic.py)"
+    return r, r.get("note")
 
 
 def main():
@@ -185,13 +206,41 @@ def main():
                     help="N > 1 gradient reduction: ring = RCCL all-reduce per layer bucket; direct = one-hop reduce-scatter "
                          "(all-to-all + owner sum) + all-gather over the xGMI mesh (dist_utils.DirectReduce)")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="transport type of the gradient buckets")
+    ap.add_argument("--grad-overlap", default="on", choices=["on", "off"],
+                    help="N > 1: on = per-layer buckets reduced on the communication stream while the backward runs; off = one blocking "
+                         "pass over the arena after the backward (the comparison run)")
+    ap.add_argument("--no-feed-bench", action="store_true", help="skip the input-pipeline feed-rate measurement (tools/feed_bench.py, N = 1 only)")
+    ap.add_argument("--padded-images", action="store_true",
+                    help="run the general visual_embed path (pixel-mask patch selection + its device-to-host count read per step) on the "
+                         "same full-size synthetic batch instead of the dense fast path")
     args = ap.parse_args()
 
+    if args.grad_overlap == "off":
+        os.environ["RMCL_NO_GRAD_OVERLAP"] = "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    feed = None
+    if world == 1 and not args.no_feed_bench and args.config == "rmcl_pgd":
+        # row f3: what the host pipeline can deliver, measured BEFORE this process touches the GPU (the child and its DataLoader
+        # workers never do): reference default of 4 workers... and every core of this box's share
+        feed = {}
+        cores = len(os.sched_getaffinity(0))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                cores = min(cores, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+        for w in sorted({4, max(4, min(cores, 32))}):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "feed_bench.py"), "--json", "--workers", str(w), "--images", "128",
+                                    "--seconds", "5", "--paths", "pixelbert_uint8"], capture_output=True, text=True, timeout=180)
+                feed[f"workers_{w}"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            except Exception as e:                              # the step measurement does not depend on it
+                feed[f"workers_{w}"] = {"error": repr(e)[:200]}
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                  f"(or without a torchrun environment, then bench.py starts the ranks itself)")
@@ -222,6 +271,9 @@ def main():
 
     if world > 1:
         L.check(L.lib.rmcl_tune_set(1, 8), "tune_set")     # leave 8 CUs to RCCL's channels (include/rmcl.h)
+    for kv in filter(None, os.environ.get("RMCL_BENCH_TUNE", "").split(",")):      # developer switch: "key:value,..." for rmcl_tune_set
+        k_, v_ = kv.split(":")
+        L.check(L.lib.rmcl_tune_set(int(k_), int(v_)), "tune_set")
     B, K = args.batch, args.adv_steps
     clean = args.config == "itm_clean"
     full = args.config == "full_rmcl"
@@ -229,13 +281,13 @@ def main():
         K = 5
     cfg = task_moco(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=args.drop_rate, image_view=not clean,
                     text_view=full, clean_view=clean, max_steps=100000, max_loops=10, n_candidates=5,
-                    dense_images=True)         # synthetic full-size 384x384 images: skip the per-batch padded-image check
+                    dense_images=not args.padded_images)   # synthetic full-size 384x384 images: skip the per-batch padded-image check
     if clean:
         cfg["loss_names"]["itm"] = 1
     barlow = args.config == "barlowtwins"
     if barlow:
         cfg = task_barlowtwins(per_gpu_batchsize=B, num_gpus=world, num_nodes=1, adv_steps_img=K, drop_rate=args.drop_rate, image_view=True,
-                               text_view=False, max_steps=100000, dense_images=True)
+                               text_view=False, max_steps=100000, dense_images=not args.padded_images)
     cfg["grad_allreduce_algo"] = args.grad_sync
     cfg["grad_allreduce_dtype"] = "bf16" if args.grad_dtype == "bf16" else None
     torch.manual_seed(0)
@@ -258,6 +310,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    from rmcl_amd.vilt.modules.dist_utils import StepTimers
+    StepTimers.enabled = use_dist                       # event brackets around the two waits on communication (N > 1 only)
+    StepTimers.reset()
 
     def fence():
         torch.cuda.synchronize()
@@ -271,19 +326,44 @@ def main():
         loss = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    comm = {k: v / args.steps for k, v in StepTimers.totals_ms().items()} if use_dist else {}
+    StepTimers.enabled = False
     kern_ms, kern_n, kern_fl = mlp_gemm_replay(L, B * 185, args.dtype, device) if rank == 0 else (0.0, 0, 0.0)
+    ingest = None
+    if feed is not None:
+        # device side of the byte path: pinned uint8 [B,384,384,3] -> H2D -> ONE kernel (normalise + pad + patch rows), per batch
+        from rmcl_amd.vilt.datasets import Uint8Batch
+        u8 = Uint8Batch(torch.randint(0, 256, (B, 384, 384, 3), dtype=torch.uint8).pin_memory(), torch.full((B, 2), 384, dtype=torch.int32))
+        eng = model.engine
+        for _ in range(2):
+            eng.bind_batch(batch["text_ids"], batch["text_masks"], u8, tag="feed")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            eng.bind_batch(batch["text_ids"], batch["text_masks"], u8, tag="feed")
+        e1.record()
+        torch.cuda.synchronize()
+        ingest = {"pairs_per_s": round(10 * B / (e0.elapsed_time(e1) * 1e-3), 1), "bytes_over_pcie_per_batch": int(u8.data.numel()),
+                  "what": "pinned uint8 batch -> device -> rmcl_image_u8_to_patches (normalise + zero-pad + patch rows), stream time per batch"}
+    per_rank = None
     if use_dist:
+        mine = {"step_ms": 1e3 * elapsed / args.steps, "comm_exposed_ms": comm.get("comm_exposed", 0.0),
+                "key_gather_wait_ms": comm.get("key_gather_wait", 0.0)}
+        per_rank = [None] * dist.get_world_size()
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
-    consistent = None
+    consistent, digest = None, None
     if use_dist and (share_gpu or backend != "nccl"):          # rehearsal: the ranks' parameters and queues must be bit-identical
         eng = model.engine
         mine = [float(eng.q32.double().sum()), float(eng.q32.double().abs().sum()), float(eng.queue.double().sum())]
         allv = [None] * world
         dist.all_gather_object(allv, mine)
         consistent = all(v == allv[0] for v in allv)
+        digest = mine
 
     if rank == 0:
         pairs = world * B * args.steps
@@ -316,24 +396,42 @@ def main():
                         f"full backward + AdamW (ViLT-B/32 + 768-8192-8192-8192 BatchNorm head), bs={B}/GPU (objectives.py:449-602)")
             metric = f"image-text pairs/sec, ViLT-B/32 Barlow-Twins step (PGD K={K})"
         kern_tf = kern_fl / (kern_ms * 1e-3) / 1e12 if kern_n else 0.0
-        traffic = traffic_record("mlp_fwd_pair") if args.dtype == "bf16" and B == 64 else None
+        traffic, traffic_note = traffic_record("mlp_fwd_pair") if args.dtype == "bf16" and B == 64 else (None, "PMC record exists for bf16, bs=64 only")
         out = {
             "metric": metric, "value": round(value, 2), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "world_size": dist.get_world_size() if use_dist else 1,
-            **({"rehearsal": f"{backend} backend, ranks share one GPU: NOT a scaling measurement", "ranks_bit_identical": consistent}
+            **({"rehearsal": f"{backend} backend, ranks share one GPU: NOT a scaling measurement", "ranks_bit_identical": consistent,
+                "param_digest": digest}
                if (share_gpu or backend != "nccl") else {}),
             "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}", "drop_rate": args.drop_rate,
-                       "grad_sync": f"{args.grad_sync}/{args.grad_dtype}", "final_loss": round(final_loss, 4)},
+                       "grad_sync": f"{args.grad_sync}/{args.grad_dtype}", "final_loss": round(final_loss, 4),
+                       "images": ("dense fast path (every synthetic image is full-size: no patch selection, no per-step count read)"
+                                  if not args.padded_images else "general visual_embed path (pixel-mask selection + count read per step)")},
             "roofline": {"bound": "mfma", "achieved": round(kern_tf, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(kern_tf * 1e12 / PEAK_BF16, 4),
                          "traffic": traffic["bytes_per_launch"] if traffic else None,
-                         "traffic_note": (traffic or {}).get("note"),
+                         "traffic_note": traffic_note, "kernel_build_id": roofline_kernel_build_id(),
                          "kernel": "encoder MLP forward GEMMs (fc1 768->3072 +bias+GELU, fc2 3072->768 +bias+residual), "
                                    f"M={B * 185}; {kern_n} replayed launches, avg {kern_ms / max(kern_n, 1):.4f} ms"},
             "step_mfma_frac": round(step_flops / (elapsed / args.steps) / PEAK_BF16, 4),
         }
+        if per_rank is not None:
+            # what an N > 1 run needs to explain itself: per-rank step time, the stream time the step stood still waiting for
+            # communication, and what was sent (max over ranks of the waits: the slowest rank sets the step)
+            sm = [r["step_ms"] for r in per_rank]
+            out["multi_gpu"] = {
+                "ranks": dist.get_world_size(), "backend": backend, "step_ms_per_rank": {"min": round(min(sm), 3), "max": round(max(sm), 3)},
+                "comm_exposed_ms": round(max(r["comm_exposed_ms"] for r in per_rank), 3),
+                "key_gather_wait_ms": round(max(r["key_gather_wait_ms"] for r in per_rank), 3),
+                "grad_overlap": args.grad_overlap, "grad_sync": StepTimers.info.get("grad_sync"),
+                "key_gather_bytes_per_rank": B * 128 * 4, "rccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                "cus_left_to_rccl": 8 if world > 1 else 0}
+        if feed is not None:
+            out["feed"] = {"host": feed, "device_ingest": ingest,
+                           "note": "row f3: host pairs/s of the arrow -> batch pipeline (byte path) beside the step's `value`; the step itself is "
+                                   "measured on a batch already resident in HBM"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(K, args.config)
         print(json.dumps(out), flush=True)

@@ -163,6 +163,13 @@ int rmcl_patch_select(const float* img, int B, int C, int Hh, int Ww, int ps, in
  * the image first).                                                                                                  */
 int rmcl_im2patch_sel(float* img, float* patches, const int32_t* sel, const int32_t* counts, int sel_ld, int B, int n, int C, int Hh,
                       int Ww, int ps, int to_image, void* stream);
+/* Feed path (row f3): a decoded batch as BYTES - uint8 [B, Hmax, Wmax, 3] (HWC, every sample in its top-left corner, sizes[b] = its
+ * (h, w), multiples of 32) -> normalised fp32 patch rows [B*n, 3*32*32]: ToTensor + Normalize(.5, .5) (transforms/pixelbert.py:9-17)
+ * through the 256-entry table `lut`, the exact zeros of the collate padding (datasets/base_dataset.py:192-206) outside a sample,
+ * and the patch cut of rmcl_im2patch_f32 / rmcl_im2patch_sel, in one pass.  sel / counts: selection of rmcl_patch_select (NULL, NULL:
+ * the whole grid in row-major order, n = grid size).                                                                              */
+int rmcl_image_u8_to_patches(const uint8_t* img, const int32_t* sizes, const int32_t* sel, const int32_t* counts, int sel_ld, int B, int n,
+                             int Hmax, int Wmax, int patch_size, const float* lut, float* patches, void* stream);
 
 /* Owner-side sum of a direct reduce-scatter over the xGMI links (replaces the reduction DDP's all-reduce performs inside the
  * collective, run.py:96): pieces [n_pieces][piece_elems] of `dtype` (F32 or BF16), this rank's slice as every rank sent
@@ -308,6 +315,10 @@ int rmcl_itm_bwd(const float* dlogits, const float* cls, const float* W, float* 
 int rmcl_gemm(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K,
               int64_t lda, int64_t ldb, int ldc, int ld_aux, float alpha, int epi, int splitk, int dt_in, int dt_out,
               int a_kc, int b_kc, int exact, void* stream);
+/* Kernel family the bf16 fast path gives a GEMM of this shape / epilogue / layout to under the current tuning: 0 = 128x128 tiles,
+ * 1 = 192x192 one workgroup per CU (gemm_st.hip), 2 = 192x384 (gemm_sw.hip), 3 = 192x192x32 two workgroups per CU (gemm_dp.hip),
+ * 4 / 5 = 256x256.  Lets a parity test state WHICH kernels it compared with the oracle.                                          */
+int rmcl_gemm_route(int M, int N, int K, int epi, int dt_out, int a_kc, int b_kc);
 /* rmcl_gemm with bf16 operands stored K-BLOCKED, [K/32][rows][32] (kblk bit 0: A, bit 1: B): the layout the two-workgroups-per-CU
  * kernel (csrc/gemm_dp.hip) streams as whole 128-byte lines; A [M,K] x B [N,K]^T only; fails when no kernel takes the layout  */
 int rmcl_gemm_kblk(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K,

@@ -19,7 +19,7 @@ vilt_module.py:275-351) pointed at the q-modules, resp. k-modules + q-pooler (:4
 Weights: ``oracle.rmcl_oracle.init_params(cfg, seed)`` loaded into the reference modules via
 their state-dict names, so a fixture is reproducible from (cfg, seed) without the reference.
 
-Usage:  python oracle/gen_golden.py [moco itm moco2 cleanitm txtatk sched ragged pipeline]   (writes tests/golden/*.npz, ~2 min)
+Usage:  python oracle/gen_golden.py [moco itm moco2 cleanitm txtatk sched ragged pipeline dataset]   (writes tests/golden/*.npz, ~2 min)
 """
 from __future__ import annotations
 
@@ -906,6 +906,82 @@ def run_pipeline():
     print("pipeline fixture", os.path.getsize(path), "bytes;", out["sizes_out_384_640"][:4].tolist())
 
 
+def run_dataset():
+    """The reference's own BaseDataset (vilt/datasets/base_dataset.py:11-165) on a toy arrow shard written by this script
+    (tests/golden/toy_shard.arrow: 6 PNG images of different sizes, 1-3 captions each out of the toy vocabulary): index_mapper,
+    corpus, and get_suite (image through the reference's MinMaxResize + ToTensor/Normalize arithmetic, tokenised text, replica
+    flag, false image / false text draws under random.seed) -> tests/golden/dataset.npz."""
+    import importlib.util
+    import io
+    import random
+    from PIL import Image
+    import pyarrow as pa
+    sys.path.insert(0, ROOT)
+    import rmcl_pkg  # noqa: F401
+    from rmcl_amd.attack import word_substitution as WS
+    from rmcl_amd.vilt.datasets import write_arrow_table
+    gold = os.path.join(ROOT, "tests", "golden")
+    rng = np.random.RandomState(7)
+    sizes = [(96, 64), (64, 96), (128, 80), (50, 70), (200, 120), (64, 64)]                       # (w, h)
+    images = []
+    for w, h in sizes:
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = (120 + 70 * np.sin(xx / 9.0)[..., None] * np.cos(yy / 7.0)[..., None] + rng.normal(0, 15, (h, w, 3))).clip(0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(a).save(buf, "PNG")
+        images.append(buf.getvalue())
+    captions = [["a dog near the house", "two cat on the street"], ["the man by a car"], ["a child in the home", "a child in the home", "her kitten under the cabin"],
+                ["some woman at the road"], ["his puppy over the lane", "the lady with a automobile"], ["three kid from the cottage"]]
+    shard = os.path.join(gold, "toy_shard.arrow")
+    write_arrow_table(shard, images, captions)
+    # the reference module with stand-ins for what it imports at the top (torchvision; its own vilt.transforms -> torchvision)
+    spec = importlib.util.spec_from_file_location("ref_transforms_utils2", os.path.join(REF, "vilt", "transforms", "utils.py"))
+    tu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+
+    def ref_transform(size):
+        r = tu.MinMaxResize(shorter=size, longer=int((1333 / 800) * size))
+        def f(img):
+            t = torch.from_numpy(np.asarray(r(img)).copy()).permute(2, 0, 1).float().div(255.0)      # ToTensor
+            return (t - 0.5) / 0.5                                                                 # Normalize(.5, .5)
+        return f
+    sys.modules["vilt.transforms"] = types.ModuleType("vilt.transforms")
+    sys.modules["vilt.transforms"].keys_to_transforms = lambda keys, size=224: [ref_transform(size) for _ in keys]
+    spec = importlib.util.spec_from_file_location("ref_base_dataset2", os.path.join(REF, "vilt", "datasets", "base_dataset.py"))
+    bd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bd)
+    _concat = pa.concat_tables                                  # (pyarrow 25 spells promote=True promote_options="default")
+    pa.concat_tables = lambda tables, promote=False, **k: _concat(tables, promote_options="default" if promote else "none", **k)
+    tok = WS.load_tokenizer(os.path.join(gold, "toy_vocab.txt"))
+    out = {}
+    for tag, kw in (("dup", dict(remove_duplicate=False)), ("imgonly", dict(remove_duplicate=False, image_only=True)), ("max4", dict(remove_duplicate=False, max_num=4))):
+        ds = bd.BaseDataset(gold, ["pixelbert"], 96, ["toy_shard"], text_column_name="caption", draw_false_image=1, draw_false_text=1, **kw)
+        ds.tokenizer = tok
+        out[f"{tag}_len"] = np.array(len(ds))
+        out[f"{tag}_index_mapper"] = np.array([[ds.index_mapper[j][0], -1 if ds.index_mapper[j][1] is None else ds.index_mapper[j][1]] for j in range(len(ds))])
+        if tag != "dup":
+            continue
+        out["corpus"] = np.array(ds.corpus)
+        random.seed(123)
+        for j in (0, 1, 4, 7):
+            r = ds.get_suite(j)
+            out[f"s{j}_meta"] = np.array([r["img_index"], r["cap_index"], r["raw_index"], int(r["replica"])])
+            out[f"s{j}_text"] = np.array(r["text"][0])
+            out[f"s{j}_ids"] = np.array(r["text"][1]["input_ids"])
+            out[f"s{j}_mask"] = np.array(r["text"][1]["attention_mask"])
+            out[f"s{j}_image"] = r["image"][0].numpy()
+            out[f"s{j}_false_image_digest"] = tensor_digest(r["false_image_0"][0])
+            out[f"s{j}_false_text"] = np.array(r["false_text_0"][0])
+            out[f"s{j}_false_ids"] = np.array(r["false_text_0"][1]["input_ids"])
+    ds = bd.BaseDataset(gold, ["pixelbert"], 96, ["toy_shard"], text_column_name="caption")        # default: captions de-duplicated per image
+    out["dedup_len"] = np.array(len(ds))
+    out["dedup_counts"] = np.array([len(t) for t in ds.all_texts])
+    pa.concat_tables = _concat
+    path = os.path.join(gold, "dataset.npz")
+    np.savez_compressed(path, **out)
+    print("dataset fixture", os.path.getsize(path), "bytes; shard", os.path.getsize(shard), "bytes; len", int(out["dup_len"]), int(out["dedup_len"]))
+
+
 def run_schedules():
     """LR curves from transformers.optimization (the functions vilt_utils.py:404-432 calls; importable here).
     HF AdamW itself (vilt_utils.py:395-398, transformers==4.2.1) no longer exists in the installed transformers:
@@ -962,6 +1038,8 @@ if __name__ == "__main__":
     if want("cleanitm"):
         run_clean_itm("L2_B4_ragged", dict(small, momentum=0.9), 4, 11, 31, 21, True)
         run_clean_itm("L12_B2", dict(full, momentum=0.95), 2, 12, 32, 22, False)
+    if want("dataset"):
+        run_dataset()
     if want("txtatk"):
         run_text_attack("L2_B4_ragged", small, 4, 11, 31, 21, True, 5)
     if want("txtwords"):

@@ -17,6 +17,7 @@ MODE_CLS_TAIL = 16        # include/rmcl.h RMCL_MODE_CLS_TAIL
 PGD_DELTA_ZERO, PGD_SUM_PREV = 1, 2   # include/rmcl.h RMCL_PGD_*
 HEADS_NO_WGRAD = 1                    # include/rmcl.h RMCL_HEADS_NO_WGRAD
 EPI_BIAS, EPI_GELU, EPI_SAVE_PREACT, EPI_RESIDUAL, EPI_DGELU, EPI_ATOMIC, EPI_ACCUM, EPI_TANH = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_LNFOLD, EPI_ROWSTAT = 2048, 4096
 
 
 class Dims(C.Structure):
@@ -74,11 +75,11 @@ lib = _load()
 # every symbol include/rmcl.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = (
     "rmcl_last_error", "rmcl_version", "rmcl_prof_begin", "rmcl_prof_end", "rmcl_tune_set", "rmcl_grad_ready_wait", "rmcl_set_side_stream", "rmcl_dropout_mask_apply", "rmcl_param_layout", "rmcl_ln_fold_elems", "rmcl_ln_fold", "rmcl_linear_rowstat", "rmcl_linear_lnfold", "rmcl_weight_transpose_bf16", "rmcl_stash_bytes", "rmcl_workspace_bytes",
-    "rmcl_heads_stash_bytes", "rmcl_im2patch_f32", "rmcl_patch_select", "rmcl_im2patch_sel", "rmcl_add_cast_f32", "rmcl_shard_sum", "rmcl_encoder_forward", "rmcl_encoder_backward",
+    "rmcl_heads_stash_bytes", "rmcl_im2patch_f32", "rmcl_patch_select", "rmcl_im2patch_sel", "rmcl_image_u8_to_patches", "rmcl_add_cast_f32", "rmcl_shard_sum", "rmcl_encoder_forward", "rmcl_encoder_backward",
     "rmcl_heads_forward", "rmcl_heads_forward2", "rmcl_heads_backward", "rmcl_infonce_ws_bytes", "rmcl_infonce_f32", "rmcl_pgd_step", "rmcl_pgd_step_fused",
     "rmcl_delta_channel_norm", "rmcl_ema_f32", "rmcl_enqueue_f32", "rmcl_cast_f32", "rmcl_adamw_f32", "rmcl_ipot_f32", "rmcl_gemm_batched", "rmcl_l2norm_rows_fwd", "rmcl_l2norm_rows_bwd",
     "rmcl_wpa_cost_finish", "rmcl_wpa_distance", "rmcl_itm_fwd", "rmcl_itm_bwd",
-    "rmcl_gemm", "rmcl_gemm_kblk", "rmcl_layernorm_fwd", "rmcl_layernorm_bwd", "rmcl_attention_scratch_elems", "rmcl_attention_fwd",
+    "rmcl_gemm", "rmcl_gemm_route", "rmcl_gemm_kblk", "rmcl_layernorm_fwd", "rmcl_layernorm_bwd", "rmcl_attention_scratch_elems", "rmcl_attention_fwd",
     "rmcl_attention_bwd",
     "rmcl_bt_stash_floats", "rmcl_bt_head_forward", "rmcl_bt_head_backward", "rmcl_bt_corr", "rmcl_bt_loss_ws_floats", "rmcl_bt_loss",
     "rmcl_bt_dz", "rmcl_bt_pair_metrics",

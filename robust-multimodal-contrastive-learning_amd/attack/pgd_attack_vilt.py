@@ -71,6 +71,8 @@ class PGDAttack_moco(PGDAttack):
     def pgd_attack(self, pl_module, batch, k_modality=None):
         eng = pl_module.engine
         img_init = batch["image"][0]
+        if hasattr(img_init, "float_image"):                 # byte batch (collate_uint8): this public API returns / leaves behind images
+            img_init = img_init.to(eng.device).float_image()
         pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], img_init)
         delta_p = self.attack_patches(pl_module, pb, k_modality, keep_prev=True)
         B = img_init.shape[0]
@@ -115,6 +117,8 @@ class PGDAttack_bartlowtwins(PGDAttack):
     def pgd_attack(self, pl_module, batch, k_modality=None):
         eng = pl_module.engine
         img_init = batch["image"][0]
+        if hasattr(img_init, "float_image"):
+            img_init = img_init.to(eng.device).float_image()
         pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], img_init, tag="bt")
         delta_p = self.attack_patches(pl_module, pb, k_modality.to(eng.device, torch.float32).contiguous(), keep_prev=True)
         batch["image"][0] = img_init.to(eng.device) + eng.patches_to_image(pb.delta_prev, pb)

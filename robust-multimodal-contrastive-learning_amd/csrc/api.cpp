@@ -283,6 +283,13 @@ int rmcl_im2patch_sel(float* img, float* patches, const int32_t* sel, const int3
   RMCL_REQUIRE(img && patches && sel && counts && n > 0, "im2patch_sel: NULL argument");
   return rmcl_im2patch_sel(img, patches, sel, counts, sel_ld, B, n, C, Hh, Ww, ps, to_image, (hipStream_t)stream);
 }
+int rmcl_image_u8_to_patches(const uint8_t* img, const int32_t* sizes, const int32_t* sel, const int32_t* counts, int sel_ld, int B, int n,
+                             int Hmax, int Wmax, int patch_size, const float* lut, float* patches, void* stream) {
+  RMCL_REQUIRE(img && sizes && lut && patches, "image_u8_to_patches: NULL argument");
+  RMCL_REQUIRE(patch_size == 32, "image_u8_to_patches: patch size 32 (ViLT-B/32)");
+  RMCL_REQUIRE((sel == nullptr) == (counts == nullptr), "image_u8_to_patches: sel and counts go together");
+  return rmcl_u8_to_patches(img, sizes, sel, counts, sel_ld, B, n, Hmax, Wmax, lut, patches, (hipStream_t)stream);
+}
 int rmcl_shard_sum(const void* pieces, int dtype, int n_pieces, int64_t piece_elems, float* out32, void* out_wire, void* stream) {
   RMCL_REQUIRE(pieces && (out32 || out_wire), "shard_sum: NULL argument");
   RMCL_REQUIRE(dtype == RMCL_F32 || dtype == RMCL_BF16, "shard_sum: dtype");
@@ -382,6 +389,16 @@ int rmcl_gemm(const void* A, const void* B, void* C, void* C2, const float* bias
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ld_aux = ld_aux;
   g.alpha = alpha; g.epi = epi; g.splitk = splitk < 1 ? 1 : splitk; g.nb1 = 1; g.nb2 = 1;
   return rmcl_launch_gemm(g, dt_in, dt_out, a_kc, b_kc, exact, (hipStream_t)stream);
+}
+int rmcl_gemm_route(int M, int N, int K, int epi, int dt_out, int a_kc, int b_kc) {
+  GemmArgs g{};
+  g.M = M; g.N = N; g.K = K; g.epi = epi; g.splitk = 1; g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;
+  g.lda = a_kc ? K : M; g.ldb = b_kc ? K : N; g.ldc = N;
+  // (the pointer checks of the folded epilogues: any non-NULL value; nothing is dereferenced here)
+  static float dummy;
+  g.ln_s = g.ln_c = &dummy; g.ln_part = &dummy; g.C2 = &dummy; g.ln_cols = K;
+  g.ln_nparts = (epi & EPI_ROWSTAT) ? 4 * (N / 192) : 4 * (K / 192);
+  return rmcl_gemm_route_code(g, dt_out, a_kc, b_kc);
 }
 int rmcl_gemm_kblk(const void* A, const void* B, void* C, void* C2, const float* bias, const void* aux, int M, int N, int K, int ldc,
                    int ld_aux, int epi, int dt_out, int kblk, void* stream) {

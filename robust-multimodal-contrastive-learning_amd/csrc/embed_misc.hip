@@ -342,6 +342,55 @@ int rmcl_im2patch_sel(float* img, float* pat, const int* sel, const int* counts,
   return 0;
 }
 
+// uint8 HWC batch -> normalised fp32 patch rows in ONE pass (row f3: the feed path).  The host pipeline hands over the decoded,
+// resized images as bytes - [B, Hmax, Wmax, 3] uint8, each sample in its top-left corner, `sizes[b]` = its (h, w) - a quarter of
+// the float batch's bytes over PCIe; this kernel applies ToTensor + Normalize(0.5, 0.5) through a 256-entry table (built on the
+// host with the reference's own arithmetic, pixelbert.py:9-17, so the values are bit-identical to the float pipeline's), writes the
+// exact zeros of BaseDataset.collate's padding (base_dataset.py:192-206) outside a sample's extent, and cuts the result into the
+// patch rows of the patch-embedding GEMM (K order (c, ky, kx)) - what im2patch / im2patch_sel produce from the float image.
+// One workgroup per (sample, slot): thread t takes 4 pixels (12 contiguous bytes) of patch line ky = t / 8.
+__global__ __launch_bounds__(256) void u8_to_patches_kernel(const unsigned char* __restrict__ img, const int* __restrict__ sizes,
+                                                            const int* __restrict__ sel, const int* __restrict__ counts, int sel_ld, int n,
+                                                            int Hmax, int Wmax, const float* __restrict__ lut, float* __restrict__ pat) {
+  __shared__ float tab[256];
+  tab[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  const int b = blockIdx.x / n, k = blockIdx.x - b * n;
+  const int gw = Wmax / 32;
+  const bool live = !counts || k < counts[b];
+  const int p = sel ? sel[(long)b * sel_ld + k] : k;
+  const int py = p / gw, px = p - py * gw;
+  const int ky = threadIdx.x >> 3, kx = (threadIdx.x & 7) * 4;
+  const int y = py * 32 + ky, x = px * 32 + kx;
+  float v[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[c][i] = 0.f;
+  if (live && y < sizes[2 * b] && x < sizes[2 * b + 1]) {                 // (w is a multiple of 32: the 4 pixels are in or out together)
+    const uint3 w = *reinterpret_cast<const uint3*>(img + (((long)b * Hmax + y) * Wmax + x) * 3);
+    const unsigned wd[3] = {w.x, w.y, w.z};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int byte = i * 3 + c;
+        v[c][i] = tab[(wd[byte >> 2] >> ((byte & 3) * 8)) & 0xff];
+      }
+  }
+  float* row = pat + (long)blockIdx.x * 3072 + ky * 32 + kx;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(row + c * 1024) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+}
+int rmcl_u8_to_patches(const unsigned char* img, const int* sizes, const int* sel, const int* counts, int sel_ld, int B, int n, int Hmax, int Wmax,
+                       const float* lut, float* pat, hipStream_t s) {
+  RMCL_REQUIRE(Hmax % 32 == 0 && Wmax % 32 == 0 && n > 0 && B > 0, "u8_to_patches: sides must be multiples of the 32-pixel patch");
+  RMCL_REQUIRE(sel || n == (Hmax / 32) * (Wmax / 32), "u8_to_patches: without a selection n must be the whole grid");
+  RMCL_LAUNCH(u8_to_patches_kernel, dim3(B * n), dim3(256), 0, s, img, sizes, sel, counts, sel_ld, n, Hmax, Wmax, lut, pat);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
 // source index and weight of torch's bilinear align_corners=True resize (upsample_bilinear2d): src = dst * (in-1)/(out-1)
 __device__ __forceinline__ void bilin_src(int dst, int in, int out, int& i0, int& i1, float& l1) {
   const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;

@@ -327,30 +327,39 @@ int rmcl_launch_gemm_big(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipS
 
 // true when rmcl_launch_gemm_fast sends this GEMM to the 192x384 or the 192x192 kernel (the only ones that implement the
 // LayerNorm-folded epilogues EPI_LNFOLD / EPI_ROWSTAT)
+// Which kernel family rmcl_launch_gemm_fast gives a GEMM to (the ONE place the routing is decided; rmcl_gemm_route in the C ABI
+// reports it so that a parity test can assert which kernels it compared): 0 = 128x128 (gemm_fast), 1 = 192x192 one workgroup per CU
+// (gemm_st), 2 = 192x384 (gemm_sw), 3 = 192x192x32 two workgroups per CU (gemm_dp), 4 = 256x256 ping-pong, 5 = 256x256
+int rmcl_gemm_route_code(const GemmArgs& g, int dt_out, int a_kc, int b_kc) {
+  if (g_gemm_cfg == 80 && rmcl_gemm_dp_supported(g, a_kc, b_kc) && !((g.epi & EPI_RESIDUAL) && dt_out != RMCL_F32)) return 3;
+  // 192x384 tiles where they make exact rounds (N = 3072 at M = 64*185: 496 tiles = 2 x 248)
+  if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc)) return 2;
+  // 192x192 ping-pong tiles for the activation GEMMs (M = B*185 rows) whenever they fill the CU rounds
+  if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc)) return 1;
+  if (g_gemm_cfg == 50 && rmcl_gemm_pp_supported(g, a_kc, b_kc)) return 4;
+  // 256x256 tiles where they measure faster (MI355X, M = 11840): narrow outputs with a long reduction
+  const bool big_wins = a_kc && g.splitk <= 1 && g.N <= 1024 && g.K >= 2048 && cdiv(g.M, 256) * (g.N / 256) >= 128;
+  if ((g_gemm_cfg == 30 || (g_gemm_cfg < 0 && big_wins)) && rmcl_gemm_big_supported(g, a_kc, b_kc)) return 5;
+  return 0;
+}
+
+// true when the GEMM runs on one of the 192-row tile kernels (the only ones that implement the LayerNorm-folded epilogues
+// EPI_LNFOLD / EPI_ROWSTAT)
 bool rmcl_gemm_routes_to_tile192(const GemmArgs& g, int a_kc, int b_kc) {
-  if (g_gemm_cfg == 80 && rmcl_gemm_dp_supported(g, a_kc, b_kc)) return true;
-  if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc)) return true;
-  if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc)) return true;
-  return false;
+  const int r = rmcl_gemm_route_code(g, (g.epi & EPI_ROWSTAT) ? RMCL_F32 : RMCL_BF16, a_kc, b_kc);
+  return r == 1 || r == 2 || r == 3;
 }
 
 int rmcl_launch_gemm_fast(const GemmArgs& g0, int dt_out, int a_kc, int b_kc, hipStream_t s) {
   GemmArgs g = g0;
-  RMCL_REQUIRE(!(g.epi & (EPI_LNFOLD | EPI_ROWSTAT)) || rmcl_gemm_routes_to_tile192(g, a_kc, b_kc),
+  const int route = rmcl_gemm_route_code(g, dt_out, a_kc, b_kc);
+  RMCL_REQUIRE(!(g.epi & (EPI_LNFOLD | EPI_ROWSTAT)) || (route >= 1 && route <= 3),
                "gemm: the LayerNorm-folded epilogues exist in the 192-row tile kernels only");
-  // 192x192x32 tiles, two 4-wave workgroups per CU (gemm_dp.hip)
-  if (g_gemm_cfg == 80 && rmcl_gemm_dp_supported(g, a_kc, b_kc) && !((g.epi & EPI_RESIDUAL) && dt_out != RMCL_F32)) return rmcl_launch_gemm_dp(g, dt_out, s);
-  // 192x384 tiles where they make exact rounds (N = 3072 at M = 64*185: 496 tiles = 2 x 248)
-  if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc))
-    return rmcl_launch_gemm_sw(g, dt_out, b_kc, s);
-  // 192x192 ping-pong tiles for the activation GEMMs (M = B*185 rows) whenever they fill the CU rounds
-  if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc))
-    return rmcl_launch_gemm_st(g, dt_out, a_kc, b_kc, s);
-  if (g_gemm_cfg == 50 && rmcl_gemm_pp_supported(g, a_kc, b_kc)) return rmcl_launch_gemm_pp(g, dt_out, s);
-  // 256x256 tiles where they measure faster (MI355X, M = 11840): narrow outputs with a long reduction
-  const bool big_wins = a_kc && g.splitk <= 1 && g.N <= 1024 && g.K >= 2048 && cdiv(g.M, 256) * (g.N / 256) >= 128;
-  if ((g_gemm_cfg == 30 || (g_gemm_cfg < 0 && big_wins)) && rmcl_gemm_big_supported(g, a_kc, b_kc))
-    return rmcl_launch_gemm_big(g, dt_out, a_kc, b_kc, s);
+  if (route == 3) return rmcl_launch_gemm_dp(g, dt_out, s);
+  if (route == 2) return rmcl_launch_gemm_sw(g, dt_out, b_kc, s);
+  if (route == 1) return rmcl_launch_gemm_st(g, dt_out, a_kc, b_kc, s);
+  if (route == 4) return rmcl_launch_gemm_pp(g, dt_out, s);
+  if (route == 5) return rmcl_launch_gemm_big(g, dt_out, a_kc, b_kc, s);
   if (g_gemm_cfg == 10) g.tag |= 1 << 30;
   if (g_gemm_cfg == 11) g.tag |= 1 << 29;
   if (g.splitk > 1) {                                          // no empty K slices (the k-tile stream assumes nk >= 1)

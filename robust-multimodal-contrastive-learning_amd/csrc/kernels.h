@@ -13,6 +13,7 @@ int rmcl_slab_reduce(const float* slab, float* out, long n, int nz, hipStream_t 
 int rmcl_gemm_fast_get_cfg();
 void rmcl_gemm_skinny_set_form(int v);     // gemm_exact.hip: 0 = row-split skinny kernel only
 bool rmcl_gemm_routes_to_tile192(const GemmArgs& g, int a_kc, int b_kc);
+int rmcl_gemm_route_code(const GemmArgs& g, int dt_out, int a_kc, int b_kc);   // 0 128x128, 1 gemm_st, 2 gemm_sw, 3 gemm_dp, 4 / 5 256x256
 // LayerNorm fold (gemm.h EPI_LNFOLD): per layer W' = bf16(W * gamma) for qkv (3D rows) then fc1 (mlp rows), and s / c vectors
 int rmcl_ln_fold_launch(const float* p32, long layer0, long stride, int layers, long ln1_w, long ln1_b, long qkv_w, long qkv_b, long ln2_w,
                         long ln2_b, long fc1_w, long fc1_b, int D, int mlp, unsigned short* wf, float* sc, hipStream_t s);
@@ -80,6 +81,8 @@ int rmcl_pos_resize_fwd(const float* table, const int* sel, const int* counts, c
                         float* out, hipStream_t s);
 int rmcl_pos_resize_bwd(const float* dtok, const int* sel, const int* counts, const int* hw, int sel_ld, int gw, int G0, int B, int n, int D,
                         float* dtable, hipStream_t s);
+int rmcl_u8_to_patches(const unsigned char* img, const int* sizes, const int* sel, const int* counts, int sel_ld, int B, int n, int Hmax, int Wmax,
+                       const float* lut, float* pat, hipStream_t s);
 int rmcl_im2patch(const float* img, float* pat, int B, int C, int Hh, int Ww, int ps, int to_image, hipStream_t s);
 int rmcl_k_add_cast(const float* a, const float* d1, const float* d2, void* out, int dt, long n, hipStream_t s);
 int rmcl_k_shard_sum(const void* pieces, int dt, int W, long n, float* out32, void* out_wire, hipStream_t s);

@@ -230,6 +230,7 @@ class Engine:
         self.dropout_on = False            # set by the module per step (self.training)
         self.seed_base = int(cfg.get("seed", 0)) + 1
         self.pass_counter = 0
+        self._lut = None                                                   # 256-entry normalisation table of the uint8 feed path
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.dw_stream = torch.cuda.Stream(device=self.device)
         self.comm_stream = torch.cuda.Stream(device=self.device)     # gradient all-reduces (N > 1), gated on backward events
@@ -375,8 +376,13 @@ class Engine:
                 counts = torch.minimum(counts, torch.full_like(counts, n))
         return RaggedGeometry(sel, counts, hw, n, gh, gw, (B, 3, Hh, Ww))
 
-    def bind_batch(self, text_ids: torch.Tensor, text_mask: torch.Tensor, image: torch.Tensor, tag: str = "moco",
+    def bind_batch(self, text_ids: torch.Tensor, text_mask: torch.Tensor, image, tag: str = "moco",
                    select: torch.Tensor = None) -> PassBuffers:
+        """image: the float batch [B,3,H,W] of ``collate`` - or a ``Uint8Batch`` (``collate_uint8``): the decoded bytes, normalised,
+        zero-padded and cut into patch rows by ONE kernel, the patch selection derived from the known extents (no selection
+        launch, no device-to-host read of the counts)."""
+        if hasattr(image, "sizes") and hasattr(image, "data"):
+            return self._bind_uint8(text_ids, text_mask, image, tag, select)
         img = image.to(self.device, torch.float32).contiguous()
         B, Cc, Hh, Ww = img.shape
         ps = self.cfg["patch_size"]
@@ -390,6 +396,51 @@ class Engine:
         else:
             check(lib.rmcl_im2patch_sel(P(img), P(pb.patches32), P(geom.sel), P(geom.counts), geom.sel.shape[1], B, geom.n, 3, Hh, Ww,
                                         ps, 0, stream_ptr()), "im2patch_sel")
+        return pb
+
+    def _bind_uint8(self, text_ids, text_mask, u8, tag, select) -> PassBuffers:
+        from .vilt.datasets.base_dataset import select_from_sizes
+        from .vilt.transforms import normalize_lut
+        ps, S = self.cfg["patch_size"], self.cfg["image_size"]
+        data = u8.data.to(self.device, non_blocking=True).contiguous()
+        B, Hh, Ww, _ = data.shape
+        if ps != 32 or Hh % ps or Ww % ps or bool((u8.sizes % ps != 0).any()):
+            raise ValueError(f"uint8 batches need sides that are multiples of the 32-pixel patch (got {tuple(data.shape)}, sizes {u8.sizes.tolist()})")
+        gh, gw = Hh // ps, Ww // ps
+        if gh * gw > 1024:
+            raise ValueError(f"at most 1024 patches per image ({gh}x{gw} given)")
+        if self._lut is None:
+            self._lut = normalize_lut().to(self.device)
+        full = Hh == S and Ww == S and select is None and bool((u8.sizes == S).all())
+        geom = None
+        if not full:
+            sel, counts, hw = select_from_sizes(u8.sizes, gh, gw, ps)
+            n = int(counts.max())
+            mil = self.cfg.get("max_image_len", -1)
+            if isinstance(mil, int) and mil > 0:
+                n = min(n, mil)                                            # vision_transformer.py:602-616
+            if n + 1 + self.cfg["max_text_len"] > 256 and self.dtype == L.BF16:
+                raise NotImplementedError(f"{n} image patches + text exceed the 256-token limit of the fused attention kernels")
+            if select is not None:
+                sel = select.to(torch.int32).contiguous()
+                assert sel.shape == (B, n), (tuple(sel.shape), (B, n))
+                counts = torch.minimum(counts, torch.full_like(counts, n))
+            else:
+                for b in (counts > n).nonzero().flatten().tolist():        # random subset like the reference (:633-636)
+                    v = int(counts[b])
+                    keep = torch.multinomial(torch.ones(v).float(), n)
+                    sel[b, :n] = sel[b, :v].index_select(0, keep)
+                counts = torch.minimum(counts, torch.full_like(counts, n))
+            geom = RaggedGeometry(sel.to(self.device), counts.to(self.device), hw.to(self.device), n, gh, gw, (B, 3, Hh, Ww))
+        pb = self.bufs(B, tag, None, None if geom is None else geom.n)
+        self._set_geometry(pb, geom)
+        pb.text_ids = text_ids.to(self.device, torch.int64).contiguous()
+        pb.text_mask = text_mask.to(self.device, torch.int64).contiguous()
+        sizes = u8.sizes.to(self.device, non_blocking=True)
+        check(lib.rmcl_image_u8_to_patches(P(data), P(sizes), P(geom.sel) if geom else None, P(geom.counts) if geom else None,
+                                           geom.sel.shape[1] if geom else 0, B, geom.n if geom else gh * gw, Hh, Ww, ps, P(self._lut),
+                                           P(pb.patches32), stream_ptr()), "image_u8_to_patches")
+        pb.keep_alive = (data, sizes)                                      # until the stream has consumed them
         return pb
 
     def bind_text(self, like: PassBuffers, text_ids: torch.Tensor, text_mask: torch.Tensor, tag: str) -> PassBuffers:

@@ -14,8 +14,12 @@ name, datamodule_base.py:12-21 - not available offline).  ``mlm_collator`` maps 
 {"input_ids", "labels"}; ``default_collator`` pads ``encoding["input_ids"]`` to ``max_text_len`` and masks nothing."""
 from __future__ import annotations
 
+import io
+import os
+import random
 from typing import Callable, Dict, List, Optional
 
+import numpy as np
 import torch
 
 
@@ -73,3 +77,218 @@ def collate(samples: List[dict], mlm_collator: Optional[Callable] = None) -> Dic
             rows = slice(B * i, B * (i + 1))
             batch.update(_expand_text(k, batch[k], flat["input_ids"][rows], flat["labels"][rows]))
     return batch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# uint8 feed path: the batch crosses the loader's pipes and PCIe as bytes; normalisation / zero padding / patch cut run on
+# the device in one kernel (csrc/embed_misc.hip u8_to_patches_kernel, Engine.bind_batch)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class Uint8Batch:
+    """One view of a collated batch as decoded bytes: ``data`` uint8 [B, Hmax, Wmax, 3] (HWC, every sample in its top-left
+    corner, zero outside), ``sizes`` int32 [B, 2] = (h, w) of every sample (multiples of 32 after MinMaxResize).  Stands where
+    the float tensor [B, 3, Hmax, Wmax] of ``collate`` stands (``batch["image"][v]``); ``float_image()`` materialises that
+    tensor (the reference's values, bit for bit) for callers outside the training step."""
+
+    def __init__(self, data: torch.Tensor, sizes: torch.Tensor):
+        assert data.dtype == torch.uint8 and data.dim() == 4 and data.shape[3] == 3, tuple(data.shape)
+        self.data, self.sizes = data, sizes.to(torch.int32)
+
+    @property
+    def shape(self):
+        B, H, W, _ = self.data.shape
+        return (B, 3, H, W)
+
+    def to(self, device, non_blocking: bool = True) -> "Uint8Batch":
+        return Uint8Batch(self.data.to(device, non_blocking=non_blocking), self.sizes)
+
+    def pin_memory(self) -> "Uint8Batch":
+        return Uint8Batch(self.data.pin_memory(), self.sizes)
+
+    def float_image(self) -> torch.Tensor:
+        from ..transforms import normalize_lut
+        x = normalize_lut().to(self.data.device)[self.data.long()].permute(0, 3, 1, 2).contiguous()
+        B, _, H, W = x.shape
+        ys, xs = torch.arange(H, device=x.device)[None, :, None], torch.arange(W, device=x.device)[None, None, :]
+        sz = self.sizes.to(x.device)
+        inside = (ys < sz[:, 0, None, None]) & (xs < sz[:, 1, None, None])
+        return x * inside[:, None].to(x.dtype)
+
+
+def select_from_sizes(sizes: torch.Tensor, gh: int, gw: int, ps: int = 32):
+    """``rmcl_patch_select`` (vision_transformer.py:563-600) for a batch whose extents are KNOWN: with byte sources a pixel inside a
+    sample is never exactly zero after Normalize ((2v - 255) / 255 is an odd multiple of 1/255, and so is every channel sum), so the
+    pixel mask is the extent rectangle.  Returns (sel [B, gh*gw] int32: valid patches row-major, then the first non-valid patch
+    repeated; counts [B]; hw [B, 2] valid patch rows / columns) - the kernel's conventions - without touching the device."""
+    B, G = sizes.shape[0], gh * gw
+    sel = np.zeros((B, G), dtype=np.int32)
+    counts = np.zeros(B, dtype=np.int32)
+    hw = np.zeros((B, 2), dtype=np.int32)
+    grid = np.arange(G, dtype=np.int32).reshape(gh, gw)
+    for b, (h, w) in enumerate(sizes.tolist()):
+        ph, pw = min(gh, (h + ps - 1) // ps), min(gw, (w + ps - 1) // ps)
+        valid = np.zeros((gh, gw), dtype=bool)
+        valid[:ph, :pw] = True
+        v = grid[valid]
+        pad = grid[~valid]
+        n = v.size
+        sel[b, :n] = v
+        sel[b, n:] = pad[0] if pad.size else 0
+        counts[b], hw[b] = n, (ph, pw)
+    return torch.from_numpy(sel), torch.from_numpy(counts), torch.from_numpy(hw)
+
+
+def _stack_views_uint8(per_sample: List[List[torch.Tensor]], hmax: int, wmax: int) -> List[Uint8Batch]:
+    n_views = len(per_sample[0])
+    out = []
+    for v in range(n_views):
+        data = torch.zeros(len(per_sample), hmax, wmax, 3, dtype=torch.uint8)
+        sizes = torch.zeros(len(per_sample), 2, dtype=torch.int32)
+        for b, views in enumerate(per_sample):
+            img = views[v]
+            data[b, : img.shape[0], : img.shape[1]] = img
+            sizes[b, 0], sizes[b, 1] = img.shape[0], img.shape[1]
+        out.append(Uint8Batch(data, sizes))
+    return out
+
+
+def collate_uint8(samples: List[dict], mlm_collator: Optional[Callable] = None) -> Dict[str, object]:
+    """``collate`` for samples whose image views are uint8 [h, w, 3] tensors (transform key "pixelbert_uint8"): every image key
+    becomes a list of ``Uint8Batch`` (one maximum extent over ALL image keys, like the reference); text keys as in ``collate``."""
+    names = {k for smp in samples for k in smp}
+    image_keys = [k for k in names if "image" in k]
+    stripped = [{k: v for k, v in smp.items() if k not in image_keys} for smp in samples]
+    batch = collate(stripped, mlm_collator)
+    if image_keys:
+        shapes = [tuple(img.shape) for k in image_keys for smp in samples if smp.get(k) is not None for img in smp[k]]
+        for shp in shapes:
+            if len(shp) != 3 or shp[2] != 3:
+                raise AssertionError(f"Collate error, a uint8 image should be in shape of (H, W, 3), instead of given {shp}")
+        hmax, wmax = max(s[0] for s in shapes), max(s[1] for s in shapes)
+        for k in image_keys:
+            batch[k] = _stack_views_uint8([smp[k] for smp in samples], hmax, wmax)
+    return batch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# arrow-table dataset: the protocol of the reference's BaseDataset (vilt/datasets/base_dataset.py:11-165)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class BaseDataset(torch.utils.data.Dataset):
+    """Image-text pairs out of ``{data_dir}/{name}.arrow`` tables (column "image": encoded bytes, column ``text_column_name``: list
+    of captions per image), with the reference's indexing and sample protocol:
+
+      * ``index_mapper[j] = (image row, caption number)``: one entry per caption (captions de-duplicated per image by default),
+        or one entry per image with caption ``None`` for ``image_only`` / no text column (base_dataset.py:70-85);
+      * ``get_image`` / ``get_false_image`` / ``get_text`` / ``get_false_text`` / ``get_suite`` return the dicts
+        ``collate`` consumes (:92-165); a failing sample is replaced by a random one like the reference does (:147-164);
+      * ``tokenizer``: any callable with the HF signature (the reference's datamodule attaches one loaded by name,
+        datamodule_base.py:12-21 - not available offline; tests use BertTokenizer on a local vocabulary file).
+
+    ``transform_keys``: "pixelbert" (float CHW views, the reference's) or "pixelbert_uint8" (byte HWC views for the device-side
+    normalisation, collate with ``collate_uint8``).  Differences kept on purpose: the tables stay memory-mapped and the caption
+    column is read once with ``to_pylist`` (no pandas round trip); de-duplication keeps first-seen order (the reference's
+    ``list(set(texts))`` order depends on the hash seed)."""
+
+    def __init__(self, data_dir: str, transform_keys: list, image_size: int, names: list, text_column_name: str = "",
+                 remove_duplicate=True, max_text_len=40, draw_false_image=0, draw_false_text=0, image_only=False, max_num=-1,
+                 tokenizer: Optional[Callable] = None):
+        import pyarrow as pa
+        from ..transforms import keys_to_transforms
+        assert len(transform_keys) >= 1
+        super().__init__()
+        self.transforms = keys_to_transforms(transform_keys, size=image_size)
+        self.text_column_name, self.names, self.max_text_len = text_column_name, names, max_text_len
+        self.draw_false_image, self.draw_false_text, self.image_only, self.data_dir = draw_false_image, draw_false_text, image_only, data_dir
+        self.tokenizer = tokenizer
+        self.all_texts: List[List[str]] = []
+        self.table = None
+        if len(names) != 0:
+            present = [n for n in names if os.path.isfile(f"{data_dir}/{n}.arrow")]
+            tables = [pa.ipc.RecordBatchFileReader(pa.memory_map(f"{data_dir}/{n}.arrow", "r")).read_all() for n in present]
+            self.table_names = [n for n, t in zip(present, tables) for _ in range(len(t))]
+            self.table = pa.concat_tables(tables, promote_options="default")
+            if text_column_name != "":
+                texts = self.table[text_column_name].to_pylist()
+                self.all_texts = [list(dict.fromkeys(t)) for t in texts] if remove_duplicate else [list(t) for t in texts]
+        self.index_mapper: Dict[int, tuple] = {}
+        if text_column_name != "" and not self.image_only:
+            j = 0
+            for i, texts in enumerate(self.all_texts[: len(self.all_texts) if max_num == -1 else max_num]):
+                for _j in range(len(texts)):
+                    self.index_mapper[j] = (i, _j)
+                    j += 1
+        elif self.table is not None:
+            for i in range(len(self.table) if max_num == -1 else min(max_num, len(self.table))):
+                self.index_mapper[i] = (i, None)
+
+    @property
+    def corpus(self):
+        return [text for texts in self.all_texts for text in texts]
+
+    def __len__(self):
+        return len(self.index_mapper)
+
+    def get_raw_image(self, index, image_key="image"):
+        from PIL import Image
+        row, _ = self.index_mapper[index]
+        return Image.open(io.BytesIO(self.table[image_key][row].as_py())).convert("RGB")
+
+    def get_image(self, index, image_key="image"):
+        image = self.get_raw_image(index, image_key=image_key)
+        return {"image": [tr(image) for tr in self.transforms], "img_index": self.index_mapper[index][0],
+                "cap_index": self.index_mapper[index][1], "raw_index": index}
+
+    def get_false_image(self, rep, image_key="image"):
+        random_index = random.randint(0, len(self.index_mapper) - 1)
+        image = self.get_raw_image(random_index, image_key=image_key)
+        return {f"false_image_{rep}": [tr(image) for tr in self.transforms]}
+
+    def get_text(self, raw_index):
+        index, caption_index = self.index_mapper[raw_index]
+        text = self.all_texts[index][caption_index]
+        encoding = self.tokenizer(text, padding="max_length", truncation=True, max_length=self.max_text_len, return_special_tokens_mask=True)
+        return {"text": (text, encoding), "img_index": index, "cap_index": caption_index, "raw_index": raw_index}
+
+    def get_false_text(self, rep):
+        random_index = random.randint(0, len(self.index_mapper) - 1)
+        index, caption_index = self.index_mapper[random_index]
+        text = self.all_texts[index][caption_index]
+        encoding = self.tokenizer(text, truncation=True, max_length=self.max_text_len, return_special_tokens_mask=True)
+        return {f"false_text_{rep}": (text, encoding)}
+
+    def get_suite(self, index):
+        while True:
+            try:
+                ret = dict()
+                ret.update(self.get_image(index))
+                if not self.image_only:
+                    txt = self.get_text(index)
+                    ret.update({"replica": True if txt["cap_index"] > 0 else False})
+                    ret.update(txt)
+                for i in range(self.draw_false_image):
+                    ret.update(self.get_false_image(i))
+                for i in range(self.draw_false_text):
+                    ret.update(self.get_false_text(i))
+                return ret
+            except Exception as e:                               # (a corrupt record: take another sample, base_dataset.py:161-164)
+                print(f"Error while read file idx {index} in {self.names[0]} -> {e}")
+                index = random.randint(0, len(self.index_mapper) - 1)
+
+    def __getitem__(self, index):
+        return self.get_suite(index)
+
+    def collate(self, batch, mlm_collator=None):
+        uint8 = any(torch.is_tensor(v) and v.dtype == torch.uint8 for smp in batch for k, vs in smp.items() if "image" in k and vs for v in vs)
+        return (collate_uint8 if uint8 else collate)(batch, mlm_collator)
+
+
+def write_arrow_table(path: str, images: List[bytes], captions: List[List[str]], text_column_name: str = "caption"):
+    """Writes a table in the layout the reference's ``make_arrow`` scripts produce (vilt/utils/write_*.py: columns image bytes,
+    caption list, image_id, split) - used by the tests and the feed benchmark to build synthetic shards."""
+    import pyarrow as pa
+    table = pa.table({"image": pa.array(images, type=pa.binary()), text_column_name: pa.array(captions, type=pa.list_(pa.string())),
+                      "image_id": pa.array([f"{i:08d}" for i in range(len(images))]), "split": pa.array(["train"] * len(images))})
+    with pa.OSFile(path, "wb") as sink:
+        with pa.RecordBatchFileWriter(sink, table.schema) as writer:
+            writer.write_table(table)

@@ -44,7 +44,23 @@ def pixelbert_transform(size=800):
     return lambda img: to_normalized_tensor(resize(img))
 
 
-_transforms = {"pixelbert": pixelbert_transform}       # (the RandAugment variant is a training-time augmentation, out of scope)
+def normalize_lut() -> torch.Tensor:
+    """The 256 values ToTensor + Normalize(0.5, 0.5) can produce, computed with the arithmetic of ``to_normalized_tensor``: the
+    device side of the uint8 feed path (rmcl_image_u8_to_patches) looks pixels up here, so its floats are bit-identical to the
+    float pipeline's."""
+    return torch.arange(256, dtype=torch.uint8).to(torch.float32).div_(255.0).sub_(0.5).div_(0.5)
+
+
+def pixelbert_uint8_transform(size=800):
+    """The pixelbert transform WITHOUT the float conversion: callable(PIL image) -> uint8 tensor [h, w, 3] (HWC, as decoded).
+    Normalisation, zero padding and the patch cut happen on the device in one kernel (Engine.bind_batch on a Uint8Batch): a
+    quarter of the bytes through the loader's pipes and over PCIe, no float image in host memory."""
+    resize = MinMaxResize(shorter=size, longer=int((1333 / 800) * size))
+    return lambda img: torch.from_numpy(np.array(resize(img).convert("RGB"), dtype=np.uint8))
+
+
+# (the RandAugment variant is a training-time augmentation, out of scope)
+_transforms = {"pixelbert": pixelbert_transform, "pixelbert_uint8": pixelbert_uint8_transform}
 
 
 def keys_to_transforms(keys: list, size=224):

@@ -1,0 +1,77 @@
+"""-m gpu, row f3: the device side of the uint8 feed path (rmcl_image_u8_to_patches + the selection derived from the known
+extents) against the float path it replaces (collate -> rmcl_patch_select -> rmcl_im2patch_f32 / _sel), and one training step
+on a byte batch against the same step on the float batch."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import rmcl_pkg  # noqa: F401,E402
+from oracle import rmcl_oracle as O  # noqa: E402
+from rmcl_amd._lib import lib, check, P  # noqa: E402
+from rmcl_amd.vilt.datasets import Uint8Batch, select_from_sizes  # noqa: E402
+from rmcl_amd.vilt.transforms import normalize_lut  # noqa: E402
+from tests.test_parity2_gpu import make_module  # noqa: E402
+from tests.test_path_gpu import dev_batch  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def byte_batch(sizes, Hmax, Wmax, seed):
+    g = torch.Generator().manual_seed(seed)
+    data = torch.zeros(len(sizes), Hmax, Wmax, 3, dtype=torch.uint8)
+    for b, (h, w) in enumerate(sizes):
+        data[b, :h, :w] = torch.randint(0, 256, (h, w, 3), generator=g, dtype=torch.uint8)
+    return Uint8Batch(data, torch.tensor(sizes, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("sizes,Hmax,Wmax", [([(384, 384)] * 3, 384, 384), ([(384, 352), (320, 384), (224, 288), (32, 32)], 384, 384),
+                                             ([(64, 96), (96, 128)], 96, 128)])
+def test_u8_to_patches_equals_float_pipeline(sizes, Hmax, Wmax):
+    u8 = byte_batch(sizes, Hmax, Wmax, 3)
+    B, gh, gw = len(sizes), Hmax // 32, Wmax // 32
+    img = u8.float_image().to(DEV)                                   # = collate of the float samples (tests/test_feed_cpu.py)
+    sel_k = torch.empty(B, gh * gw, dtype=torch.int32, device=DEV)
+    cnt_k = torch.empty(B, dtype=torch.int32, device=DEV)
+    hw_k = torch.empty(B, 2, dtype=torch.int32, device=DEV)
+    check(lib.rmcl_patch_select(P(img), B, 3, Hmax, Wmax, 32, P(sel_k), P(cnt_k), P(hw_k), stream()))
+    sel, counts, hw = select_from_sizes(u8.sizes, gh, gw)
+    assert torch.equal(sel, sel_k.cpu()) and torch.equal(counts, cnt_k.cpu()) and torch.equal(hw, hw_k.cpu())   # extents == pixel mask
+    n = int(counts.max())
+    ref = torch.empty(B * n, 3072, device=DEV)
+    check(lib.rmcl_im2patch_sel(P(img), P(ref), P(sel_k), P(cnt_k), gh * gw, B, n, 3, Hmax, Wmax, 32, 0, stream()))
+    out = torch.full((B * n, 3072), 7.0, device=DEV)
+    lut, data, sz = normalize_lut().to(DEV), u8.data.to(DEV), u8.sizes.to(DEV)
+    check(lib.rmcl_image_u8_to_patches(P(data), P(sz), P(sel_k), P(cnt_k), gh * gw, B, n, Hmax, Wmax, 32, P(lut), P(out), stream()))
+    assert torch.equal(out, ref)
+    if all(s == (Hmax, Wmax) for s in sizes):                        # dense form: no selection
+        dense = torch.empty(B * gh * gw, 3072, device=DEV)
+        check(lib.rmcl_im2patch_f32(P(img), P(dense), B, 3, Hmax, Wmax, 32, 0, stream()))
+        out2 = torch.empty_like(dense)
+        check(lib.rmcl_image_u8_to_patches(P(data), P(sz), None, None, 0, B, gh * gw, Hmax, Wmax, 32, P(lut), P(out2), stream()))
+        assert torch.equal(out2, dense)
+
+
+@pytest.mark.parametrize("sizes", [[(384, 384)] * 4, [(384, 352), (320, 384), (224, 288), (384, 384)]])
+def test_training_step_on_a_byte_batch_equals_the_float_batch(sizes):
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=len(sizes), adv_steps_img=2)
+    batch = O.synthetic_batch(ocfg, len(sizes), 4, ragged_text=True)
+    u8 = byte_batch(sizes, 384, 384, 9)
+    res = []
+    for kind in ("float", "bytes"):
+        m, _ = make_module(ocfg, 5, "bf16", k_seed=6)
+        b = dev_batch(dict(batch, image=[u8.float_image()]))
+        if kind == "bytes":
+            b["image"] = [u8]                                        # host bytes: bind_batch moves and normalises them
+        m.zero_grad()
+        loss = m.training_step(b, 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss), m.engine.g32.clone(), m.proj_queue.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])

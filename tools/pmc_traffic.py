@@ -59,6 +59,9 @@ def main():
                             "note": "mean over the replayed fc1 / fc2 forward launches of (2 x FETCH_SIZE + WRITE_SIZE) KiB from separate rocprofv3 "
                                     "--pmc passes (gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE x 2); algorithmic = operands + outputs once",
                             "detail": res}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                                             # the identity of the kernel sources this record was measured on
+    rec["kernel_build_id"] = bench.roofline_kernel_build_id()
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(rec, open(args.out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
