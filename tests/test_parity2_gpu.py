@@ -515,7 +515,7 @@ def test_bs64_step_on_the_benchmarked_kernels_against_the_cpu_oracle(objective):
         e["delta_same_saturation_frac"] = float(same.float().mean())
         e["delta_mean_abs_diff_over_eps"] = float((d - dr).abs().mean()) / eps
         assert float(d.abs().max()) <= eps + 1e-9
-        assert e["delta_same_saturation_frac"] > 0.93 and e["delta_mean_abs_diff_over_eps"] < 0.1, e
+        assert e["delta_same_saturation_frac"] > 0.97 and e["delta_mean_abs_diff_over_eps"] < 0.04, e     # measured 0.990 / 0.010
     params = dict(m.named_parameters())
     worst, worst_name, n_cmp = 0.0, "", 0
     for n, t in po.items():
@@ -537,9 +537,10 @@ def test_bs64_step_on_the_benchmarked_kernels_against_the_cpu_oracle(objective):
         cosines[n] = float((a * b).sum() / (a.norm() * b.norm()))
     e["grad_cosine_min"] = min(cosines.values())
     record(f"bs64_benchmarked_kernels_vs_oracle_{objective}", **e)
-    # bf16 GEMM operands against an fp32 oracle (bounds ~3-4x the measured values; the fp32 engine is the 1e-3 gate, section 4)
-    assert e["loss"] < 0.15 and e["k"] < 4e-2 and e["q"] < 4e-2 and e["queue_block"] < 4e-2, e
-    assert worst < 0.06 and e["grad_cosine_min"] > 0.985, (e, cosines)
+    # bf16 GEMM operands against an fp32 oracle; bounds ~4x the measured values (rmcl_pgd / clean_itm: loss 3.3e-3 / 8e-4 at ~50, k
+    # 1.4e-3, q 1e-3, worst gradient-norm error 4e-4 / 3e-3, smallest gradient cosine 0.9996); the fp32 engine is the 1e-3 gate
+    assert e["loss"] < 0.03 and e["k"] < 6e-3 and e["q"] < 6e-3 and e["queue_block"] < 6e-3, e
+    assert worst < 1.5e-2 and e["grad_cosine_min"] > 0.998, (e, cosines)
 
 
 # -------------------------------------------------------------------------------------------------------------------
