@@ -261,6 +261,12 @@ int rmcl_heads_backward(const rmcl_dims* d, const float* pool32, const float* he
 int64_t rmcl_infonce_ws_bytes(int B, int64_t Kq);
 int rmcl_infonce_f32(const float* q, const float* k, const float* queue, int B, int proj, int64_t Kq, float temperature,
                      float grad_scale, float* dq, float* rows_out, float* loss_sum, void* workspace, void* stream);
+/* The same pass for the bf16 engine: logits and dq on the bf16 matrix cores with SPLIT operands (x = bf16(x) + bf16(x - bf16(x)),
+ * three products per pair: 2^-16 relative per product, fp32 softmax / accumulation) - the fp32 queue is read as it is.
+ * with_metrics = 0 (the PGD passes consume dq only): rows_out[6..8] (queue-distance means) are written as 0.              */
+int rmcl_infonce_split_bf16(const float* q, const float* k, const float* queue, int B, int proj, int64_t Kq, float temperature,
+                            float grad_scale, float* dq, float* rows_out, float* loss_sum, void* workspace, int with_metrics,
+                            void* stream);
 
 /* PGD ascent step in patch layout (attack/pgd_attack_vilt.py:162-173).  amax_scratch: 64 * B uint32 (per-block partial maxima of
  * |grad| per sample; need not be cleared).                                                          */

@@ -53,7 +53,7 @@ class PGDAttack_moco(PGDAttack):
             if step == 0 and before_first_loss is not None:
                 before_first_loss()
             # CE(label 0) / K, mean over the batch (:152-158); gradient wrt q only
-            eng.infonce(pb, grad_scale=1.0 / (pb.B * K), want_dq=True)
+            eng.infonce(pb, grad_scale=1.0 / (pb.B * K), want_dq=True, metrics=False)     # (only dq and the prediction are read)
             if step == 0 and clean_out is not None:
                 clean_out["prediction"] = pb.rows[:, 1].clone()
                 clean_out["q"] = pb.q.clone()

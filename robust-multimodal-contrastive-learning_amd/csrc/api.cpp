@@ -305,6 +305,12 @@ int rmcl_infonce_f32(const float* q, const float* k, const float* queue, int B, 
   RMCL_REQUIRE(q && k && queue && rows_out && workspace, "infonce: NULL argument");
   return rmcl_infonce(q, k, queue, B, proj, Kq, temperature, grad_scale, dq, rows_out, loss_sum, workspace, (hipStream_t)stream);
 }
+int rmcl_infonce_split_bf16(const float* q, const float* k, const float* queue, int B, int proj, int64_t Kq, float temperature,
+                            float grad_scale, float* dq, float* rows_out, float* loss_sum, void* workspace, int with_metrics, void* stream) {
+  RMCL_REQUIRE(q && k && queue && rows_out && workspace, "infonce: NULL argument");
+  return rmcl_infonce(q, k, queue, B, proj, Kq, temperature, grad_scale, dq, rows_out, loss_sum, workspace, (hipStream_t)stream,
+                      with_metrics ? 1 : 2);
+}
 int rmcl_pgd_step(const void* grad, int dtype, float* delta, uint32_t* amax_scratch, int B, int64_t per_sample, float lr,
                   float eps, void* stream) {
   RMCL_REQUIRE(grad && delta && amax_scratch, "pgd_step: NULL argument");

@@ -76,10 +76,12 @@ __device__ __forceinline__ bf16x8 st_ld_b(const char* lds_b, int off, int s) {
   if (KC) {
     return *reinterpret_cast<const bf16x8*>(lds_b + off);          // (off already holds the k-step swizzle)
   } else {
+    // transposed reads by inline asm (rmcl_common.h lds_read_tr16_asm): the builtin made hipcc drain the in-flight LDS-DMA with
+    // vmcnt(0) at the head of every k-tile.  Every caller retires them with an explicit lgkmcnt(0) + sched_barrier before the MFMAs.
     union { bf16x8 v; s16x4 h[2]; } u;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds_b + off + s * (32 * 384) + h * (4 * 384)));
+    const uint32_t a = lds_addr(lds_b + off);
+    if (s == 0) { u.h[0] = lds_read_tr16_asm<0>(a); u.h[1] = lds_read_tr16_asm<4 * 384>(a); }
+    else { u.h[0] = lds_read_tr16_asm<32 * 384>(a); u.h[1] = lds_read_tr16_asm<32 * 384 + 4 * 384>(a); }
     return u.v;
   }
 }
@@ -473,13 +475,21 @@ __global__ __launch_bounds__(512) void gemm_dw_group_kernel(DwGroupArgs a) {
     ones = u.v;
   }
   auto bias_step = [&](const char* cur) {                      // column sums of the A tile in LDS stage `cur` (both k-steps)
+    bf16x8 f0[2], f1[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        if (i == bi0) accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, st_ld_b<false>(cur, c.aoffi[i], s), accb[0], 0, 0, 0);
-        if (i == bi1) accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, st_ld_b<false>(cur, c.aoffi[i], s), accb[1], 0, 0, 0);
+        if (i == bi0) f0[s] = st_ld_b<false>(cur, c.aoffi[i], s);
+        if (i == bi1) f1[s] = st_ld_b<false>(cur, c.aoffi[i], s);
       }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (asm reads: no compiler-inserted wait)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f0[s], accb[0], 0, 0, 0);
+      if (bi1 < 6) accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f1[s], accb[1], 0, 0, 0);
     }
   };
   int sc = 0, sn = 2, kt = 0;

@@ -369,6 +369,265 @@ __global__ __launch_bounds__(256) void infonce_partial2_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the folded pass on the bf16 matrix cores with SPLIT operands (x = hi + lo, hi = bf16(x), lo = bf16(x - hi)):
+// a.b ~ a_hi.b_hi + a_hi.b_lo + a_lo.b_hi leaves a 2^-16 relative error per product - logits of +-40 move by ~1e-4, two orders
+// below what plain bf16 logits would cost - at 3/16 of the exact-f32 MFMA time (v_mfma_f32_16x16x32_bf16: 16 cycles for 16 K FLOP
+// against 64 cycles for 4 K FLOP of v_mfma_f32_32x32x2_f32).  The fp32 queue is read as before (no shadow copy, no change to the
+// enqueue) and split on its way into LDS.  One image per sub-slice and half: [128 c][64 j] bf16, 128-byte rows, the transposed-read
+// swizzle of attention.hip's V image - read by ds_read_b64_tr_b16 for the logits (contraction over c) and by rows for
+// dq += P Qs^T (contraction over j).  Same partials as infonce_partial2_kernel: infonce_combine2_kernel merges them.
+//   logits^T tile: D[queue column][query row] = sum_c A[column][c] B[c][row]: wave w owns column tile w, 4 row tiles, K = 128:
+//       48 MFMAs per sub-slice; dq^T: D[c][row] = sum_j Qs[c][j] P[row][j]: wave w owns c tiles 2w, 2w+1, 4 row tiles: 48 MFMAs.
+// METRICS = false (the PGD passes: only dq is consumed) skips the column norms and the queue-distance sums.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 nbf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void nce_split8(const float (&x)[8], nbf16x8& hi, nbf16x8& lo) {
+  union { nbf16x8 v; bf16_t e[8]; } h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h.e[i] = f2bf(x[i]);
+    l.e[i] = f2bf(x[i] - bf2f(h.e[i]));
+  }
+  hi = h.v;
+  lo = l.v;
+}
+// A operand of a 32-deep k step out of a [k rows][64 columns] image (128-byte rows, 32-byte group swizzle ^ ((row >> 1) & 3)):
+// rows of the MFMA = the 16 image columns of tile `dt`, k order (g, j) -> base + 16 (j >> 2) + 4 g + (j & 3)
+__device__ __forceinline__ nbf16x8 nce_frag_tr(const char* img, int base, int dt, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  union { nbf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int row = base + 16 * half + 4 * g + q;
+    const int t = dt ^ ((row >> 1) & 3);
+    u.h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + row * 128 + t * 32 + p * 8));
+  }
+  return u.v;
+}
+// row fragment (rows row0 + lane % 16, k = 32 s + 8 (lane / 16) .. + 7) of the same image
+__device__ __forceinline__ nbf16x8 nce_frag_row(const char* img, int row0, int s, int lane) {
+  const int row = row0 + (lane & 15);
+  const int c = 4 * s + (lane >> 4);
+  const int cp = (((c >> 1) ^ ((row >> 1) & 3)) << 1) | (c & 1);
+  return *reinterpret_cast<const nbf16x8*>(img + row * 128 + cp * 16);
+}
+
+#define NCE3_IMG (PD * 128)                  // one half image: 128 rows x 128 B = 16 KiB
+
+template <bool METRICS>
+__global__ __launch_bounds__(256) void infonce_partial3_kernel(const float* __restrict__ q, const float* __restrict__ queue, long Kq,
+                                                               int B, float invT, float* __restrict__ part, float* __restrict__ dq_part,
+                                                               int Bpad) {
+  extern __shared__ __attribute__((aligned(16))) char smc[];
+  auto Qhi = [&](int i) { return smc + i * (2 * NCE3_IMG); };
+  auto Qlo = [&](int i) { return smc + i * (2 * NCE3_IMG) + NCE3_IMG; };
+  float* Ps = reinterpret_cast<float*>(smc + 4 * NCE3_IMG);     // [RT][PLD] logits, then probabilities; first the query block [RT][129]
+  constexpr int PLD = 68;                                       // 16-byte aligned rows, 4-row period over the 64 banks
+  float* c2p = Ps + RT * 132;                                   // [4][SL2]
+  float* q2 = c2p + 4 * SL2;                                    // [RT]
+  float* fo = q2 + RT;
+  float* fs = fo + RT;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
+  const int wg = blockIdx.x, r0 = blockIdx.y * RT;
+  const long j00 = (long)wg * (SL2 * NS2);
+
+  // ---- query block -> LDS [RT][129] (inside the Ps area) -> B-operand fragments (hi, lo) in the transposed reads' k order
+  {
+    for (int i = 0; i < 8; ++i) {
+      const int v = t + 256 * i, r = v >> 5, cq = (v & 31) * 4;
+      float4 x = make_float4(0, 0, 0, 0);
+      if (r0 + r < B) x = *reinterpret_cast<const float4*>(q + (long)(r0 + r) * PD + cq);
+      float* d = Ps + r * 129 + cq;
+      d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+      float sq = (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+#pragma unroll
+      for (int o = 1; o <= 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+      if ((t & 31) == 0) q2[r] = sq;
+    }
+  }
+  float4 pre[8];
+  auto fetch = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int v = t + 256 * i, c = v >> 4, jq = (v & 15) * 4;
+      pre[i] = *reinterpret_cast<const float4*>(queue + (long)c * Kq + j00 + (long)s * SL2 + jq);
+    }
+  };
+  auto deposit = [&](int buf) {
+    char* hi = Qhi(buf);
+    char* lo = Qlo(buf);
+    float cs0 = 0.f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int v = t + 256 * i, c = v >> 4, jq = (v & 15) * 4;
+      const float x[4] = {pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+      bf16_t h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { h[e] = f2bf(x[e]); l[e] = f2bf(x[e] - bf2f(h[e])); }
+      const int off = c * 128 + (((jq >> 4) ^ ((c >> 1) & 3)) << 5) + ((jq & 15) << 1);
+      *reinterpret_cast<uint2*>(hi + off) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+      *reinterpret_cast<uint2*>(lo + off) = make_uint2((uint32_t)l[0] | ((uint32_t)l[1] << 16), (uint32_t)l[2] | ((uint32_t)l[3] << 16));
+      if (METRICS) { cs0 += x[0] * x[0]; cs1 += x[1] * x[1]; cs2 += x[2] * x[2]; cs3 += x[3] * x[3]; }
+    }
+    if (METRICS) {
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        cs0 += __shfl_xor(cs0, o, 64); cs1 += __shfl_xor(cs1, o, 64); cs2 += __shfl_xor(cs2, o, 64); cs3 += __shfl_xor(cs3, o, 64);
+      }
+      if (lane < 16) {
+        float* o = c2p + wave * SL2 + lane * 4;
+        o[0] = cs0; o[1] = cs1; o[2] = cs2; o[3] = cs3;
+      }
+    }
+  };
+  fetch(0);
+  __syncthreads();
+  nbf16x8 qh[4][4], ql[4][4];                                  // [row tile][k step]: q[16 rt + lane % 16][32 ks + 16 (j >> 2) + 4 g + (j & 3)]
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+      const float* src = Ps + (16 * rt + (lane & 15)) * 129 + 32 * ks + 4 * g;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = src[16 * (j >> 2) + (j & 3)];
+      nce_split8(x, qh[rt][ks], ql[rt][ks]);
+    }
+  deposit(0);
+  __syncthreads();                                             // (the query block's LDS copy is dead: Ps is free)
+
+  f32x4 dq[2][4];                                              // running dq^T: c tile 2 wave + i, row tile rt: lane = query row, regs = 4 c
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) dq[i][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int row = t >> 2, sub = t & 3;
+  float m_run = -INFINITY, z_run = 0.f, best = -INFINITY, sd = 0.f, sc = 0.f, so = 0.f;
+  int bi = 0;
+  const float qq = q2[row];
+
+  for (int s = 0; s < NS2; ++s) {
+    const char* hi = Qhi(s & 1);
+    const char* lo = Qlo(s & 1);
+    if (s + 1 < NS2) fetch(s + 1);
+    {  // step 1: logits^T tile of this wave's 16 columns x 64 rows
+      f32x4 acc[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const nbf16x8 ah = nce_frag_tr(hi, 32 * ks, wave, lane), al = nce_frag_tr(lo, 32 * ks, wave, lane);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, qh[rt][ks], acc[rt], 0, 0, 0);
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ql[rt][ks], acc[rt], 0, 0, 0);
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, qh[rt][ks], acc[rt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)                            // lane: query row 16 rt + lane % 16, columns 16 wave + 4 g .. + 3
+        *reinterpret_cast<float4*>(Ps + (16 * rt + (lane & 15)) * PLD + 16 * wave + 4 * g) = make_float4(acc[rt][0], acc[rt][1], acc[rt][2], acc[rt][3]);
+    }
+    __syncthreads();
+    {  // step 2: block softmax of this sub-slice (+ metrics), merged into the running values: 4 threads per row, 16 columns each
+      float sbest = -INFINITY;
+      int sbi = 0;
+      for (int i = 0; i < SL2 / 4; ++i) {
+        const int col = 4 * i + sub;
+        const float dot = Ps[row * PLD + col];
+        if (dot > sbest) { sbest = dot; sbi = col; }
+        if (METRICS) {
+          const float cc = (c2p[col] + c2p[SL2 + col]) + (c2p[2 * SL2 + col] + c2p[3 * SL2 + col]);
+          sd += sqrtf(fmaxf(qq + cc - 2.f * dot, 0.f));
+          sc += dot / fmaxf(sqrtf(qq) * sqrtf(cc), 1e-6f);
+          so += dot;
+        }
+      }
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) {
+        const float ob = __shfl_xor(sbest, o, 64);
+        const int oi = __shfl_xor(sbi, o, 64);
+        if (ob > sbest || (ob == sbest && oi < sbi)) { sbest = ob; sbi = oi; }
+      }
+      const float ms = sbest * invT;
+      float z = 0.f;
+      for (int i = 0; i < SL2 / 4; ++i) {
+        const int col = 4 * i + sub;
+        const float p = __expf(Ps[row * PLD + col] * invT - ms);
+        Ps[row * PLD + col] = p;
+        z += p;
+      }
+      z += __shfl_xor(z, 1, 64);
+      z += __shfl_xor(z, 2, 64);
+      const float mn = fmaxf(m_run, ms), f_old = __expf(m_run - mn), f_s = __expf(ms - mn);
+      z_run = z_run * f_old + z * f_s;
+      m_run = mn;
+      if (sbest > best) { best = sbest; bi = s * SL2 + sbi; }
+      if (sub == 0) { fo[row] = f_old; fs[row] = f_s; }
+    }
+    __syncthreads();
+    {  // step 3: dq^T = dq^T * f_old + Qs (f_s P)^T
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const float f = fo[16 * rt + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) dq[i][rt] *= f;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        nbf16x8 ph[4], pl[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const int pr = 16 * rt + (lane & 15);
+          const float fsr = fs[pr];
+          const float4 a = *reinterpret_cast<const float4*>(Ps + pr * PLD + 32 * ks + 8 * g);
+          const float4 b = *reinterpret_cast<const float4*>(Ps + pr * PLD + 32 * ks + 8 * g + 4);
+          const float x[8] = {a.x * fsr, a.y * fsr, a.z * fsr, a.w * fsr, b.x * fsr, b.y * fsr, b.z * fsr, b.w * fsr};
+          nce_split8(x, ph[rt], pl[rt]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int c0 = 16 * (2 * wave + i);
+          const nbf16x8 ah = nce_frag_row(hi, c0, ks, lane), al = nce_frag_row(lo, c0, ks, lane);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) {
+            dq[i][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, ph[rt], dq[i][rt], 0, 0, 0);
+            dq[i][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, pl[rt], dq[i][rt], 0, 0, 0);
+            dq[i][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, ph[rt], dq[i][rt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (s + 1 < NS2) deposit((s + 1) & 1);
+    __syncthreads();
+  }
+  if (METRICS) {
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      sd += __shfl_xor(sd, o, 64);
+      sc += __shfl_xor(sc, o, 64);
+      so += __shfl_xor(so, o, 64);
+    }
+  }
+  if (sub == 0 && r0 + row < B) {
+    float* o = part + ((long)wg * Bpad + r0 + row) * NPART;
+    o[0] = m_run; o[1] = z_run; o[2] = best; o[3] = __int_as_float((int)(j00 + bi));
+    o[4] = sd; o[5] = sc; o[6] = so; o[7] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int rr = r0 + 16 * rt + (lane & 15);
+      if (rr < B)
+        *reinterpret_cast<float4*>(dq_part + ((long)wg * Bpad + rr) * PD + 16 * (2 * wave + i) + 4 * g) =
+            make_float4(dq[i][rt][0], dq[i][rt][1], dq[i][rt][2], dq[i][rt][3]);
+    }
+}
+
 // One workgroup per query row: merge slice partials, add the positive pair.  1024 threads = 8 groups of PD: group 0 does the
 // scalar bookkeeping, all eight split the slices of the Z / dq merge (the serial 512-slice loop was latency-bound).
 // rows_out[i, 0..9] = loss_i, pred_i (argmax of the logits incl. the positive at index 0),
@@ -554,7 +813,7 @@ long rmcl_infonce_workspace_bytes(int B, long Kq) {
 }
 
 int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int Pd, long Kq, float T, float gscale, float* dq,
-                 float* rows_out, float* loss_sum, void* workspace, hipStream_t s) {
+                 float* rows_out, float* loss_sum, void* workspace, hipStream_t s, int form) {
   RMCL_REQUIRE(Pd == PD, "infonce: projection dim must be 128");
   RMCL_REQUIRE(Kq % SLICE == 0 && Kq > 0, "infonce: queue length must be a multiple of 128");
   RMCL_REQUIRE(B > 0, "infonce: empty batch");
@@ -568,7 +827,19 @@ int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int 
     attr_set = true;
   }
   int nparts = ns;
-  if (Kq % (SL2 * NS2) == 0 && g_infonce_fold >= 1) {           // 256 columns per workgroup, four folded 64-column sub-slices
+  if (form != 0 && Kq % (SL2 * NS2) == 0 && g_infonce_fold >= 1) {
+    // split-bf16 matrix cores (form 1: with the queue-distance metrics; 2: without - the PGD passes read dq only)
+    nparts = (int)(Kq / (SL2 * NS2));
+    const size_t lds3 = 4 * NCE3_IMG + (RT * 132 + 4 * SL2 + 3 * RT) * sizeof(float);
+    static bool attr3 = false;
+    if (!attr3) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      attr3 = true;
+    }
+    if (form == 2) RMCL_LAUNCH(infonce_partial3_kernel<false>, dim3(nparts, Bpad / RT), dim3(256), lds3, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
+    else RMCL_LAUNCH(infonce_partial3_kernel<true>, dim3(nparts, Bpad / RT), dim3(256), lds3, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
+  } else if (Kq % (SL2 * NS2) == 0 && g_infonce_fold >= 1) {           // 256 columns per workgroup, four folded 64-column sub-slices
     nparts = (int)(Kq / (SL2 * NS2));
     const size_t lds2 = (2 * PD * ILD2 + RT * ILD2 + 4 * SL2 + 3 * RT) * sizeof(float);
     static bool attr2 = false;

@@ -104,8 +104,10 @@ int rmcl_adamw(float* p, const float* g, float* m, float* v, void* p_lp, const l
                hipStream_t s);
 
 long rmcl_infonce_workspace_bytes(int B, long Kq);
+// form 0: exact-f32 matrix cores (the fp32 parity engine); 1: split-bf16 matrix cores (x = hi + lo, three products: 2^-16 relative);
+// 2: as 1 without the queue-distance metrics (rows_out[6..8] = 0)
 int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int Pd, long Kq, float T, float gscale, float* dq,
-                 float* rows_out, float* loss_sum, void* workspace, hipStream_t s);
+                 float* rows_out, float* loss_sum, void* workspace, hipStream_t s, int form = 0);
 
 int rmcl_cost_finish(float* cost, const int* txt_valid, const int* img_valid, int B, int Lt, int Li, int ld, hipStream_t s);
 int rmcl_wpa_dist(const float* cost, const float* T, const float* w, float* dist, float* dsim, int B, int Lt, int Li, int ld,

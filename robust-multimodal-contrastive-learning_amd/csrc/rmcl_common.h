@@ -108,6 +108,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ds_read_b64_tr_b16 through inline asm.  The builtin (__builtin_amdgcn_ds_read_tr16_b64_v4i16) carries no alias information, so
+// hipcc (ROCm 7.2) orders it behind EVERY LDS-DMA still in flight with an s_waitcnt vmcnt(0) - in a k-loop that keeps the next
+// tiles' global_load_lds in flight across barriers that wait drains the whole prefetch at the head of every k-tile (found in the
+// weight-gradient launch's .s: one vmcnt(0) per k-tile in front of its 36 transposed reads; row reads through a bf16x8-typed
+// pointer are spared by type-based alias analysis).  The asm form is invisible to that pass; the CALLER owns both waits: the counted
+// vmcnt + barrier that makes the DMA'd bytes visible, and an explicit s_waitcnt lgkmcnt(0) followed by sched_barrier(0) before the
+// first use of the result (cdna_hip_programming.md 5.7 form (iii)).  `a` = LDS byte address (lds_addr), OFF = immediate offset.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_read_tr16_asm(uint32_t a) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+  return v;
+}
+
 // ---- host side -------------------------------------------------------------------------------
 #ifdef __cplusplus
 extern "C" void rmcl_set_error(const char* msg);

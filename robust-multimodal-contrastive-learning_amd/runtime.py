@@ -515,8 +515,15 @@ class Engine:
         pb.loss_i += 1
         return pb.loss_sum
 
-    def infonce(self, pb: PassBuffers, grad_scale: float, want_dq: bool):
+    def infonce(self, pb: PassBuffers, grad_scale: float, want_dq: bool, metrics: bool = True):
+        """metrics=False: the caller reads only loss / dq (PGD passes) - the bf16 engine's form then skips the queue-distance sums.
+        bf16 passes run the split-bf16 matrix-core form (include/rmcl.h rmcl_infonce_split_bf16), fp32 passes the exact one."""
         self.zero_scalar(pb)
+        if pb.dtype == L.BF16 and not self.exact and os.environ.get("RMCL_INFONCE_EXACT", "0") != "1":
+            check(lib.rmcl_infonce_split_bf16(P(pb.q), P(pb.k), P(self.queue), pb.B, 128, I64(self.num_negative),
+                                              F(self.cfg["temperature"]), F(grad_scale), P(pb.dq if want_dq else None), P(pb.rows),
+                                              P(pb.loss_sum), P(pb.nce_ws), 1 if metrics else 0, stream_ptr()), "infonce")
+            return
         check(lib.rmcl_infonce_f32(P(pb.q), P(pb.k), P(self.queue), pb.B, 128, I64(self.num_negative),
                                    F(self.cfg["temperature"]), F(grad_scale), P(pb.dq if want_dq else None), P(pb.rows),
                                    P(pb.loss_sum), P(pb.nce_ws), stream_ptr()), "infonce")

@@ -251,7 +251,7 @@ def compute_moco_contrastive(pl_module, batch):
         eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op, cls_tail=True)     # clean query
         eng.heads_forward(pb, key=False)
         join_key_stream()
-        eng.infonce(pb, 0.0, want_dq=False)
+        eng.infonce(pb, 0.0, want_dq=False, metrics=False)
         clean = {"prediction": pb.rows[:, 1].clone(), "q": pb.q.clone()}
     prediction_original = clean.get("prediction")
 

@@ -74,4 +74,7 @@ def test_training_step_on_a_byte_batch_equals_the_float_batch(sizes):
         loss.backward()
         torch.cuda.synchronize()
         res.append((float(loss), m.engine.g32.clone(), m.proj_queue.clone()))
-    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    # identical patch rows in, so identical loss / keys; the gradient arena up to the order of its float atomics (bias sums, embeddings)
+    # (the batch loss is an atomic sum over the rows: equal up to the order of 4 float adds)
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and torch.equal(res[0][2], res[1][2])
+    assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 1e-6

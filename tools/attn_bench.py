@@ -34,6 +34,20 @@ fwd = lambda: check(lib.rmcl_attention_fwd(P(qkv), P(mask), P(out), P(probs), P(
 b2 = lambda: check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), None, P(dqkv), P(scores), P(dS), B, N, H, L.BF16, 0, stream()))
 b1 = lambda: check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), P(out), P(dqkv), P(scores), P(dS), B, N, H, L.BF16, 0, stream()))
 print(f"fwd {t(fwd):.1f} us   bwd two kernels {t(b2):.1f} us   bwd one kernel {t(b1):.1f} us")
+flush = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+
+
+def cold(fn, n=7):
+    ts = []
+    for _ in range(n):
+        flush.fill_(1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    return sorted(ts)[n // 2]
+
+
 for wv in (4, 6, 8, 12):
     lib.rmcl_tune_set(4, wv)
     print(f"fwd with {wv} waves per workgroup: {t(fwd):.1f} us")

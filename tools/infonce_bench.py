@@ -33,5 +33,14 @@ for fold in (0, 1):
     run()
     res[fold] = (dq.clone(), rows.clone(), float(loss))
     print(f"fold={fold}: {t():.1f} us per call (partial + combine); queue 33.5 MB -> {33.5e6 / (t() * 1e-6) / 1e12:.2f} TB/s effective")
+run3 = lambda m: (lambda: check(lib.rmcl_infonce_split_bf16(P(q), P(k), P(queue), B, 128, I64(Kq), F(0.07), F(1.0 / B), P(dq), P(rows), P(loss), P(ws), m, stream())))
+for m in (1, 0):
+    run = run3(m)
+    loss.zero_()
+    run()
+    l3 = float(loss)
+    us = t()
+    print(f"split-bf16 form, metrics={m}: {us:.1f} us per call; queue 33.5 MB -> {33.5e6 / (us * 1e-6) / 1e12:.2f} TB/s effective; "
+          f"loss {l3:.6f} vs exact-f32 {res[1][2]:.6f} (drift {abs(l3 - res[1][2]):.2e}); max |dq diff| {float((res[1][0] - dq).abs().max()):.2e}")
 for f in (1,):
     print(f"form {f} vs 0: max |dq diff|", float((res[0][0] - res[f][0]).abs().max()), " rows diff", float((res[0][1] - res[f][1]).abs().max()), res[0][2], res[f][2])
