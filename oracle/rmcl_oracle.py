@@ -183,9 +183,15 @@ def gelu_erf(x: Tensor) -> Tensor:
 
 
 def text_embed(p: Params, pre: str, ids: Tensor, word_embeds: Optional[Tensor] = None) -> Tensor:
-    """HF BertEmbeddings (vilt_module.py:26-38,293): LN_{1e-12}(word[id] + type[0] + pos[0:L])."""
+    """HF BertEmbeddings (vilt_module.py:26-38,293): LN_{1e-12}(word[id] + type[0] + pos[0:L]).  word_embeddings is
+    nn.Embedding(vocab, hidden, padding_idx=pad_token_id = 0) (transformers 4.2.1 modeling_bert.py BertEmbeddings.__init__): the [PAD]
+    row never receives a gradient, whatever the loss reads."""
     L = ids.shape[1]
-    we = p[pre + "text_embeddings.word_embeddings.weight"][ids] if word_embeds is None else word_embeds
+    if word_embeds is None:
+        w = p[pre + "text_embeddings.word_embeddings.weight"]
+        we = torch.nn.functional.embedding(ids, w, padding_idx=0)
+    else:
+        we = word_embeds
     e = (we
          + p[pre + "text_embeddings.token_type_embeddings.weight"][0]
          + p[pre + "text_embeddings.position_embeddings.weight"][:L][None])

@@ -39,6 +39,22 @@ def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
     mod.register_parameter(parts[-1], param)
 
 
+class _InferFeatures(torch.autograd.Function):
+    """The four feature tensors of ``infer`` with a backward: their gradients are handed to the closure, which launches the HIP
+    heads / encoder backward into the gradient arena (every ``param.grad`` is a view of it)."""
+
+    @staticmethod
+    def forward(ctx, anchor, closure, prescale, text_feats, image_feats, cls_feats, raw_cls_feats):
+        ctx.closure, ctx.prescale = closure, float(prescale)
+        return text_feats.clone(), image_feats.clone(), cls_feats.clone(), raw_cls_feats.clone()
+
+    @staticmethod
+    def backward(ctx, g_txt, g_img, g_cls, g_raw):
+        sc = (lambda g: None if g is None else (g * ctx.prescale if ctx.prescale != 1.0 else g))
+        ctx.closure(sc(g_txt), sc(g_img), sc(g_cls), sc(g_raw))
+        return None, None, None, None, None, None, None
+
+
 class ViLTransformerSS(nn.Module):
     def __init__(self, config, device="cuda:0", compute_dtype="bf16", exact=False, pgd_dtype=None):
         super().__init__()
@@ -257,9 +273,13 @@ class ViLTransformerSS(nn.Module):
         eng = self.engine
         eng.dropout_on = self.training and eng.drop_p > 0
         text_ids, text_masks = batch["text_ids"], batch["text_masks"]
-        pb = eng.bind_batch(text_ids, text_masks, batch["image"][0])
+        # the reference's infer is an ordinary differentiable forward (vilt_module.py:275-351): with autograd on, the query pass keeps
+        # the FULL stash and the returned features carry a backward into the gradient arena (the momentum pass never does: k_* get no
+        # gradients, vilt_module.py:270-273)
+        need_grad = (not key) and torch.is_grad_enabled()
+        pb = eng.bind_batch(text_ids, text_masks, batch["image"][0], tag="infer" if need_grad else "moco")
         op = eng.make_operand(pb)
-        eng.encoder_forward(pb, key=key, mode=L.MODE_INFER, patchesT=op)
+        eng.encoder_forward(pb, key=key, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op)
         eng.heads_forward(pb, key=key, want_q=False)
         d = pb.d
         N = d.L + 1 + d.P
@@ -273,11 +293,29 @@ class ViLTransformerSS(nn.Module):
             sel = pb.geom.sel[:, : pb.geom.n].to(torch.int64)
             patch_index = torch.stack([sel // pb.geom.gw, sel % pb.geom.gw], dim=-1)
             grid_hw = (pb.geom.gh, pb.geom.gw)
+        feats = (x[:, : d.L].clone(), x[:, d.L:].clone(), pb.cls.clone(), x[:, 0].clone())
+        if need_grad:
+            def backward(g_txt, g_img, g_cls, g_raw, pb=pb, op=op, N=N):
+                dxn = torch.zeros(pb.B, N, d.D, device=eng.device)
+                if g_txt is not None:
+                    dxn[:, : d.L] += g_txt.to(torch.float32)
+                if g_img is not None:
+                    dxn[:, d.L:] += g_img.to(torch.float32)
+                if g_raw is not None:
+                    dxn[:, 0] += g_raw.to(torch.float32)
+                dcls = torch.zeros(pb.B, d.D, device=eng.device) if g_cls is None else g_cls.to(torch.float32).contiguous()
+                eng.heads_backward(pb, None, dcls, with_grads=True)          # pooler: tanh(W x[:, 0] + b) (heads.py:10-20)
+                dxn[:, 0] += pb.dcls
+                eng.encoder_backward(pb, L.MODE_FULL, op, dxn.view(pb.B * N, d.D), cls_only=False, dpatches=None)
+                self.after_backward()
+
+            self.step_sync.begin_step()
+            feats = _InferFeatures.apply(self.grad_anchor, backward, self.grad_prescale(), *feats)
         ret = {
-            "text_feats": x[:, : d.L].clone(),
-            "image_feats": x[:, d.L:].clone(),
-            "cls_feats": pb.cls.clone(),
-            "raw_cls_feats": x[:, 0].clone(),
+            "text_feats": feats[0],
+            "image_feats": feats[1],
+            "cls_feats": feats[2],
+            "raw_cls_feats": feats[3],
             "image_masks": pb.co_mask[:, d.L:].to(torch.int64),
             "text_ids": text_ids,
             "text_masks": text_masks,
@@ -288,8 +326,11 @@ class ViLTransformerSS(nn.Module):
             ret["text_labels"] = batch.get("text_labels")
         return ret
 
-    @torch.no_grad()
     def infer(self, batch, mask_text=False, mask_image=False, image_token_type_idx=1, image_embeds=None, image_masks=None):
+        """vilt_module.py:275-351.  Differentiable like the reference's when autograd is on (``text_feats`` / ``image_feats`` /
+        ``cls_feats`` / ``raw_cls_feats`` back-propagate into every query parameter's ``.grad``); ``torch.no_grad()`` gives the
+        stash-free inference pass.  The ``image_embeds`` shortcut (pre-computed visual_embed output, used by the reference's
+        downstream tasks only) is not built."""
         return self._infer(batch, False, mask_text, mask_image, image_token_type_idx, image_embeds, image_masks)
 
     @torch.no_grad()

@@ -168,7 +168,8 @@ def test_bf16_12_layers_against_reference_golden(pgd_dtype):
     m, p = make_module(ocfg, sw, "bf16", pgd_dtype=pgd_dtype)
     batch = O.synthetic_batch(ocfg, B, sb, ragged_text=ragged)
     name = "bf16_L12" + ("_pgd_f32" if pgd_dtype else "_pgd_bf16")
-    r = m.infer(dev_batch(batch))
+    with torch.no_grad():                                    # (the stash-free inference pass; with autograd on infer is differentiable)
+        r = m.infer(dev_batch(batch))
     e_cls = float((r["cls_feats"].cpu() - torch.from_numpy(g["cls_feats"])).abs().max())
     e_txt = float((r["text_feats"].cpu() - torch.from_numpy(g["text_feats"])).abs().max())
     assert e_cls < 2.5e-2 and e_txt < 0.06, (e_cls, e_txt)      # measured 5e-3 / 1.5e-2                      # features are O(1..4) after the final LayerNorm
@@ -422,7 +423,8 @@ def test_bf16_ragged_images_track_reference_golden(tag):
     sizes = [tuple(int(v) for v in r) for r in g["sizes"]]
     m, p = make_module(ocfg, sw, "bf16")
     batch = O.synthetic_batch(ocfg, B, sb, ragged_text=ragged, sizes=sizes)
-    r = m.infer(dev_batch(batch))
+    with torch.no_grad():                                    # (the stash-free inference pass; with autograd on infer is differentiable)
+        r = m.infer(dev_batch(batch))
     e_cls = float((r["cls_feats"].cpu() - torch.from_numpy(g["cls_feats"])).abs().max())
     np.testing.assert_array_equal(r["image_masks"].cpu().numpy(), g["image_masks"])
     valid = torch.from_numpy(g["image_masks"]) == 1
@@ -561,7 +563,8 @@ def test_layernorm_fold_matches_separate_layernorm_bs64():
     outs = {}
     for name in ("fold", "separate"):
         m.engine.fold = fold if name == "fold" else {}
-        r = m.infer(dev)
+        with torch.no_grad():                                    # (the stash-free inference pass; with autograd on infer is differentiable)
+            r = m.infer(dev)
         k = torch.nn.functional.normalize(torch.randn(B, 128, generator=torch.Generator().manual_seed(3)), dim=1).to(DEV)
         delta = PGDAttack_moco(dict(m.config)).pgd_attack(m, dev_batch(batch), k_modality=k)
         outs[name] = (r["cls_feats"].cpu(), r["text_feats"].cpu(), r["image_feats"].cpu(), delta.cpu())

@@ -54,7 +54,8 @@ def case(request):
 
 def test_infer_matches_reference_golden(case):
     g, ocfg, m, p, batch = case
-    r = m.infer(dev_batch(batch))
+    with torch.no_grad():                                    # (the stash-free inference pass; with autograd on infer is differentiable)
+        r = m.infer(dev_batch(batch))
     np.testing.assert_allclose(r["cls_feats"].cpu().numpy(), g["cls_feats"], atol=1e-4)
     np.testing.assert_allclose(r["raw_cls_feats"].cpu().numpy(), g["raw_cls_feats"], atol=2e-4)
     np.testing.assert_allclose(r["text_feats"].cpu().numpy(), g["text_feats"], atol=2e-4)
@@ -137,7 +138,8 @@ def test_bf16_path_tracks_fp32_golden():
     ocfg, B, sw, sb, ragged = cfg_from_meta(O, g["meta"])
     m, p = build_module(ocfg, sw, "bf16")
     batch = O.synthetic_batch(ocfg, B, sb, ragged_text=ragged)
-    r = m.infer(dev_batch(batch))
+    with torch.no_grad():                                    # (the stash-free inference pass; with autograd on infer is differentiable)
+        r = m.infer(dev_batch(batch))
     assert float((r["cls_feats"].cpu() - torch.from_numpy(g["cls_feats"])).abs().max()) < 3e-2
     loss = m.training_step(dev_batch(batch), 0)
     assert abs(float(loss) - float(g["moco_loss"])) < 0.5          # logits ~ +-40 in bf16 inputs: 8-bit mantissa
@@ -682,3 +684,36 @@ def test_cls_only_tail_equals_the_dense_last_block(dtype, Bn, layers):
     eng.encoder_forward(pb, key=False, mode=L.MODE_FULL, patchesT=op, cls_tail=True)
     with pytest.raises(L.RmclError):
         eng.encoder_backward(pb, L.MODE_FULL, op, pb.xn, cls_only=False, dpatches=None)
+
+
+def test_public_infer_is_differentiable_like_the_reference():
+    """vilt_module.py:275-351 is an ordinary differentiable forward: a scalar of the four returned feature tensors back-propagates
+    into every query parameter; against the oracle's autograd (fp32 engine, ragged text)."""
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=3, adv_steps_img=1)
+    m, p = build_module(ocfg, 5, "f32")
+    batch = O.synthetic_batch(ocfg, 3, 7, ragged_text=True)
+    g = torch.Generator().manual_seed(3)
+    w_txt, w_img, w_cls, w_raw = (torch.randn(s, generator=g) for s in ((3, 40, 768), (3, 145, 768), (3, 768), (3, 768)))
+    po = {n: t.clone().requires_grad_(not n.startswith("k_")) for n, t in p.items()}
+    ro = O.infer(po, ocfg, batch["text_ids"], batch["text_masks"], batch["image"][0])
+    fo = (ro["text_feats"] * w_txt).sum() + (ro["image_feats"] * w_img).sum() + (ro["cls_feats"] * w_cls).sum() + (ro["raw_cls_feats"] * w_raw).sum()
+    fo.backward()
+    m.zero_grad()
+    r = m.infer(dev_batch(batch))
+    assert r["cls_feats"].requires_grad and r["text_feats"].requires_grad
+    f = (r["text_feats"] * w_txt.to(DEV)).sum() + (r["image_feats"] * w_img.to(DEV)).sum() + (r["cls_feats"] * w_cls.to(DEV)).sum() \
+        + (r["raw_cls_feats"] * w_raw.to(DEV)).sum()
+    assert abs(float(f) - float(fo)) < 2e-3 * max(1.0, abs(float(fo)))
+    f.backward()
+    params = dict(m.named_parameters())
+    n_cmp = 0
+    for n, t in po.items():
+        if t.grad is None or n not in params or float(t.grad.norm()) < 1e-9:
+            continue
+        rel = float((params[n].grad.cpu() - t.grad).norm() / t.grad.norm())
+        assert rel < 5e-3, (n, rel)
+        n_cmp += 1
+    assert n_cmp > 30
+    with torch.no_grad():                                        # and the stash-free pass returns plain tensors
+        assert not m.infer(dev_batch(batch))["cls_feats"].requires_grad
+    assert not m.infer_k(dev_batch(batch))["cls_feats"].requires_grad   # the momentum pass never carries gradients

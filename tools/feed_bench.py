@@ -47,7 +47,10 @@ def make_shard(path, n, seed=0):
 def measure(data_dir, transform, workers, batch, seconds):
     tok = WS.load_tokenizer(os.path.join(ROOT, "tests", "golden", "toy_vocab.txt"))
     ds = BaseDataset(data_dir, [transform], 384, ["feed"], text_column_name="caption", tokenizer=tok)
-    dl = torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=True, num_workers=workers, collate_fn=ds.collate, drop_last=True,
+    # one long "epoch" (sampling with replacement): with a small shard an epoch is a handful of batches and only that many workers ever
+    # run - the loader would measure its own epoch seams, not the pipeline
+    sampler = torch.utils.data.RandomSampler(ds, replacement=True, num_samples=1 << 22)
+    dl = torch.utils.data.DataLoader(ds, batch_size=batch, sampler=sampler, num_workers=workers, collate_fn=ds.collate, drop_last=True,
                                      persistent_workers=workers > 0, prefetch_factor=2 if workers > 0 else None)
     pairs, t0, nbytes = 0, None, 0
     while True:
