@@ -6,7 +6,9 @@ import rmcl_pkg
 from rmcl_amd.vilt.config import task_moco
 from rmcl_amd.vilt.modules import ViLTransformerSS
 from bench import synthetic_batch
-cfg = task_moco(per_gpu_batchsize=64, num_gpus=1, num_nodes=1, adv_steps_img=3, drop_rate=0.0, image_view=True, max_steps=100000)
+# dense_images=True like bench.py: the general visual_embed path reads the patch counts back once per step (a host sync that would
+# make "enqueue time" equal the GPU time)
+cfg = task_moco(per_gpu_batchsize=64, num_gpus=1, num_nodes=1, adv_steps_img=3, drop_rate=0.0, image_view=True, max_steps=100000, dense_images=True)
 m = ViLTransformerSS(cfg, device="cuda:0", compute_dtype="bf16"); m.train()
 (opt,), (sched,) = m.configure_optimizers()
 batch = synthetic_batch(cfg, 64, 1, "cuda:0")
