@@ -237,7 +237,7 @@ def main():
         for w in sorted({4, max(4, min(cores, 32))}):
             try:
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "feed_bench.py"), "--json", "--workers", str(w), "--images", "128",
-                                    "--seconds", "5", "--paths", "pixelbert_uint8"], capture_output=True, text=True, timeout=180)
+                                    "--seconds", "5", "--paths", "pixelbert_uint8"], capture_output=True, text=True, timeout=90)
                 feed[f"workers_{w}"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             except Exception as e:                              # the step measurement does not depend on it
                 feed[f"workers_{w}"] = {"error": repr(e)[:200]}

@@ -109,8 +109,10 @@ extern bool g_dw_grouped;
 extern int g_attn_fwd_waves;
 extern int g_infonce_fold;
 extern int g_dp_stagger;
+extern int g_attn_bwd_persist;
 int rmcl_tune_set(int key, int value) {
   if (key == 7) { g_dp_stagger = value < 0 ? 0 : value; return 0; }                                  // gemm_dp: start delay of every CU's second workgroup (10 ns ticks)
+  if (key == 8) { g_attn_bwd_persist = value < 0 ? 0 : value; return 0; }                           // fused attention backward: workgroups (0: one per problem)
   if (key == 6) { rmcl_gemm_skinny_set_form(value); return 0; }                                   // 0: skinny GEMMs in the row-split form only
   if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }
   if (key == 1) { g_st_reserve_cus = value < 0 ? 0 : (value > 128 ? 128 : value); return 0; }   // CUs left free by the activation GEMMs

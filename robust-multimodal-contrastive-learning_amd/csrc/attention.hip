@@ -41,6 +41,16 @@ __device__ __forceinline__ void stage_rows(char* img, const bf16_t* __restrict__
   }
 }
 
+// One dword of the 128-byte line at p -> L2 (and a 256-byte per-wave LDS sink nobody reads): an LDS-DMA load has no register
+// destination, so nothing has to stay reserved while it is in flight; written as inline assembly so that the compiler's waitcnt
+// insertion does not see an LDS write it would order the transposed LDS reads of phase 1 behind (vmcnt(0), found in round 3).
+// Untracked loads only make later compiler-placed vmcnt(N) waits longer than needed (VMEM loads return in order), never shorter.
+__device__ __forceinline__ void touch_line(const void* p, uint32_t sink_lds_addr) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(p), "s"(sink_lds_addr));
+}
+
 __device__ __forceinline__ bf16x8 frag_row_lds(const char* img, int row0, int s, int lane) {
   const int row = row0 + (lane & 15);
   const int chunk = (4 * s + (lane >> 4)) ^ (row & 7);
@@ -113,8 +123,11 @@ __device__ long long g_at_trace[2][32];
 extern "C" int rmcl_debug_at_trace(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_at_trace), sizeof(long long) * 64);
 }
+#define AT_STAMPB(i)                                                                                             \
+  if (prob == 300 && (threadIdx.x == 0 || threadIdx.x == 320)) g_at_trace[threadIdx.x != 0][i] = wall_clock64()
 #else
 #define AT_STAMP(i)
+#define AT_STAMPB(i)
 #endif
 
 // ================================================================================== forward
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 template <int NKT>
 __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
                                                                  const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
-                                                                 const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H) {
+                                                                 const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, int P) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
   constexpr int NKP = NKT * 16, NW = NKT, NSUB = (NKP + 63) / 64;
   char* Qtr = sm;
@@ -435,10 +448,16 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
   char* dSimg = sm + 3 * NKP * 128;                             // NSUB sub-images of [NKP keys][64 q] bf16 (128-B rows)
   float* Ls = reinterpret_cast<float*>(sm + (3 + NSUB) * NKP * 128);   // lse per query, log2 domain (+inf for pad rows)
   float* Ds = Ls + NKP;                                         // delta per query
+  char* touch_sink = reinterpret_cast<char*>(Ds + NKP);         // 256 B per wave: where the next problem's touch loads land (never read)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, g = lane >> 4;
-  const int b = blockIdx.x / H, h = blockIdx.x % H, D = H * 64;
-  AT_STAMP(0);
+  const int D = H * 64;
   const long ld = 3 * D;
+  // One workgroup per CU walks problems p, p + grid, ... (grid == P: one problem each).  The load phase of a problem is a burst of
+  // ~118 KB per CU that every CU issues at the same moment and then waits for; while phase 1 computes, each thread touches one or
+  // two 128-byte lines of the NEXT problem's operands, so that the next burst is served by L2 / MALL instead of HBM.
+  for (int prob = blockIdx.x; prob < P; prob += gridDim.x) {
+  const int b = prob / H, h = prob % H;
+  AT_STAMPB(0);
   const bf16_t* base = qkv + (long)b * N * ld + h * 64;
   const bf16_t* dob = dout + (long)b * N * D + h * 64;
   const bf16_t* ob = out + (long)b * N * D + h * 64;
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
   bf16x8 kf[2], vf[2];
   const int* mrow = mask + (long)b * N;
   const int key = wave * 16 + (lane & 15);
-  const float mbk = (key < N && mrow[key] != 0) ? 0.f : -INFINITY;
+  const int mkey = mrow[min(key, N - 1)];                       // consumed after the barrier: a branch around the load made it a serial round trip
 #pragma unroll
   for (int s = 0; s < 2; ++s) vf[s] = frag_row_global(base + 2 * D, ld, wave * 16, N, s, lane);   // (K: out of its LDS image, below)
   // delta of query tile `wave`: O row fragments from global now, dO out of its LDS image after the barrier (dO is staged for the
@@ -458,15 +477,16 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
   stage_rows<true, NW>(Qtr, base, ld, N, NKP, wave, lane);
   stage_rows<true, NW>(Dtr, dob, D, N, NKP, wave, lane);
   stage_rows<true, NW>(Ktr, base + D, ld, N, NKP, wave, lane);
-  AT_STAMP(1);
-  for (int j = t; j < NKP; j += NW * 64) Ls[j] = j < N ? lse[((long)blockIdx.x) * NKP + j] * LOG2E : INFINITY;
-  AT_STAMP(2);
+  AT_STAMPB(1);
+  for (int j = t; j < NKP; j += NW * 64) Ls[j] = j < N ? lse[((long)prob) * NKP + j] * LOG2E : INFINITY;
+  AT_STAMPB(2);
   f32x4 dK[4], dV[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  AT_STAMP(3);
+  AT_STAMPB(3);
   __syncthreads();
-  AT_STAMP(4);
+  AT_STAMPB(4);
+  const float mbk = (key < N && mkey != 0) ? 0.f : -INFINITY;
 #pragma unroll
   for (int s = 0; s < 2; ++s) kf[s] = frag_row_ldsT(Ktr, wave * 16, s, lane);    // the K image is staged anyway (phase 2): no second global read of K
   {
@@ -487,6 +507,19 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
     if (g == 0) Ds[q] = q < N ? dl : 0.f;
   }
   __syncthreads();                                             // delta of every query tile is in LDS
+  if (prob + (int)gridDim.x < P) {
+    const int pn = prob + gridDim.x, bn = pn / H, hn = pn % H;
+    const bf16_t* basen = qkv + (long)bn * N * ld + hn * 64;
+    const bf16_t* dobn = dout + (long)bn * N * D + hn * 64;
+    const bf16_t* obn = out + (long)bn * N * D + hn * 64;
+    const uint32_t sink = __builtin_amdgcn_readfirstlane(lds_addr(touch_sink + wave * 256));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                              // 5 N lines: Q, K, V, dO, O rows of 128 bytes (the tail re-touches the last line)
+      const int l = min(t + i * NW * 64, 5 * N - 1), r = l / 5, w = l - 5 * r;
+      const bf16_t* a = w < 3 ? basen + (long)r * ld + w * D : (w == 3 ? dobn : obn) + (long)r * D;
+      touch_line(a, sink);
+    }
+  }
 
   // ---- phase 1 -------------------------------------------------------------------------------------------------------
   for (int qt = 0; qt < NKT; ++qt) {
@@ -531,7 +564,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
       dK[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtr[dt], sa, dK[dt], 0, 0, 0);   // += Q^T dS
     }
   }
-  AT_STAMP(5);
+  AT_STAMPB(5);
   if (key < N) {
     bf16_t* o = dqkv + ((long)b * N + key) * ld + h * 64 + 4 * g;
 #pragma unroll
@@ -545,9 +578,9 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
       *reinterpret_cast<uint2*>(o + 2 * D + 16 * dt) = pv;
     }
   }
-  AT_STAMP(6);
+  AT_STAMPB(6);
   __syncthreads();
-  AT_STAMP(7);
+  AT_STAMPB(7);
 
   // ---- phase 2: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for query tile `wave` ------------------------------------
   {
@@ -562,7 +595,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) dQ[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr32_lds(Ktr, 32 * u, dt, lane), sb, dQ[dt], 0, 0, 0);
     }
-    AT_STAMP(8);
+    AT_STAMPB(8);
     const int q_lane = qt * 16 + (lane & 15);
     if (q_lane < N) {
       bf16_t* o = dqkv + ((long)b * N + q_lane) * ld + h * 64 + 4 * g;
@@ -576,10 +609,12 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
     }
   }
 #ifdef ST_TRACE
-  AT_STAMP(9);
+  AT_STAMPB(9);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  AT_STAMP(10);
+  AT_STAMPB(10);
 #endif
+  __syncthreads();                                             // phase 2 has read Ktr / dS^T: the next problem may stage
+  }
 }
 
 // ================================================================================== launchers
@@ -604,18 +639,20 @@ template <int NKT> static int launch_fwd(const bf16_t* qkv, const int* mask, bf1
   if (g_attn_fwd_waves == 4) return launch_fwd_w<NKT, 4>(qkv, mask, out, lse, B, N, H, s);
   return launch_fwd_w<NKT, 8>(qkv, mask, out, lse, B, N, H, s);
 }
+int g_attn_bwd_persist = 256;        // rmcl_tune_set key 8: workgroups of the fused backward (each walks problems p, p + grid, ...); 0: one per problem
 bool g_attn_fused_bwd = true;        // rmcl_tune_set key 2: 0 selects the two-kernel backward (A/B and parity tests)
 
 template <int NKT> static int launch_bwd_fused(const bf16_t* qkv, const int* mask, const bf16_t* dout, const bf16_t* out, const float* lse,
                                                bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
   constexpr int NKP = NKT * 16, NSUB = (NKP + 63) / 64;
-  const size_t lds = (size_t)(3 + NSUB) * NKP * 128 + 2 * NKP * 4;
+  const size_t lds = (size_t)(3 + NSUB) * NKP * 128 + 2 * NKP * 4 + NKT * 256;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  RMCL_LAUNCH(attn_bwd_fused_kernel<NKT>, dim3(B * H), dim3(NKT * 64), lds, s, qkv, mask, dout, out, lse, dqkv, N, H);
+  const int P = B * H, grid = g_attn_bwd_persist > 0 ? min(P, g_attn_bwd_persist) : P;
+  RMCL_LAUNCH(attn_bwd_fused_kernel<NKT>, dim3(grid), dim3(NKT * 64), lds, s, qkv, mask, dout, out, lse, dqkv, N, H, P);
   RMCL_CHECK_LAUNCH();
   return 0;
 }

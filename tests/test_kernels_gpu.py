@@ -160,6 +160,16 @@ def test_attention_bwd_one_kernel_full_batch():
         res.append(dqkv.float())
     assert torch.isfinite(res[1]).all()
     assert rel_err(res[1], res[0]) < 1e-2
+    # the default walks the 768 problems with 256 workgroups (next problem's lines touched into L2 during phase 1): one workgroup
+    # per problem, and a grid that does not divide the problem count, give the same bits
+    try:
+        for wg in (0, 100):
+            check(lib.rmcl_tune_set(8, wg))
+            dqkv = torch.full((B * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
+            check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), P(out), P(dqkv), P(scores), P(dS), B, N, H, dt, 0, stream()))
+            assert torch.equal(dqkv.float(), res[1]), wg
+    finally:
+        check(lib.rmcl_tune_set(8, 256))
 
 
 # --------------------------------------------------------------------------------------- InfoNCE

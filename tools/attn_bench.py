@@ -52,3 +52,7 @@ for wv in (4, 6, 8, 12):
     lib.rmcl_tune_set(4, wv)
     print(f"fwd with {wv} waves per workgroup: {t(fwd):.1f} us")
 lib.rmcl_tune_set(4, 8)
+for wg in (0, 128, 192, 248, 256, 384):
+    lib.rmcl_tune_set(8, wg)
+    print(f"bwd one kernel, {wg or B * H} workgroups: hot {t(b1):.1f} us   cold {cold(b1):.1f} us   (fwd cold {cold(fwd):.1f} us)")
+lib.rmcl_tune_set(8, 256)
