@@ -110,8 +110,10 @@ extern int g_attn_fwd_waves;
 extern int g_infonce_fold;
 extern int g_dp_stagger;
 extern int g_attn_bwd_persist;
+extern int g_attn_bwd_tpw;
 int rmcl_tune_set(int key, int value) {
   if (key == 7) { g_dp_stagger = value < 0 ? 0 : value; return 0; }                                  // gemm_dp: start delay of every CU's second workgroup (10 ns ticks)
+  if (key == 9) { g_attn_bwd_tpw = value; return 0; }                                             // fused attention backward: key tiles per wave (1, 2, 3)
   if (key == 8) { g_attn_bwd_persist = value < 0 ? 0 : value; return 0; }                           // fused attention backward: workgroups (0: one per problem)
   if (key == 6) { rmcl_gemm_skinny_set_form(value); return 0; }                                   // 0: skinny GEMMs in the row-split form only
   if (key == 0) { rmcl_gemm_fast_set_cfg(value); return 0; }

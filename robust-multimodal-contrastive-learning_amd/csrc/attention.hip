@@ -436,12 +436,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 //            -> LDS image [key][q] (bf16, written as the transposed-read layout of the 64-column sub-image q / 64)
 //   phase 2: dQ^T = K^T dS^T for the wave's query tile: both operands by ds_read_b64_tr_b16, same permuted k order.
 // Nothing but dqkv is written to HBM; qkv / dO / O are read once per workgroup (+ L1-resident fragment re-reads).
-template <int NKT>
-__global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
-                                                                 const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
-                                                                 const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, int P) {
+template <int NKT, int TPW>
+__global__ __launch_bounds__(NKT / TPW * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ mask,
+                                                                       const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                                       const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int N, int H, int P) {
   extern __shared__ __attribute__((aligned(16))) char sm[];
-  constexpr int NKP = NKT * 16, NW = NKT, NSUB = (NKP + 63) / 64;
+  constexpr int NKP = NKT * 16, NW = NKT / TPW, NSUB = (NKP + 63) / 64;
+  static_assert(NKT % TPW == 0, "key tiles per wave must divide the tile count");
   char* Qtr = sm;
   char* Dtr = sm + NKP * 128;
   char* Ktr = sm + 2 * NKP * 128;
@@ -453,49 +454,60 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
   const int D = H * 64;
   const long ld = 3 * D;
   // One workgroup per CU walks problems p, p + grid, ... (grid == P: one problem each).  The load phase of a problem is a burst of
-  // ~118 KB per CU that every CU issues at the same moment and then waits for; while phase 1 computes, each thread touches one or
-  // two 128-byte lines of the NEXT problem's operands, so that the next burst is served by L2 / MALL instead of HBM.
+  // ~118 KB per CU that every CU issues at the same moment and then waits for; while phase 1 computes, each thread touches a few
+  // 128-byte lines of the NEXT problem's operands, so that the next burst is served by L2 / MALL instead of HBM.
+  // Wave w owns key tiles (and, in phase 2, query tiles) w * TPW .. w * TPW + TPW - 1: every Q / dO fragment it reads from LDS in
+  // phase 1 serves TPW key tiles (phase 1 is LDS-bandwidth bound: each wave reads all of Q and dO in two layouts).
   for (int prob = blockIdx.x; prob < P; prob += gridDim.x) {
   const int b = prob / H, h = prob % H;
   AT_STAMPB(0);
   const bf16_t* base = qkv + (long)b * N * ld + h * 64;
   const bf16_t* dob = dout + (long)b * N * D + h * 64;
   const bf16_t* ob = out + (long)b * N * D + h * 64;
-  // this wave's key tile: K / V row fragments and the key mask stay in registers.  Issued FIRST: behind the lse load below (consumed at
+  // the wave's key tiles: K / V row fragments and the key mask stay in registers.  Issued FIRST: behind the lse load below (consumed at
   // once, i.e. after a vmcnt(0) that also waits for the staging) they were a second, serial HBM round trip of the load phase
-  bf16x8 kf[2], vf[2];
+  bf16x8 kf[TPW][2], vf[TPW][2], of[TPW][2];
   const int* mrow = mask + (long)b * N;
-  const int key = wave * 16 + (lane & 15);
-  const int mkey = mrow[min(key, N - 1)];                       // consumed after the barrier: a branch around the load made it a serial round trip
+  int mkey[TPW];                                                // consumed after the barrier: a branch around the load made it a serial round trip
 #pragma unroll
-  for (int s = 0; s < 2; ++s) vf[s] = frag_row_global(base + 2 * D, ld, wave * 16, N, s, lane);   // (K: out of its LDS image, below)
-  // delta of query tile `wave`: O row fragments from global now, dO out of its LDS image after the barrier (dO is staged for the
+  for (int i = 0; i < TPW; ++i) mkey[i] = mrow[min((wave * TPW + i) * 16 + (lane & 15), N - 1)];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) vf[i][s] = frag_row_global(base + 2 * D, ld, (wave * TPW + i) * 16, N, s, lane);   // (K: out of its LDS image, below)
+  // delta of the wave's query tiles: O row fragments from global now, dO out of its LDS image after the barrier (dO is staged for the
   // transposed reads anyway: no second global read of it)
-  bf16x8 of[2];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) of[s] = frag_row_global(ob, D, wave * 16, N, s, lane);
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) of[i][s] = frag_row_global(ob, D, (wave * TPW + i) * 16, N, s, lane);
   stage_rows<true, NW>(Qtr, base, ld, N, NKP, wave, lane);
   stage_rows<true, NW>(Dtr, dob, D, N, NKP, wave, lane);
   stage_rows<true, NW>(Ktr, base + D, ld, N, NKP, wave, lane);
   AT_STAMPB(1);
   for (int j = t; j < NKP; j += NW * 64) Ls[j] = j < N ? lse[((long)prob) * NKP + j] * LOG2E : INFINITY;
   AT_STAMPB(2);
-  f32x4 dK[4], dV[4];
+  f32x4 dK[TPW][4], dV[TPW][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dK[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   AT_STAMPB(3);
   __syncthreads();
   AT_STAMPB(4);
-  const float mbk = (key < N && mkey != 0) ? 0.f : -INFINITY;
+  float mbk[TPW];
 #pragma unroll
-  for (int s = 0; s < 2; ++s) kf[s] = frag_row_ldsT(Ktr, wave * 16, s, lane);    // the K image is staged anyway (phase 2): no second global read of K
-  {
+  for (int i = 0; i < TPW; ++i) {
+    const int key = (wave * TPW + i) * 16 + (lane & 15);
+    mbk[i] = (key < N && mkey[i] != 0) ? 0.f : -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) kf[i][s] = frag_row_ldsT(Ktr, (wave * TPW + i) * 16, s, lane);   // the K image is staged anyway (phase 2): no second global read of K
     float dl = 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       union { bf16x8 v; uint32_t w[4]; } a, c;
-      a.v = frag_row_ldsT(Dtr, wave * 16, s, lane);
-      c.v = of[s];
+      a.v = frag_row_ldsT(Dtr, (wave * TPW + i) * 16, s, lane);
+      c.v = of[i][s];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         dl = fmaf(__uint_as_float(a.w[e] << 16), __uint_as_float(c.w[e] << 16), dl);
@@ -503,8 +515,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
       }
     }
     dl = group_sum(dl);
-    const int q = wave * 16 + (lane & 15);
-    if (g == 0) Ds[q] = q < N ? dl : 0.f;
+    if (g == 0) Ds[key] = key < N ? dl : 0.f;
   }
   __syncthreads();                                             // delta of every query tile is in LDS
   if (prob + (int)gridDim.x < P) {
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
     const bf16_t* obn = out + (long)bn * N * D + hn * 64;
     const uint32_t sink = __builtin_amdgcn_readfirstlane(lds_addr(touch_sink + wave * 256));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {                              // 5 N lines: Q, K, V, dO, O rows of 128 bytes (the tail re-touches the last line)
+    for (int i = 0; i < (5 * NKP + NW * 64 - 1) / (NW * 64); ++i) {   // 5 N lines: Q, K, V, dO, O rows of 128 bytes (the tail re-touches the last line)
       const int l = min(t + i * NW * 64, 5 * N - 1), r = l / 5, w = l - 5 * r;
       const bf16_t* a = w < 3 ? basen + (long)r * ld + w * D : (w == 3 ? dobn : obn) + (long)r * D;
       touch_line(a, sink);
@@ -540,71 +551,104 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_fused_kernel(const bf16_t* 
       dot[dt] = frag_tr16_lds(Dtr, qt * 16, dt, lane);
       qtr[dt] = frag_tr16_lds(Qtr, qt * 16, dt, lane);
     }
-    f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], kf[s], S, 0, 0, 0);        // S[q = 4g+r][key = lane&15]
-      dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[s], vf[s], dP, 0, 0, 0);
-    }
-    f32x4 P, dS;
+    for (int i = 0; i < TPW; ++i) {
+      f32x4 S = {0.f, 0.f, 0.f, 0.f}, dP = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      P[r] = __builtin_amdgcn_exp2f(fmaf(S[r], SCALE_L2, mbk - Lr[r]));
-      dS[r] = P[r] * (dP[r] - Dr[r]) * SCALE;
-    }
-    const s16x4 pa = pack4(P), sa = pack4(dS);
-    {                                                          // dS^T tile -> image [key][q]: 4 adjacent q of key lane&15, 8 bytes
-      const int row = wave * 16 + (lane & 15);
-      char* img = dSimg + (qt >> 2) * (NKP * 128);
-      *reinterpret_cast<s16x4*>(img + row * 128 + (((qt & 3) ^ ((row >> 1) & 3)) * 32) + g * 8) = sa;
-    }
+      for (int s = 0; s < 2; ++s) {
+        S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], kf[i][s], S, 0, 0, 0);        // S[q = 4g+r][key = lane&15]
+        dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[s], vf[i][s], dP, 0, 0, 0);
+      }
+      f32x4 Pr, dS;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {                           // swapped operands: dV^T[d = 4g+r][key = lane&15]
-      dV[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dot[dt], pa, dV[dt], 0, 0, 0);   // += dO^T P
-      dK[dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtr[dt], sa, dK[dt], 0, 0, 0);   // += Q^T dS
+      for (int r = 0; r < 4; ++r) {
+        Pr[r] = __builtin_amdgcn_exp2f(fmaf(S[r], SCALE_L2, mbk[i] - Lr[r]));
+        dS[r] = Pr[r] * (dP[r] - Dr[r]) * SCALE;
+      }
+      const s16x4 pa = pack4(Pr), sa = pack4(dS);
+      {                                                        // dS^T tile -> image [key][q]: 4 adjacent q of key lane&15, 8 bytes
+        const int row = (wave * TPW + i) * 16 + (lane & 15);
+        char* img = dSimg + (qt >> 2) * (NKP * 128);
+        *reinterpret_cast<s16x4*>(img + row * 128 + (((qt & 3) ^ ((row >> 1) & 3)) * 32) + g * 8) = sa;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {                         // swapped operands: dV^T[d = 4g+r][key = lane&15]
+        dV[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dot[dt], pa, dV[i][dt], 0, 0, 0);   // += dO^T P
+        dK[i][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qtr[dt], sa, dK[i][dt], 0, 0, 0);   // += Q^T dS
+      }
     }
   }
   AT_STAMPB(5);
-  if (key < N) {
-    bf16_t* o = dqkv + ((long)b * N + key) * ld + h * 64 + 4 * g;
+  __syncthreads();                                             // every wave is done with the Q / dO images; dS^T is complete
+  AT_STAMPB(6);
+  // dK / dV: the accumulators hold 4 adjacent d of one key per lane (8 bytes; a direct store touches 32 bytes of each of 16 rows per
+  // instruction: 3.3 us of a 17 us problem went into issuing them).  Through the wave's OWN rows of the dead Q / dO images instead
+  // (row-major, 16-byte chunk c at c ^ (row & 7)), read back as whole 128-byte rows: 4 full-line stores per tile; phase 2 runs under them.
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int row = (wave * TPW + i) * 16 + (lane & 15);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       uint2 pk, pv;
-      pk.x = (uint32_t)f2bf(dK[dt][0]) | ((uint32_t)f2bf(dK[dt][1]) << 16);
-      pk.y = (uint32_t)f2bf(dK[dt][2]) | ((uint32_t)f2bf(dK[dt][3]) << 16);
-      pv.x = (uint32_t)f2bf(dV[dt][0]) | ((uint32_t)f2bf(dV[dt][1]) << 16);
-      pv.y = (uint32_t)f2bf(dV[dt][2]) | ((uint32_t)f2bf(dV[dt][3]) << 16);
-      *reinterpret_cast<uint2*>(o + D + 16 * dt) = pk;
-      *reinterpret_cast<uint2*>(o + 2 * D + 16 * dt) = pv;
+      pk.x = (uint32_t)f2bf(dK[i][dt][0]) | ((uint32_t)f2bf(dK[i][dt][1]) << 16);
+      pk.y = (uint32_t)f2bf(dK[i][dt][2]) | ((uint32_t)f2bf(dK[i][dt][3]) << 16);
+      pv.x = (uint32_t)f2bf(dV[i][dt][0]) | ((uint32_t)f2bf(dV[i][dt][1]) << 16);
+      pv.y = (uint32_t)f2bf(dV[i][dt][2]) | ((uint32_t)f2bf(dV[i][dt][3]) << 16);
+      const int off = row * 128 + (((2 * dt + (g >> 1)) ^ (row & 7)) * 16) + (g & 1) * 8;
+      *reinterpret_cast<uint2*>(Qtr + off) = pk;
+      *reinterpret_cast<uint2*>(Dtr + off) = pv;
     }
   }
-  AT_STAMPB(6);
-  __syncthreads();
+  asm volatile("" ::: "memory");                               // (same wave, LDS operations complete in order: no barrier)
+#pragma unroll
+  for (int it = 0; it < 2 * TPW; ++it) {
+    const int r = wave * TPW * 16 + it * 8 + (lane >> 3), c = lane & 7;
+    const int off = r * 128 + ((c ^ (r & 7)) * 16);
+    const uint2 k0 = *reinterpret_cast<const uint2*>(Qtr + off), k1 = *reinterpret_cast<const uint2*>(Qtr + off + 8);
+    const uint2 v0 = *reinterpret_cast<const uint2*>(Dtr + off), v1 = *reinterpret_cast<const uint2*>(Dtr + off + 8);
+    if (r < N) {
+      bf16_t* o = dqkv + ((long)b * N + r) * ld + h * 64 + c * 8;
+      *reinterpret_cast<uint4*>(o + D) = uint4{k0.x, k0.y, k1.x, k1.y};
+      *reinterpret_cast<uint4*>(o + 2 * D) = uint4{v0.x, v0.y, v1.x, v1.y};
+    }
+  }
   AT_STAMPB(7);
 
-  // ---- phase 2: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for query tile `wave` ------------------------------------
+  // ---- phase 2: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] for the wave's query tiles: a K^T fragment serves all TPW of them ------
   {
-    const int qt = wave;
-    const char* img = dSimg + (qt >> 2) * (NKP * 128);
-    f32x4 dQ[4];
+    f32x4 dQ[TPW][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TPW; ++i)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dQ[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NKT / 2; ++u) {
-      const bf16x8 sb = frag_tr32_lds(img, 32 * u, qt & 3, lane);
+      bf16x8 sb[TPW];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dQ[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr32_lds(Ktr, 32 * u, dt, lane), sb, dQ[dt], 0, 0, 0);
-    }
-    AT_STAMPB(8);
-    const int q_lane = qt * 16 + (lane & 15);
-    if (q_lane < N) {
-      bf16_t* o = dqkv + ((long)b * N + q_lane) * ld + h * 64 + 4 * g;
+      for (int i = 0; i < TPW; ++i) {
+        const int qt = wave * TPW + i;
+        sb[i] = frag_tr32_lds(dSimg + (qt >> 2) * (NKP * 128), 32 * u, qt & 3, lane);
+      }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        uint2 pk;
-        pk.x = (uint32_t)f2bf(dQ[dt][0]) | ((uint32_t)f2bf(dQ[dt][1]) << 16);
-        pk.y = (uint32_t)f2bf(dQ[dt][2]) | ((uint32_t)f2bf(dQ[dt][3]) << 16);
-        *reinterpret_cast<uint2*>(o + 16 * dt) = pk;
+        const bf16x8 ka = frag_tr32_lds(Ktr, 32 * u, dt, lane);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) dQ[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, sb[i], dQ[i][dt], 0, 0, 0);
+      }
+    }
+    AT_STAMPB(8);
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int q_lane = (wave * TPW + i) * 16 + (lane & 15);
+      if (q_lane < N) {
+        bf16_t* o = dqkv + ((long)b * N + q_lane) * ld + h * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 pk;
+          pk.x = (uint32_t)f2bf(dQ[i][dt][0]) | ((uint32_t)f2bf(dQ[i][dt][1]) << 16);
+          pk.y = (uint32_t)f2bf(dQ[i][dt][2]) | ((uint32_t)f2bf(dQ[i][dt][3]) << 16);
+          *reinterpret_cast<uint2*>(o + 16 * dt) = pk;
+        }
       }
     }
   }
@@ -639,22 +683,29 @@ template <int NKT> static int launch_fwd(const bf16_t* qkv, const int* mask, bf1
   if (g_attn_fwd_waves == 4) return launch_fwd_w<NKT, 4>(qkv, mask, out, lse, B, N, H, s);
   return launch_fwd_w<NKT, 8>(qkv, mask, out, lse, B, N, H, s);
 }
-int g_attn_bwd_persist = 256;        // rmcl_tune_set key 8: workgroups of the fused backward (each walks problems p, p + grid, ...); 0: one per problem
+int g_attn_bwd_tpw = 1;              // rmcl_tune_set key 9: key tiles per wave of the fused backward (1, 2 or 3)
+int g_attn_bwd_persist = 0;          // rmcl_tune_set key 8: workgroups of the fused backward (each walks problems p, p + grid, ...); 0: one per problem
 bool g_attn_fused_bwd = true;        // rmcl_tune_set key 2: 0 selects the two-kernel backward (A/B and parity tests)
 
-template <int NKT> static int launch_bwd_fused(const bf16_t* qkv, const int* mask, const bf16_t* dout, const bf16_t* out, const float* lse,
-                                               bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
-  constexpr int NKP = NKT * 16, NSUB = (NKP + 63) / 64;
-  const size_t lds = (size_t)(3 + NSUB) * NKP * 128 + 2 * NKP * 4 + NKT * 256;
+template <int NKT, int TPW> static int launch_bwd_fused_t(const bf16_t* qkv, const int* mask, const bf16_t* dout, const bf16_t* out, const float* lse,
+                                                          bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
+  constexpr int NKP = NKT * 16, NSUB = (NKP + 63) / 64, NW = NKT / TPW;
+  const size_t lds = (size_t)(3 + NSUB) * NKP * 128 + 2 * NKP * 4 + NW * 256;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NKT, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
   const int P = B * H, grid = g_attn_bwd_persist > 0 ? min(P, g_attn_bwd_persist) : P;
-  RMCL_LAUNCH(attn_bwd_fused_kernel<NKT>, dim3(grid), dim3(NKT * 64), lds, s, qkv, mask, dout, out, lse, dqkv, N, H, P);
+  RMCL_LAUNCH((attn_bwd_fused_kernel<NKT, TPW>), dim3(grid), dim3(NW * 64), lds, s, qkv, mask, dout, out, lse, dqkv, N, H, P);
   RMCL_CHECK_LAUNCH();
   return 0;
+}
+template <int NKT> static int launch_bwd_fused(const bf16_t* qkv, const int* mask, const bf16_t* dout, const bf16_t* out, const float* lse,
+                                               bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
+  if constexpr (NKT % 2 == 0) if (g_attn_bwd_tpw == 2) return launch_bwd_fused_t<NKT, 2>(qkv, mask, dout, out, lse, dqkv, B, N, H, s);
+  if constexpr (NKT % 3 == 0) if (g_attn_bwd_tpw == 3) return launch_bwd_fused_t<NKT, 3>(qkv, mask, dout, out, lse, dqkv, B, N, H, s);
+  return launch_bwd_fused_t<NKT, 1>(qkv, mask, dout, out, lse, dqkv, B, N, H, s);
 }
 
 template <int NKT> static int launch_bwd(const bf16_t* qkv, const int* mask, const bf16_t* dout, const float* lse, float* delta,

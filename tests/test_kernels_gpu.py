@@ -135,6 +135,9 @@ def test_attention_fwd_bwd(dt, exact, BN):
         assert rel_err(dqkv, x.grad) < tol, with_out
 
 
+ATTN_BWD_TPW_DEFAULT = 1
+
+
 def test_attention_bwd_one_kernel_full_batch():
     """B = 64 (768 workgroups of 12 waves, 145.5 KiB LDS each): the one-kernel backward against the two-kernel form."""
     B, N, H, D = 64, 185, 12, 768
@@ -163,13 +166,15 @@ def test_attention_bwd_one_kernel_full_batch():
     # the default walks the 768 problems with 256 workgroups (next problem's lines touched into L2 during phase 1): one workgroup
     # per problem, and a grid that does not divide the problem count, give the same bits
     try:
-        for wg in (0, 100):
+        for wg, tpw in ((0, 1), (100, 1), (256, 2), (0, 3), (256, 3)):   # (key 9: key tiles per wave; same sums in the same order)
             check(lib.rmcl_tune_set(8, wg))
+            check(lib.rmcl_tune_set(9, tpw))
             dqkv = torch.full((B * N, 3 * D), float("nan"), dtype=torch.bfloat16, device=DEV)
             check(lib.rmcl_attention_bwd(P(qkv), P(mask), P(probs), P(dout), P(out), P(dqkv), P(scores), P(dS), B, N, H, dt, 0, stream()))
-            assert torch.equal(dqkv.float(), res[1]), wg
+            assert torch.equal(dqkv.float(), res[1]), (wg, tpw)
     finally:
         check(lib.rmcl_tune_set(8, 256))
+        check(lib.rmcl_tune_set(9, ATTN_BWD_TPW_DEFAULT))
 
 
 # --------------------------------------------------------------------------------------- InfoNCE

@@ -56,3 +56,10 @@ for wg in (0, 128, 192, 248, 256, 384):
     lib.rmcl_tune_set(8, wg)
     print(f"bwd one kernel, {wg or B * H} workgroups: hot {t(b1):.1f} us   cold {cold(b1):.1f} us   (fwd cold {cold(fwd):.1f} us)")
 lib.rmcl_tune_set(8, 256)
+for tpw in (1, 2, 3):
+    lib.rmcl_tune_set(9, tpw)
+    for wg in (0, 256):
+        lib.rmcl_tune_set(8, wg)
+        print(f"bwd one kernel, {tpw} key tiles per wave, {wg or B * H} workgroups: hot {t(b1):.1f} us   cold {cold(b1):.1f} us")
+lib.rmcl_tune_set(9, 1)
+lib.rmcl_tune_set(8, 256)
