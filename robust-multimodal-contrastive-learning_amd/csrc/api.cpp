@@ -111,8 +111,10 @@ extern int g_infonce_fold;
 extern int g_dp_stagger;
 extern int g_attn_bwd_persist;
 extern int g_attn_bwd_tpw;
+extern int g_gemm_share;
 int rmcl_tune_set(int key, int value) {
   if (key == 7) { g_dp_stagger = value < 0 ? 0 : value; return 0; }                                  // gemm_dp: start delay of every CU's second workgroup (10 ns ticks)
+  if (key == 10) { g_gemm_share = value < 1 ? 1 : (value > 8 ? 8 : value); return 0; }                 // chains sharing the chip (GEMM routing sizes a launch against CUs / share)
   if (key == 9) { g_attn_bwd_tpw = value; return 0; }                                             // fused attention backward: key tiles per wave (1, 2, 3)
   if (key == 8) { g_attn_bwd_persist = value < 0 ? 0 : value; return 0; }                           // fused attention backward: workgroups (0: one per problem)
   if (key == 6) { rmcl_gemm_skinny_set_form(value); return 0; }                                   // 0: skinny GEMMs in the row-split form only

@@ -319,7 +319,8 @@ int rmcl_launch_gemm_sw(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s);
 bool rmcl_gemm_sw_supported(const GemmArgs& g, int a_kc, int b_kc);
 double rmcl_gemm_sw_fill(const GemmArgs& g, int cus);
 int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipStream_t s);
-double rmcl_gemm_st_fill(const GemmArgs& g);
+double rmcl_gemm_st_fill(const GemmArgs& g, int cus);
+int g_gemm_share = 1;               // rmcl_tune_set key 10: independent chains sharing the chip (half-batch lanes: 2) - a launch is sized against 1 / share of the CUs
 bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc);
 bool rmcl_gemm_pp_supported(const GemmArgs& g, int a_kc, int b_kc);
 bool rmcl_gemm_big_supported(const GemmArgs& g, int a_kc, int b_kc);
@@ -333,9 +334,9 @@ int rmcl_launch_gemm_big(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipS
 int rmcl_gemm_route_code(const GemmArgs& g, int dt_out, int a_kc, int b_kc) {
   if (g_gemm_cfg == 80 && rmcl_gemm_dp_supported(g, a_kc, b_kc) && !((g.epi & EPI_RESIDUAL) && dt_out != RMCL_F32)) return 3;
   // 192x384 tiles where they make exact rounds (N = 3072 at M = 64*185: 496 tiles = 2 x 248)
-  if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc)) return 2;
+  if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248 / g_gemm_share) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc)) return 2;
   // 192x192 ping-pong tiles for the activation GEMMs (M = B*185 rows) whenever they fill the CU rounds
-  if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc)) return 1;
+  if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g, 256 / g_gemm_share) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc)) return 1;
   if (g_gemm_cfg == 50 && rmcl_gemm_pp_supported(g, a_kc, b_kc)) return 4;
   // 256x256 tiles where they measure faster (MI355X, M = 11840): narrow outputs with a long reduction
   const bool big_wins = a_kc && g.splitk <= 1 && g.N <= 1024 && g.K >= 2048 && cdiv(g.M, 256) * (g.N / 256) >= 128;

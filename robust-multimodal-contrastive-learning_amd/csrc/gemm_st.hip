@@ -561,9 +561,9 @@ bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
 }
 
 // how full the CU rounds of a launch are (1 = every round uses all 256 CUs)
-double rmcl_gemm_st_fill(const GemmArgs& g) {
+double rmcl_gemm_st_fill(const GemmArgs& g, int cus) {
   const long tiles = (long)cdiv(g.M, ST_T) * (g.N / ST_T) * (g.splitk > 1 ? g.splitk : 1);
-  return (double)tiles / (double)(cdiv(tiles, 256L) * 256L);
+  return (double)tiles / (double)(cdiv(tiles, (long)cus) * cus);
 }
 
 int g_st_reserve_cus = 8;            // CUs left to other kernels (rmcl_tune_set key 1; RCCL channels, side-stream kernels): free at M = 64*185

@@ -117,10 +117,16 @@ class BtBuffers:
 class PassBuffers:
     """Everything sized by the per-GPU batch B (allocated once, reused every step)."""
 
-    def __init__(self, eng: "Engine", B: int, dtype=None, P=None):
+    def __init__(self, eng: "Engine", B: int, dtype=None, P=None, lane_of: "PassBuffers" = None, lane: int = 0):
+        """lane_of / lane: these buffers are LANE `lane` of `lane_of` (samples [lane * B, (lane + 1) * B) of its batch): everything that is
+        laid out per sample is a row-range VIEW of the parent's tensor, only the scratch of a pass (workspace, stashes, InfoNCE
+        workspace, loss ring) is the lane's own - see Engine.lanes."""
         dev = eng.device
         self.dtype = eng.dtype if dtype is None else dtype       # arithmetic of the passes run through these buffers
         d = eng.dims(B, self.dtype, P)
+        if lane_of is not None:
+            self._init_lane(eng, d, lane_of, lane)
+            return
         self.geom = None                # RaggedGeometry of a zero-padded batch (None: full-size images, dense patches)
         self.ragged = None              # the rmcl_ragged struct handed to the encoder passes (own pos_tok / dpos_tok scratch)
         self.B = B
@@ -159,6 +165,34 @@ class PassBuffers:
         self.pos_tok = self.dpos_tok = None      # per-sample position rows of a zero-padded batch and their gradient (lazy)
         self.drop = {L.MODE_INFER: (0, 0.0), L.MODE_DATA: (0, 0.0), L.MODE_FULL: (0, 0.0)}
         self.tail = {}                           # mode -> the last forward in that mode used the cls-only tail
+
+
+    def _init_lane(self, eng: "Engine", d, par: "PassBuffers", lane: int):
+        dev, B = eng.device, d.B
+        N = d.L + 1 + d.P
+        u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+        rows = lambda t, per: t[lane * B * per:(lane + 1) * B * per]
+        self.geom = self.ragged = None
+        self.B, self.d, self.lane, self.parent = B, d, lane, par
+        self.workspace = u8(lib.rmcl_workspace_bytes(C.byref(d)))
+        self.stash_full = None                                   # lanes run the data-gradient passes only
+        self.stash_data = u8(lib.rmcl_stash_bytes(C.byref(d), L.MODE_DATA))
+        self.hstash_q = u8(lib.rmcl_heads_stash_bytes(C.byref(d)))
+        self.hstash_k = u8(lib.rmcl_heads_stash_bytes(C.byref(d)))
+        self.co_mask = rows(par.co_mask, 1)
+        self.xn = rows(par.xn, N)
+        self.patches32, self.patchesT, self.patchesT_full = rows(par.patches32, d.P), rows(par.patchesT, d.P), rows(par.patchesT_full, d.P)
+        self.gpatch, self.delta, self.delta_prev = rows(par.gpatch, d.P), rows(par.delta, d.P), rows(par.delta_prev, d.P)
+        self.amax = rows(par.amax, 64)
+        self.cls, self.q, self.k, self.dq, self.dcls, self.rows = (rows(t, 1) for t in (par.cls, par.q, par.k, par.dq, par.dcls, par.rows))
+        self.loss_ring = torch.zeros(32, dtype=torch.float32, device=dev)
+        self.loss_i = 0
+        self.loss_sum = self.loss_ring[0:1]
+        self.nce_ws = u8(lib.rmcl_infonce_ws_bytes(B, I64(eng.num_negative)))
+        self.text_ids = self.text_mask = None
+        self.pos_tok = self.dpos_tok = None
+        self.drop = {L.MODE_INFER: (0, 0.0), L.MODE_DATA: (0, 0.0), L.MODE_FULL: (0, 0.0)}
+        self.tail = {}
 
 
 class RaggedGeometry:
@@ -274,6 +308,29 @@ class Engine:
     @staticmethod
     def _rg(pb: PassBuffers):
         return C.byref(pb.ragged) if pb.ragged is not None else None
+
+    def lanes(self, pb: PassBuffers, n: int = 2):
+        """The batch of `pb` as n independent half-size passes (or None where that does not apply).  Why: at B = 64 every launch of the
+        encoder fills the chip by itself, so all CUs load, run their k-loops and reach their (HBM-bound) epilogues TOGETHER, and most
+        launches are one tile per CU - nothing runs under a tile's prologue / epilogue.  Two chains of B / 2 on two HIP streams take
+        half the CUs each and drift apart, so one chain's epilogues and attention kernels fall into the other's k-loops
+        (tools/two_stream_test.py: 12-layer forward 2.93 ms as one chain, 2.58-2.70 ms as two).  The passes of the PGD loop are
+        independent per sample (the loss couples them only through the constant 1 / B), so each lane runs its own K-step loop.
+        RMCL_LANES=0 turns this off, RMCL_LANES=1 forces it for any even B (tests); default: even B >= 32, dense full-size images,
+        bf16 passes, dropout off."""
+        mode = os.environ.get("RMCL_LANES", "auto")
+        if mode == "0" or pb.B % n or pb.geom is not None or self.dropout_on or pb.dtype != L.BF16 or self.exact:
+            return None
+        if mode != "1" and pb.B < 32:
+            return None
+        ls = getattr(pb, "_lanes", None)
+        if ls is None:
+            ls = pb._lanes = [PassBuffers(self, pb.B // n, pb.dtype, None, lane_of=pb, lane=i) for i in range(n)]
+        for i, ln in enumerate(ls):                                          # the text tensors are new every step
+            ln.text_ids = pb.text_ids[i * ln.B:(i + 1) * ln.B]
+            ln.text_mask = pb.text_mask[i * ln.B:(i + 1) * ln.B]
+            ln.k = pb.k[i * ln.B:(i + 1) * ln.B]                             # (pb.k may have been re-pointed: compute_moco_contrastive)
+        return ls
 
     def pgd_bufs(self, pb: PassBuffers) -> PassBuffers:
         """Buffers of the PGD inner loop: `pb` itself, or (pgd_dtype="f32" on a bf16 engine) an fp32 twin that shares the

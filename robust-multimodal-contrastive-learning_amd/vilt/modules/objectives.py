@@ -3,6 +3,7 @@ vilt/modules/objectives.py (``compute_<task>(pl_module, batch) -> dict``); all t
 librmcl_hip.so through ``pl_module.engine``."""
 from __future__ import annotations
 
+import os
 from copy import copy
 
 import torch
@@ -218,21 +219,38 @@ def compute_moco_contrastive(pl_module, batch):
     # momentum update (:257-260).  (Moving the 1.6 GB sweep onto the key encoder's stream, beside the query encoder's first
     # forward, measured no gain: 37.5 vs 37.6 ms per step - both are HBM-bound there.)
     eng.ema(pl_module.momentum)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op, cls_tail=True)
-        eng.heads_forward(pk, key=True, wgrad=False)
+    # PGD step 0 runs the query encoder on img + delta_0 = img: with dropout off that IS the clean query forward
+    # (:267-275), so it is computed once (common sub-expression) and its logits give prediction_original.
+    fuse_clean = pl_module.image_view and not pl_module.text_view and not eng.dropout_on and not clean_view
+    # two half-batch chains (Engine.lanes) where the whole front of the step - key forward, K PGD iterations - is per sample: each
+    # lane runs its key forward and then its PGD loop, lane 0 on this stream, lane 1 on the side stream
+    use_lanes = fuse_clean and eng.pgd_bufs(pb) is pb and eng.lanes(pb) is not None
+    # with the lanes on this stream and the side stream, the key forward takes the (idle) weight-gradient stream: three chains
+    key_stream = eng.dw_stream if (use_lanes and os.environ.get("RMCL_KEY_LANES", "0") != "1") else side
+    key_lanes = eng.lanes(pk) if (use_lanes and key_stream is side) else None
+    if key_lanes is not None:
+        eng.fold_of(True)                                   # (refreshed on the main stream before the fork)
+        side.wait_stream(main)
+        check(lib.rmcl_tune_set(10, len(key_lanes)), "tune_set")
+        per = key_lanes[0].B * pb.d.P
+        for i, kl in enumerate(key_lanes):
+            with torch.cuda.stream(side if i else main):
+                eng.encoder_forward(kl, key=True, mode=L.MODE_INFER, patchesT=op[i * per:(i + 1) * per], cls_tail=True)
+                eng.heads_forward(kl, key=True, wgrad=False)
+        check(lib.rmcl_tune_set(10, 1), "tune_set")
+    else:
+        key_stream.wait_stream(main)
+        with torch.cuda.stream(key_stream):
+            eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op, cls_tail=True)
+            eng.heads_forward(pk, key=True, wgrad=False)
     gather_box = {}
 
     def join_key_stream():
-        main.wait_stream(side)
+        main.wait_stream(key_stream)
         # asynchronous key all-gather (RCCL's own stream): overlaps everything until the enqueue (one rank: the keys themselves)
         gather_box["g"] = dist_utils.KeyGather(pb.k.clone() if dist_utils.world_size() > 1 else pb.k) if pl_module.training else None
 
     k = pb.k
-    # PGD step 0 runs the query encoder on img + delta_0 = img: with dropout off that IS the clean query forward
-    # (:267-275), so it is computed once (common sub-expression) and its logits give prediction_original.
-    fuse_clean = pl_module.image_view and not pl_module.text_view and not eng.dropout_on and not clean_view
     clean = {}
     loss = 0
     loss_num = 0
@@ -266,8 +284,12 @@ def compute_moco_contrastive(pl_module, batch):
         loss = loss + loss_t
         loss_num += 1
     if pl_module.image_view:                                                # :319-354
-        if fuse_clean:
-            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, before_first_loss=join_key_stream, clean_out=clean, clean_op=op)
+        if key_lanes is not None:
+            join_key_stream()                               # lane 0 waits for lane 1's key forward only; every lane reads its own keys
+            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, clean_out=clean, clean_op=op)
+            prediction_original = clean["prediction"]
+        elif fuse_clean:
+            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, before_first_loss=join_key_stream, clean_out=clean, clean_op=op, key_stream=key_stream)
             prediction_original = clean["prediction"]
         else:
             pl_module.pgd_attacker.attack_patches(pl_module, pb, k, clean_op=op)        # compute_pgd (:319-323)

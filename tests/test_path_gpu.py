@@ -717,3 +717,37 @@ def test_public_infer_is_differentiable_like_the_reference():
     with torch.no_grad():                                        # and the stash-free pass returns plain tensors
         assert not m.infer(dev_batch(batch))["cls_feats"].requires_grad
     assert not m.infer_k(dev_batch(batch))["cls_feats"].requires_grad   # the momentum pass never carries gradients
+
+
+def test_half_batch_lanes_give_the_one_chain_step(monkeypatch):
+    """B = 64, bf16: the front of the step as two half-batch chains on two streams (Engine.lanes: key forward on a third stream, K PGD
+    iterations per lane, every per-sample buffer of a lane a view of the batch's) against the one-chain step.  Each sample's
+    arithmetic is the same in both (row-wise kernels, the same k order in every GEMM), so the perturbation, the keys and the
+    queries agree to the bit; the loss and the gradients come from the same attacked view."""
+    ocfg = O.default_config(num_layers=3, num_negative=1024, per_gpu_batchsize=64, adv_steps_img=2)
+    m, p = build_module(ocfg, 5, "bf16")
+    batch = dev_batch(O.synthetic_batch(ocfg, 64, 9, ragged_text=True))
+    m.engine.cfg["dense_images"] = True                          # (full-size images: the lanes' precondition, known without a device read)
+    out = {}
+    for lanes in ("0", "1", "0"):
+        monkeypatch.setenv("RMCL_LANES", lanes)
+        m.zero_grad()
+        m.queue_ptr = 0
+        m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+        m.shadow_momentum_encoder()
+        loss = m.training_step(batch, 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        pb = m.engine.bufs(64)
+        used = getattr(pb, "_lanes", None) is not None
+        assert used == (lanes == "1") or lanes == "0"
+        out.setdefault(lanes, []).append({"loss": float(loss), "delta": pb.delta.clone(), "q": pb.q.clone(), "k": pb.k.clone(),
+                                          "att": pb.patchesT_full.clone(), "g": m.engine.g32.clone()})
+    a, b, a2 = out["0"][0], out["1"][0], out["0"][1]
+    assert getattr(m.engine.bufs(64), "_lanes", None) is not None, "the lanes did not run"
+    for key in ("delta", "k", "att"):
+        assert torch.equal(a[key], b[key]), key
+    assert abs(a["loss"] - b["loss"]) < 1e-4 * abs(a["loss"])
+    ref_noise = float((a["g"] - a2["g"]).norm() / a["g"].norm())                       # run-to-run (float atomics of the cls-row scatter)
+    rel = float((a["g"] - b["g"]).norm() / a["g"].norm())
+    assert rel < max(1e-5, 10 * ref_noise), (rel, ref_noise)
