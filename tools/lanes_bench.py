@@ -37,9 +37,11 @@ def pgd():
     atk.attack_patches(m, pb, None, clean_op=eng.make_operand(pb))
 
 
+if os.environ.get("LANES_ATTN_WG"):
+    L.check(L.lib.rmcl_tune_set(8, int(os.environ["LANES_ATTN_WG"])))       # persistent attention backward with this many workgroups
 for lanes in ("0", "1"):
     os.environ["RMCL_LANES"] = lanes
-    for lag in ((0,) if lanes == "0" else (0, 50, 200, 1000)):
+    for lag in ((0,) if lanes == "0" else (0, 200)):
         os.environ["RMCL_LANE_LAG_US"] = str(lag)
         print(f"PGD loop, lanes={lanes}, lag {lag} us: {timed(pgd):.3f} ms")
 

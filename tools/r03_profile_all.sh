@@ -6,11 +6,16 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03p
 mkdir -p $O
 if [ "${1:-a}" == "a" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-feed-bench > $O/bench_trace.json 2> $O/trace.err
+# the one-chain step (RMCL_LANES=0: comparable with round 2's table), then the default step (half-batch lanes: 1378 dispatches, host-bound under the profiler)
+RMCL_LANES=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-feed-bench > $O/bench_trace.json 2> $O/trace.err
 python tools/step_timeline.py "$O/trace/**/*_kernel_trace.csv" --md $O/r03_step_table.md > /dev/null
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/r03_step_kernel_stats.csv
 python tools/dump_step.py "$O/trace/**/*_kernel_trace.csv" > $O/step_dump.txt
 rm -rf $O/trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/tracel -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-feed-bench > $O/bench_trace_lanes.json 2> $O/tracel.err
+python tools/step_timeline.py "$O/tracel/**/*_kernel_trace.csv" --md $O/r03_step_table_lanes.md > /dev/null
+cp $(ls $O/tracel/*/*kernel_stats.csv | head -1) $O/r03_step_kernel_stats_lanes.csv
+rm -rf $O/tracel
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/traceb -- python3 bench.py --config barlowtwins --steps 3 --warmup 1 --no-cpu-baseline --no-feed-bench > $O/bench_barlow.json 2> $O/traceb.err
 cp $(ls $O/traceb/*/*kernel_stats.csv | head -1) $O/r03_barlowtwins_kernel_stats.csv
 rm -rf $O/traceb
