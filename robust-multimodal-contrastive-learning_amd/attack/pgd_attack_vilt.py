@@ -82,7 +82,9 @@ class PGDAttack_moco(PGDAttack):
         # streams onto four hardware queues, and a fifth stream of this process shared the main stream's queue - the lanes then ran
         # one after the other (measured: no change of the step at all)
         side = eng.side_stream
-        streams = [main, side]
+        streams = [main, side, eng.comm_stream, eng.dw_stream][:len(lanes)]     # (four lanes: experiment, RMCL_LANE_COUNT=4)
+        for st in streams[2:]:
+            st.wait_stream(main)
         op_full = clean_op if clean_op is not None else eng.make_operand(pb)
         eng.fold_of(False)                                    # parameter-derived operands are refreshed on the main stream BEFORE the fork
         eng.weights_T()
@@ -134,7 +136,8 @@ class PGDAttack_moco(PGDAttack):
                     ops[i] = ln.patchesT_full if last else ln.patchesT
                     eng.pgd_step(ln, self.adv_lr_img, self.adv_max_norm_img, first=step == 0, out=ops[i], sum_prev=last)
         check(lib.rmcl_tune_set(10, 1), "tune_set")
-        main.wait_stream(side)
+        for st in streams[1:]:
+            main.wait_stream(st)
         return pb.delta
 
     def pgd_attack(self, pl_module, batch, k_modality=None):

@@ -309,7 +309,7 @@ class Engine:
     def _rg(pb: PassBuffers):
         return C.byref(pb.ragged) if pb.ragged is not None else None
 
-    def lanes(self, pb: PassBuffers, n: int = 2):
+    def lanes(self, pb: PassBuffers, n: int = None):
         """The batch of `pb` as n independent half-size passes (or None where that does not apply).  Why: at B = 64 every launch of the
         encoder fills the chip by itself, so all CUs load, run their k-loops and reach their (HBM-bound) epilogues TOGETHER, and most
         launches are one tile per CU - nothing runs under a tile's prologue / epilogue.  Two chains of B / 2 on two HIP streams take
@@ -319,12 +319,13 @@ class Engine:
         RMCL_LANES=0 turns this off, RMCL_LANES=1 forces it for any even B (tests); default: even B >= 32, dense full-size images,
         bf16 passes, dropout off."""
         mode = os.environ.get("RMCL_LANES", "auto")
+        n = int(os.environ.get("RMCL_LANE_COUNT", "2")) if n is None else n
         if mode == "0" or pb.B % n or pb.geom is not None or self.dropout_on or pb.dtype != L.BF16 or self.exact:
             return None
         if mode != "1" and pb.B < 32:
             return None
         ls = getattr(pb, "_lanes", None)
-        if ls is None:
+        if ls is None or len(ls) != n:
             ls = pb._lanes = [PassBuffers(self, pb.B // n, pb.dtype, None, lane_of=pb, lane=i) for i in range(n)]
         for i, ln in enumerate(ls):                                          # the text tensors are new every step
             ln.text_ids = pb.text_ids[i * ln.B:(i + 1) * ln.B]

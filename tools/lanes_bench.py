@@ -39,11 +39,11 @@ def pgd():
 
 if os.environ.get("LANES_ATTN_WG"):
     L.check(L.lib.rmcl_tune_set(8, int(os.environ["LANES_ATTN_WG"])))       # persistent attention backward with this many workgroups
-for lanes in ("0", "1"):
+for lanes, cnt in (("0", 2), ("1", 2), ("1", 4), ("0", 2), ("1", 2), ("1", 4)):
     os.environ["RMCL_LANES"] = lanes
-    for lag in ((0,) if lanes == "0" else (0, 200)):
-        os.environ["RMCL_LANE_LAG_US"] = str(lag)
-        print(f"PGD loop, lanes={lanes}, lag {lag} us: {timed(pgd):.3f} ms")
+    os.environ["RMCL_LANE_COUNT"] = str(cnt)
+    print(f"PGD loop, lanes={lanes} x {cnt}: {timed(pgd):.3f} ms")
+os.environ["RMCL_LANE_COUNT"] = "2"
 
 # forward / backward alone
 os.environ["RMCL_LANES"] = "1"
