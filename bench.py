@@ -187,6 +187,53 @@ def traffic_record(kernel_key):
     return r, r.get("note")
 
 
+def realistic_leg(model, cfg, batch, args, device, ViLTransformerSS, steps=10, warmup=3):
+    """The reference's real recipe beside the headline (SURVEY 8d "a separate training-realistic throughput line"): `task_moco` is
+    trained from `load_path=...vilt_200k_mlm_itm.ckpt` (TRAIN.md:21) with `drop_rate = 0.1` (config.py:57).  The headline model's state
+    is written to a checkpoint file and a SECOND module is constructed from it through config["load_path"] with drop_rate 0.1 - i.e.
+    through the code path a real run takes (what stays on after the load is reported) - then timed on the same synthetic batch:
+    dropout live in every train-mode forward incl. the key encoder and the PGD passes, the clean query forward separate from PGD
+    step 0 ((5 + 2K) F per pair instead of (4 + 2K) F: the two draw different masks in the reference)."""
+    import tempfile
+    import shutil
+    tmp = tempfile.mkdtemp(prefix="rmcl_bench_")
+    try:
+        path = os.path.join(tmp, "state.ckpt")
+        torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()}}, path)
+        cfg2 = dict(cfg, drop_rate=0.1, load_path=path)
+        cfg2["loss_names"] = dict(cfg["loss_names"])
+        m2 = ViLTransformerSS(cfg2, device=device, compute_dtype=args.dtype)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    m2.train()
+    (opt2,), (sched2,) = m2.configure_optimizers()
+
+    def step(i):
+        loss = m2.training_step(batch, i)
+        loss.backward()
+        opt2.step()
+        sched2["scheduler"].step()
+        opt2.zero_grad()
+        return loss
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng = m2.engine
+    B = batch["text_ids"].shape[0]
+    pb = eng.bufs(B)
+    return {"drop_rate": 0.1, "load_path": "checkpoint of the headline model's state, loaded through config['load_path']",
+            "ln_fold": m2.load_report.get("ln_fold"), "half_batch_lanes": "on" if getattr(pb, "_lanes", None) is not None else "off",
+            "cls_only_tail": "on" if any(pb.tail.values()) else "off",
+            "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3), "pairs_per_s": round(B * steps / dt, 2),
+            "executed_F_per_pair": 5 + 2 * cfg["adv_steps_img"], "final_loss": round(float(loss.detach()), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +257,9 @@ def main():
                     help="N > 1: on = per-layer buckets reduced on the communication stream while the backward runs; off = one blocking "
                          "pass over the arena after the backward (the comparison run)")
     ap.add_argument("--no-feed-bench", action="store_true", help="skip the input-pipeline feed-rate measurement (tools/feed_bench.py, N = 1 only)")
+    ap.add_argument("--no-realistic", action="store_true",
+                    help="skip the second, short leg of the default run: the same step in the reference's real recipe (drop_rate 0.1 after a "
+                         "load_path-style checkpoint load, TRAIN.md:21 / config.py:57) -> `training_realistic` in the JSON line")
     ap.add_argument("--padded-images", action="store_true",
                     help="run the general visual_embed path (pixel-mask patch selection + its device-to-host count read per step) on the "
                          "same full-size synthetic batch instead of the dense fast path")
@@ -370,7 +420,7 @@ def main():
         value = pairs / elapsed
         # algorithmic FLOPs per GPU per step: SURVEY 8(d) counts (5+2K)F; with dropout off the clean query forward
         # and PGD step 0's forward are the same computation and run once -> (4+2K)F are executed and credited
-        tail = args.drop_rate == 0 and (5 * B if full else B) <= 1024 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"   # (candidate batch: 5 B rows)
+        tail = (5 * B if full else B) <= 1024 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"   # (candidate batch: 5 B rows)
         F_c = F_PER_PAIR - (F_TAIL_SKIPPED if tail else 0.0)           # executed FLOPs of one contrastive forward-equivalent
         step_flops = ((4 if args.drop_rate == 0 else 5) + 2 * K) * F_c * B
         workload = (f"RMCL step, PGD K={K} image attack + MoCo InfoNCE (queue 65536) + full backward + AdamW, "
@@ -432,6 +482,9 @@ def main():
             out["feed"] = {"host": feed, "device_ingest": ingest,
                            "note": "row f3: host pairs/s of the arrow -> batch pipeline (byte path) beside the step's `value`; the step itself is "
                                    "measured on a batch already resident in HBM"}
+        out["config"]["ln_fold"] = "on (shift-robust form)" if model.engine.fold else "off"
+        if world == 1 and args.config == "rmcl_pgd" and args.drop_rate == 0 and not args.no_realistic:
+            out["training_realistic"] = realistic_leg(model, cfg, batch, args, device, ViLTransformerSS)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(K, args.config)
         print(json.dumps(out), flush=True)

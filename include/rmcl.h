@@ -99,6 +99,15 @@ int rmcl_linear_rowstat(const void* A, const void* W, const float* bias, const f
                         int M, int N, int K, void* stream);
 int rmcl_linear_lnfold(const void* xb, const void* wf, const float* s, const float* c, const float* part, int nparts, void* out,
                        void* preact, int M, int N, int K, int gelu, float eps, float* mean, float* rstd, void* stream);
+/* The SHIFT-ROBUST pair (round 4; what the encoder passes run).  LayerNorm is shift-invariant, LN(x) = LN(x - c) for any per-row c:
+ * with `center` [M] the producer stores out_bf16 = bf16(out - c_m) and the partial sums of (out - c_m), so the bf16 operand's rounding
+ * follows the row's spread instead of its offset (a trained checkpoint's residual stream is not zero-mean; reference norms:
+ * vision_transformer.py:351,362); the consumer's arithmetic is unchanged and it adds c_m back to the `mean` it writes.  The encoder
+ * uses c = the row mean of the row's previous LayerNorm, which already sits in the stash.  center = NULL: the two functions above.  */
+int rmcl_linear_rowstat_c(const void* A, const void* W, const float* bias, const float* residual, const float* center, float* out,
+                          void* out_bf16, float* part, int M, int N, int K, void* stream);
+int rmcl_linear_lnfold_c(const void* xb, const void* wf, const float* s, const float* c, const float* part, int nparts, const float* center,
+                         void* out, void* preact, int M, int N, int K, int gelu, float eps, float* mean, float* rstd, void* stream);
 
 /* Element offsets into a parameter arena.  Names follow the reference state dict. */
 typedef struct rmcl_layout {

@@ -400,23 +400,24 @@ def queue_metrics(q: Tensor, k: Tensor, queue: Tensor) -> dict:
     }
 
 
-def encode_q(p: Params, cfg: dict, ids, masks, img) -> Tuple[Tensor, dict]:
-    out = infer(p, cfg, ids, masks, img)
+def encode_q(p: Params, cfg: dict, ids, masks, img, drop: Optional[dict] = None) -> Tuple[Tensor, dict]:
+    out = infer(p, cfg, ids, masks, img, drop=drop)
     return l2_normalize(moco_head(p, "", out["cls_feats"])), out
 
 
 def pgd_attack(p: Params, cfg: dict, batch: dict, k: Tensor, queue: Tensor,
-               return_steps: bool = False):
+               return_steps: bool = False, drops: Optional[list] = None):
     """PGDAttack_moco.pgd_attack (attack/pgd_attack_vilt.py:130-175): K steps of
-    delta <- clamp(delta + lr * g / max(|g|_inf per sample, 1e-8), +-eps), g = d(CE/K)/d(delta)."""
+    delta <- clamp(delta + lr * g / max(|g|_inf per sample, 1e-8), +-eps), g = d(CE/K)/d(delta).
+    ``drops``: explicit dropout masks of each step's forward (the deep-copied encoder stays in train mode there)."""
     K, lr, eps = cfg["adv_steps_img"], cfg["adv_lr_img"], cfg["adv_max_norm_img"]
     img0 = batch["image"][0]
     delta = torch.zeros_like(img0)
     steps = []
-    for _ in range(K):
+    for step in range(K):
         d = delta.detach().clone().requires_grad_(True)
         with torch.enable_grad():
-            q, _ = encode_q(p, cfg, batch["text_ids"], batch["text_masks"], img0 + d)
+            q, _ = encode_q(p, cfg, batch["text_ids"], batch["text_masks"], img0 + d, drop=drops[step] if drops else None)
             loss = infonce_loss(infonce_logits(q, k, queue, cfg["temperature"])) / float(K)
             (g,) = torch.autograd.grad(loss, d)
         den = g.abs().flatten(1).max(dim=1).values.clamp_min(1e-8).view(-1, 1, 1, 1)
@@ -543,8 +544,12 @@ def enqueue(queue: Tensor, ptr: int, keys_all: Tensor, per_step_bs: int) -> int:
 
 
 def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, ptr: int,
-                             training: bool = True, gathered_keys=None) -> dict:
+                             training: bool = True, gathered_keys=None, drops: Optional[dict] = None) -> dict:
     """objectives.compute_moco_contrastive (objectives.py:217-447), image view.
+
+    ``drops`` (image view only): explicit dropout masks per encoder pass - {"key", "clean", "pgd": [one per step], "img"}, each an
+    ``infer(drop=...)`` dict - for the training-realistic configuration (drop_rate 0.1: dropout is live in every train-mode forward
+    incl. the key encoder and the PGD copies; torch's RNG stream cannot be matched, so the caller hands over the masks).
 
     Mutates ``p`` (EMA of k_*) and ``queue``.  Returns the loss (with autograd graph onto the
     query params that have requires_grad), logits, delta, metrics and the new queue pointer."""
@@ -553,9 +558,9 @@ def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, p
     ema_update(p, cfg["momentum"])
     ids, masks, img = batch["text_ids"], batch["text_masks"], batch["image"][0]
     with torch.no_grad():
-        out_k = infer(p, cfg, ids, masks, img, key=True)
+        out_k = infer(p, cfg, ids, masks, img, key=True, drop=(drops or {}).get("key"))
         k = l2_normalize(moco_head(p, "k_", out_k["cls_feats"]))
-    q0, _ = encode_q(p, cfg, ids, masks, img)
+    q0, _ = encode_q(p, cfg, ids, masks, img, drop=(drops or {}).get("clean"))
     T = cfg["temperature"]
     neg = queue.clone().detach()
     logits0 = infonce_logits(q0, k, neg, T)
@@ -578,14 +583,14 @@ def compute_moco_contrastive(p: Params, cfg: dict, batch: dict, queue: Tensor, p
                     "geom_success_rate": (lt.argmax(-1) != pred0).float().mean()})
     if cfg["image_view"]:
         pd = {kk: (v.detach() if torch.is_tensor(v) else v) for kk, v in p.items()}
-        delta, steps = pgd_attack(pd, cfg, batch, k, neg, return_steps=True)
+        delta, steps = pgd_attack(pd, cfg, batch, k, neg, return_steps=True, drops=(drops or {}).get("pgd"))
         # Reference quirk: pgd_attack overwrites the (deep-copied) batch image in place with
         # img_init + delta_{K-1} on its last iteration (pgd_attack_vilt.py:144) and compute_pgd then
         # adds the returned delta_K on top (objectives.py:176), so the attacked view is
         # img + delta_{K-1} + delta_K (delta_0 = 0), i.e. up to 2*eps away from the clean image.
         prev = steps[-2] if len(steps) >= 2 else torch.zeros_like(delta)
         attacked = img + prev + delta
-        qa, _ = encode_q(p, cfg, ids, masks, attacked)
+        qa, _ = encode_q(p, cfg, ids, masks, attacked, drop=(drops or {}).get("img"))
         la = infonce_logits(qa, k, neg, T)
         li = infonce_loss(la)
         loss, n = loss + li, n + 1

@@ -26,7 +26,7 @@ class PGDAttack_moco(PGDAttack):
     def __init__(self, config):
         super().__init__(config, "moco")
 
-    def attack_patches(self, pl_module, pb, k, before_first_loss=None, clean_out=None, keep_prev=False, clean_op=None, key_stream=None):
+    def attack_patches(self, pl_module, pb, k, before_first_loss=None, clean_out=None, keep_prev=False, clean_op=None, key_stream=None, key_event=None):
         """K-step attack in patch layout.  Leaves delta_K in ``pb.delta`` and the ATTACKED VIEW's operand
         cast(img + delta_{K-1} + delta_K) (see compute_pgd / objectives.py:176) in ``pb.patchesT_full``; with ``keep_prev``
         also delta_{K-1} in ``pb.delta_prev`` (the public ``pgd_attack`` needs it for the batch image it leaves behind).
@@ -46,7 +46,7 @@ class PGDAttack_moco(PGDAttack):
         pb = eng.pgd_bufs(pb)                                 # fp32 twin when the engine runs PGD in fp32 (:141)
         lanes = eng.lanes(pb) if pb is pb0 else None
         if lanes is not None:
-            return self._attack_lanes(eng, pb, lanes, K, before_first_loss, clean_out, keep_prev, clean_op, key_stream)
+            return self._attack_lanes(eng, pb, lanes, K, before_first_loss, clean_out, keep_prev, clean_op, key_stream, key_event)
         # img_init + delta_0, delta_0 = 0 (:136,144); ``clean_op``: the caller's cast of the clean image in pb.patchesT, if it has one
         op = clean_op if (clean_op is not None and pb is pb0) else eng.make_operand(pb)
         for step in range(K):
@@ -71,27 +71,28 @@ class PGDAttack_moco(PGDAttack):
             eng.pgd_step(pb, self.adv_lr_img, self.adv_max_norm_img, first=step == 0, out=op, sum_prev=last)   # :162-173
         return pb.delta
 
-    def _attack_lanes(self, eng, pb, lanes, K, before_first_loss, clean_out, keep_prev, clean_op, key_stream):
+    def _attack_lanes(self, eng, pb, lanes, K, before_first_loss, clean_out, keep_prev, clean_op, key_stream, key_event=None):
         """The same K steps as two independent half-batch chains (Engine.lanes): lane 0 on the current stream, lane 1 on
         ``eng.side_stream`` (RMCL_LANE_LAG_US: an extra start delay of lane 1; the host's call-by-call enqueue order already staggers them).
         Every per-sample buffer of a lane is a view of ``pb``'s, so ``pb`` ends up exactly as the one-chain loop leaves it.
-        ``key_stream``: the stream the keys are produced on, if not the current one (lane 1 waits for it by itself)."""
+        ``key_stream`` / ``key_event``: where the keys are produced, if not on the current stream (lane 1 waits for the event - or the
+        whole stream - by itself before its first InfoNCE)."""
         import os
+        from .._lib import lib, check
         main = torch.cuda.current_stream()
         # lane 1 runs on the engine's side stream, BEHIND the key-encoder forward the caller may have put there: HIP multiplexes its
         # streams onto four hardware queues, and a fifth stream of this process shared the main stream's queue - the lanes then ran
         # one after the other (measured: no change of the step at all)
         side = eng.side_stream
         streams = [main, side, eng.comm_stream, eng.dw_stream][:len(lanes)]     # (four lanes: experiment, RMCL_LANE_COUNT=4)
-        for st in streams[2:]:
-            st.wait_stream(main)
         op_full = clean_op if clean_op is not None else eng.make_operand(pb)
         eng.fold_of(False)                                    # parameter-derived operands are refreshed on the main stream BEFORE the fork
         eng.weights_T()
         if clean_out is not None:
             clean_out["prediction"] = torch.empty(pb.B, dtype=torch.float32, device=eng.device)
             clean_out["q"] = torch.empty_like(pb.q)
-        side.wait_stream(main)
+        for st in streams[1:]:                                # every lane stream forks AFTER the operand / fold / transposed-weight refresh
+            st.wait_stream(main)
         lag = float(os.environ.get("RMCL_LANE_LAG_US", "0"))
         if lag > 0:
             with torch.cuda.stream(side):
@@ -101,43 +102,47 @@ class PGDAttack_moco(PGDAttack):
         def on(i):
             return torch.cuda.stream(streams[i])
 
-        from .._lib import lib, check
         check(lib.rmcl_tune_set(10, len(lanes)), "tune_set")  # the GEMM routing sizes a launch against its share of the CUs
-
-        for step in range(K):
-            last = step == K - 1
-            # the host alternates between the lanes call by call, so that neither queue runs dry while the other is being filled
-            for i, ln in enumerate(lanes):
-                with on(i):
-                    eng.encoder_forward(ln, key=False, mode=L.MODE_DATA, patchesT=ops[i], cls_tail=True)
-                    eng.heads_forward(ln, key=False, wgrad=False)
-            for i, ln in enumerate(lanes):
-                with on(i):
-                    if step == 0:
-                        if i == 0 and before_first_loss is not None:
-                            before_first_loss()
-                        if i > 0 and key_stream is not None and key_stream is not streams[i]:
-                            streams[i].wait_stream(key_stream)
-                    eng.infonce(ln, grad_scale=1.0 / (pb.B * K), want_dq=True, metrics=False)       # 1 / B of the WHOLE batch (:152-158)
-                    if step == 0 and clean_out is not None:
-                        clean_out["prediction"][i * ln.B:(i + 1) * ln.B].copy_(ln.rows[:, 1])
-                        clean_out["q"][i * ln.B:(i + 1) * ln.B].copy_(ln.q)
-                    eng.heads_backward(ln, ln.dq, None, with_grads=False)
-            for i, ln in enumerate(lanes):
-                with on(i):
-                    eng.encoder_backward(ln, L.MODE_DATA, ops[i], ln.dcls, cls_only=True, dpatches=ln.gpatch)
-            for i, ln in enumerate(lanes):
-                with on(i):
-                    if last and keep_prev:
-                        if K > 1:
-                            ln.delta_prev.copy_(ln.delta)
-                        else:
-                            ln.delta_prev.zero_()
-                    ops[i] = ln.patchesT_full if last else ln.patchesT
-                    eng.pgd_step(ln, self.adv_lr_img, self.adv_max_norm_img, first=step == 0, out=ops[i], sum_prev=last)
-        check(lib.rmcl_tune_set(10, 1), "tune_set")
-        for st in streams[1:]:
-            main.wait_stream(st)
+        try:
+            for step in range(K):
+                last = step == K - 1
+                # the host alternates between the lanes call by call, so that neither queue runs dry while the other is being filled
+                for i, ln in enumerate(lanes):
+                    with on(i):
+                        eng.encoder_forward(ln, key=False, mode=L.MODE_DATA, patchesT=ops[i], cls_tail=True)
+                        eng.heads_forward(ln, key=False, wgrad=False)
+                for i, ln in enumerate(lanes):
+                    with on(i):
+                        if step == 0:
+                            if i == 0 and before_first_loss is not None:
+                                before_first_loss()
+                            if i > 0 and key_event is not None:
+                                streams[i].wait_event(key_event)
+                            elif i > 0 and key_stream is not None and key_stream is not streams[i]:
+                                streams[i].wait_stream(key_stream)
+                        eng.infonce(ln, grad_scale=1.0 / (pb.B * K), want_dq=True, metrics=False)       # 1 / B of the WHOLE batch (:152-158)
+                        if step == 0 and clean_out is not None:
+                            clean_out["prediction"][i * ln.B:(i + 1) * ln.B].copy_(ln.rows[:, 1])
+                            clean_out["q"][i * ln.B:(i + 1) * ln.B].copy_(ln.q)
+                        eng.heads_backward(ln, ln.dq, None, with_grads=False)
+                for i, ln in enumerate(lanes):
+                    with on(i):
+                        eng.encoder_backward(ln, L.MODE_DATA, ops[i], ln.dcls, cls_only=True, dpatches=ln.gpatch)
+                for i, ln in enumerate(lanes):
+                    with on(i):
+                        if last and keep_prev:
+                            if K > 1:
+                                ln.delta_prev.copy_(ln.delta)
+                            else:
+                                ln.delta_prev.zero_()
+                        ops[i] = ln.patchesT_full if last else ln.patchesT
+                        eng.pgd_step(ln, self.adv_lr_img, self.adv_max_norm_img, first=step == 0, out=ops[i], sum_prev=last)
+        finally:
+            # process-global routing state and the forked streams are put back on EVERY path: an exception inside the loop must not
+            # leave every later GEMM sized for half the chip or the side streams unjoined
+            check(lib.rmcl_tune_set(10, 1), "tune_set")
+            for st in streams[1:]:
+                main.wait_stream(st)
         return pb.delta
 
     def pgd_attack(self, pl_module, batch, k_modality=None):

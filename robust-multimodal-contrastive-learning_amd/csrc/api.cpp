@@ -112,7 +112,9 @@ extern int g_dp_stagger;
 extern int g_attn_bwd_persist;
 extern int g_attn_bwd_tpw;
 extern int g_gemm_share;
+extern bool g_lnfold_centred;
 int rmcl_tune_set(int key, int value) {
+  if (key == 11) { g_lnfold_centred = value != 0; return 0; }
   if (key == 7) { g_dp_stagger = value < 0 ? 0 : value; return 0; }                                  // gemm_dp: start delay of every CU's second workgroup (10 ns ticks)
   if (key == 10) { g_gemm_share = value < 1 ? 1 : (value > 8 ? 8 : value); return 0; }                 // chains sharing the chip (GEMM routing sizes a launch against CUs / share)
   if (key == 9) { g_attn_bwd_tpw = value; return 0; }                                             // fused attention backward: key tiles per wave (1, 2, 3)
@@ -263,20 +265,28 @@ int rmcl_weight_transpose_bf16(const rmcl_dims* d, const void* params_lp, void* 
 }
 int rmcl_linear_rowstat(const void* A, const void* W, const float* bias, const float* residual, float* out, void* out_bf16, float* part,
                         int M, int N, int K, void* stream) {
-  RMCL_REQUIRE(A && W && bias && residual && out && out_bf16 && part, "linear_rowstat: NULL argument");
-  GemmArgs g = ga(A, W, out, M, N, K, K, K, N);
-  g.epi = EPI_BIAS | EPI_RESIDUAL | EPI_ROWSTAT; g.bias = bias; g.aux = residual; g.ld_aux = N; g.C2 = out_bf16;
-  g.ln_part = part; g.ln_nparts = 4 * (N / 192);
-  RMCL_REQUIRE(N % 192 == 0 && rmcl_gemm_routes_to_tile192(g, 1, 1), "linear_rowstat: shape does not run on the 192-row tile kernels");
-  return rmcl_launch_gemm(g, RMCL_BF16, RMCL_F32, 1, 1, 0, (hipStream_t)stream);
+  return rmcl_linear_rowstat_c(A, W, bias, residual, nullptr, out, out_bf16, part, M, N, K, stream);
 }
 int rmcl_linear_lnfold(const void* xb, const void* wf, const float* s, const float* c, const float* part, int nparts, void* out,
                        void* preact, int M, int N, int K, int gelu, float eps, float* mean, float* rstd, void* stream) {
+  return rmcl_linear_lnfold_c(xb, wf, s, c, part, nparts, nullptr, out, preact, M, N, K, gelu, eps, mean, rstd, stream);
+}
+int rmcl_linear_rowstat_c(const void* A, const void* W, const float* bias, const float* residual, const float* center, float* out,
+                          void* out_bf16, float* part, int M, int N, int K, void* stream) {
+  RMCL_REQUIRE(A && W && bias && residual && out && out_bf16 && part, "linear_rowstat: NULL argument");
+  GemmArgs g = ga(A, W, out, M, N, K, K, K, N);
+  g.epi = EPI_BIAS | EPI_RESIDUAL | EPI_ROWSTAT; g.bias = bias; g.aux = residual; g.ld_aux = N; g.C2 = out_bf16;
+  g.ln_part = part; g.ln_nparts = 4 * (N / 192); g.ln_center = center;
+  RMCL_REQUIRE(N % 192 == 0 && rmcl_gemm_routes_to_tile192(g, 1, 1), "linear_rowstat: shape does not run on the 192-row tile kernels");
+  return rmcl_launch_gemm(g, RMCL_BF16, RMCL_F32, 1, 1, 0, (hipStream_t)stream);
+}
+int rmcl_linear_lnfold_c(const void* xb, const void* wf, const float* s, const float* c, const float* part, int nparts, const float* center,
+                         void* out, void* preact, int M, int N, int K, int gelu, float eps, float* mean, float* rstd, void* stream) {
   RMCL_REQUIRE(xb && wf && s && c && part && out, "linear_lnfold: NULL argument");
   GemmArgs g = ga(xb, wf, out, M, N, K, K, K, N);
   g.epi = EPI_LNFOLD | (gelu ? EPI_GELU : 0) | (preact ? EPI_SAVE_PREACT : 0); g.C2 = preact;
   g.ln_s = s; g.ln_c = c; g.ln_part = const_cast<float*>(part); g.ln_nparts = nparts; g.ln_cols = K; g.ln_eps = eps;
-  g.ln_mean = mean; g.ln_rstd = rstd;
+  g.ln_mean = mean; g.ln_rstd = rstd; g.ln_center = center;
   RMCL_REQUIRE(rmcl_gemm_routes_to_tile192(g, 1, 1), "linear_lnfold: shape does not run on the 192-row tile kernels");
   return rmcl_launch_gemm(g, RMCL_BF16, RMCL_BF16, 1, 1, 0, (hipStream_t)stream);
 }

@@ -367,7 +367,10 @@ __global__ __launch_bounds__(256) void u8_to_patches_kernel(const unsigned char*
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[c][i] = 0.f;
-  if (live && y < sizes[2 * b] && x < sizes[2 * b + 1]) {                 // (w is a multiple of 32: the 4 pixels are in or out together)
+  // extents clamped to the padded batch (the host checks them too: a hand-built batch must not send this read past its sample); a
+  // selected patch index outside the grid reads nothing
+  const int hb = min(sizes[2 * b], Hmax), wb = min(sizes[2 * b + 1], Wmax);
+  if (live && p >= 0 && y < hb && x < wb) {                                // (w is a multiple of 32: the 4 pixels are in or out together)
     const uint3 w = *reinterpret_cast<const uint3*>(img + (((long)b * Hmax + y) * Wmax + x) * 3);
     const unsigned wd[3] = {w.x, w.y, w.z};
 #pragma unroll
@@ -866,6 +869,23 @@ int rmcl_adamw(float* p, const float* g, float* m, float* v, void* p_lp, const l
 // x[i] *= mask(seed, i)  (in place; with x pre-filled with ones this materialises a site's mask for the tests)
 __global__ __launch_bounds__(256) void dropout_apply_kernel(float* __restrict__ x, long n, uint32_t dseed, uint32_t dthresh, float dinv) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x[i] *= drop_scale(dseed, (uint32_t)i, dthresh, dinv);
+}
+// out[r, c] = in[r, c] * mask(seed, (r * row_mul) * cols + c): the dropout mask of DENSE row r * row_mul applied to compact row r (the cls-only
+// tail under dropout draws the masks of the dense rows it stands for, so tail and dense block give the same numbers)
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, long row_mul,
+                                                           uint32_t dseed, uint32_t dthresh, float dinv) {
+  const long n = (long)rows * cols;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / cols, c = i - r * cols;
+    out[i] = in[i] * drop_scale(dseed, (uint32_t)(r * row_mul * cols + c), dthresh, dinv);
+  }
+}
+int rmcl_dropout_rows(const float* in, float* out, int rows, int cols, long row_mul, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
+  if (rows <= 0 || cols <= 0) return 0;
+  RMCL_LAUNCH(dropout_rows_kernel, dim3(std::min<long>(cdiv((long)rows * cols, 256), 1024)), dim3(256), 0, s, in, out, rows, cols, row_mul, dseed,
+              dthresh, dinv);
+  RMCL_CHECK_LAUNCH();
+  return 0;
 }
 int rmcl_dropout_apply(float* x, long n, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s) {
   if (n <= 0 || dthresh == 0) return 0;

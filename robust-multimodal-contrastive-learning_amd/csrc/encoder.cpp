@@ -227,6 +227,8 @@ int ensure_events() {
 
 }  // namespace
 
+bool g_lnfold_centred = true;        // rmcl_tune_set key 11: 0 = the uncentred LayerNorm fold of round 2 (A/B, precision tests)
+bool rmcl_lnfold_centred() { return g_lnfold_centred; }
 bool g_dw_grouped = true;            // rmcl_tune_set key 3: 0 selects the per-GEMM weight-gradient path (A/B and parity tests)
 
 extern "C" int rmcl_set_side_stream(void* stream) { g_side = (hipStream_t)stream; return 0; }
@@ -349,7 +351,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
   const bool tail_req = (mode & RMCL_MODE_CLS_TAIL) != 0;     // only the cls rows of xn will be read (include/rmcl.h)
   mode &= ~RMCL_MODE_CLS_TAIL;
   RMCL_REQUIRE(mode == RMCL_MODE_INFER || stash, "encoder_forward: stash required unless mode is INFER");
-  RMCL_REQUIRE(!tail_req || (drop_p == 0.f && d->B <= 1024), "encoder_forward: the cls-only tail needs dropout off and B <= 1024");
+  RMCL_REQUIRE(!tail_req || d->B <= 1024, "encoder_forward: the cls-only tail needs B <= 1024");
   Ctx c{*d, params32, params_lp, {}, (hipStream_t)stream, d->dtype};
   rmcl_param_layout(d, &c.lay);
   const rmcl_layout& y = c.lay;
@@ -363,8 +365,8 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
   RMCL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "encoder_forward: dropout probability must be in [0,1)");
   const uint32_t dth = drop_p > 0.f ? (uint32_t)((double)drop_p * 4294967296.0) : 0u;
   const float dinv = 1.0f / (1.0f - drop_p);
-  auto with_drop = [&](GemmArgs& g, int layer, int site) {
-    if (dth) { g.epi |= EPI_DROPOUT; g.drop_seed = rmcl_site_seed(drop_seed, layer, site); g.drop_thresh = dth; g.drop_inv_keep = dinv; }
+  auto with_drop = [&](GemmArgs& g, int layer, int site, int row_mul = 1) {
+    if (dth) { g.epi |= EPI_DROPOUT; g.drop_seed = rmcl_site_seed(drop_seed, layer, site); g.drop_thresh = dth; g.drop_inv_keep = dinv; g.drop_row_mul = row_mul; }
   };
 
   float* x0 = keep ? st.layer[0].x_in : w.x_a;
@@ -388,21 +390,26 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
 
   // LayerNorm folded into the consuming GEMMs (gemm.h EPI_LNFOLD / EPI_ROWSTAT): passes that keep no LayerNorm output
   // (INFER, DATA), bf16, dropout off, and only where every GEMM involved runs on the 192-row tile kernels
-  bool folded = fold && fold->wf && fold->sc && !full && dt == RMCL_BF16 && !d->exact && dth == 0 && D % 192 == 0;
+  // (dropout: the 192-row tile kernels carry the dropout epilogues as separate instantiations since round 4, so the fold stays on)
+  bool folded = fold && fold->wf && fold->sc && !full && dt == RMCL_BF16 && !d->exact && D % 192 == 0;
   const int fold_rows = 3 * D + d->mlp, nparts = 4 * (D / 192);
   if (folded) {
     GemmArgs t1 = gemm_args(w.xb_in, fold->wf, w.qkv, M, 3 * D, D, D, D, 3 * D);
     t1.epi = EPI_LNFOLD; t1.ln_s = fold->sc; t1.ln_c = fold->sc; t1.ln_part = w.part_in; t1.ln_nparts = nparts; t1.ln_cols = D;
     GemmArgs t2 = gemm_args(w.xb_mid, fold->wf, w.h, M, d->mlp, D, D, D, d->mlp);
-    t2.epi = EPI_LNFOLD | EPI_GELU | EPI_SAVE_PREACT; t2.C2 = w.u; t2.ln_s = fold->sc; t2.ln_c = fold->sc; t2.ln_part = w.part_mid; t2.ln_nparts = nparts; t2.ln_cols = D;
+    t2.epi = EPI_LNFOLD | EPI_GELU | EPI_SAVE_PREACT | (dth ? EPI_DROPOUT : 0); t2.C2 = w.u; t2.ln_s = fold->sc; t2.ln_c = fold->sc; t2.ln_part = w.part_mid; t2.ln_nparts = nparts; t2.ln_cols = D;
     GemmArgs t3 = gemm_args(w.ao, c.W(c.L(0, y.proj_w)), w.x_mid, M, D, D, D, D, D);
-    t3.epi = EPI_BIAS | EPI_RESIDUAL | EPI_ROWSTAT; t3.bias = c.V(y.norm_b); t3.aux = w.x_a; t3.ld_aux = D; t3.C2 = w.xb_mid; t3.ln_part = w.part_mid; t3.ln_nparts = nparts;
+    t3.epi = EPI_BIAS | EPI_RESIDUAL | EPI_ROWSTAT | (dth ? EPI_DROPOUT : 0); t3.bias = c.V(y.norm_b); t3.aux = w.x_a; t3.ld_aux = D; t3.C2 = w.xb_mid; t3.ln_part = w.part_mid; t3.ln_nparts = nparts;
     GemmArgs t4 = gemm_args(w.h, c.W(c.L(0, y.fc2_w)), w.x_a, M, D, d->mlp, d->mlp, d->mlp, D);
     t4.epi = t3.epi; t4.bias = t3.bias; t4.aux = w.x_mid; t4.ld_aux = D; t4.C2 = w.xb_in; t4.ln_part = w.part_in; t4.ln_nparts = nparts;
     folded = rmcl_gemm_routes_to_tile192(t1, 1, 1) && rmcl_gemm_routes_to_tile192(t2, 1, 1) && rmcl_gemm_routes_to_tile192(t3, 1, 1) &&
              rmcl_gemm_routes_to_tile192(t4, 1, 1);
   }
   const bf16_t* fw = folded ? (const bf16_t*)fold->wf : nullptr;
+  // shift-robust form of the fold (gemm.h ln_center): every producer stores bf16(x - c) and the partial sums of (x - c), c = the row mean
+  // of the row's PREVIOUS LayerNorm (LN is shift-invariant: exact for any c), so the operand's rounding follows the row's spread instead of
+  // its offset.  rmcl_tune_set(11, 0) restores the uncentred round-2 form (A/B, precision tests).
+  const bool centred = folded && rmcl_lnfold_centred();
   float* x = x0;
   for (int l = 0; l < d->layers; ++l) {
     LayerStash ls{};
@@ -419,13 +426,17 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     void* h = full ? ls.h : w.h;
     void* u = keep ? ls.u : nullptr;
     const float* sc_l = folded ? fold->sc + (long)l * 2 * fold_rows : nullptr;        // s[0..rows), c[rows..2 rows)
+    // LayerNorm 2's row means of the previous layer = the centre the previous fc2 used for this layer's LayerNorm-1 operand
+    const float* m2_prev = l > 0 ? (keep ? st.layer[l - 1].mean2 : w.stat + 2 * M) : nullptr;
 
     if (folded && l > 0) {
       // qkv = LN1(x) Wqkv^T + b: A = the bf16 copy of x the previous fc2 epilogue wrote, row statistics from its partial sums
       GemmArgs g = gemm_args(w.xb_in, fw + (long)l * fold_rows * D, qkv, M, 3 * D, D, D, D, 3 * D);
       g.epi = EPI_LNFOLD; g.tag = GEMM_TAG_QKV;
       g.ln_s = sc_l; g.ln_c = sc_l + fold_rows; g.ln_part = w.part_in; g.ln_nparts = nparts; g.ln_cols = D; g.ln_eps = 1e-6f;
-      g.ln_mean = keep ? m1 : nullptr; g.ln_rstd = keep ? r1 : nullptr;
+      // the partials (and the bf16 operand) were taken about the previous LayerNorm's row mean (m2 of layer l - 1, see the fc2 producer);
+      // the statistics are written in every mode now: the next producer centres on them
+      g.ln_mean = m1; g.ln_rstd = r1; g.ln_center = centred ? m2_prev : nullptr;
       RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
     } else {
       RMCL_TRY(rmcl_ln_fwd(x, D, c.V(c.L(l, y.ln1_w)), c.V(c.L(l, y.ln1_b)), 1e-6f, ln1, D, dt, m1, r1, M, D, 0, s));
@@ -439,7 +450,8 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
       // heads.py:17), and everything behind the attention is row-wise - proj, LayerNorm 2, the MLP and the final LayerNorm run
       // on the B cls rows (fp32, exact skinny GEMMs) instead of on all B * N tokens.  Compact results live in the FIRST B rows
       // of the buffers the dense path would have filled (x_mid, u, h, ln2, x_final, the LN statistics) - the backward with
-      // cls_only = 2 reads them there.
+      // cls_only = 2 reads them there.  Dropout: compact row b draws the mask of the dense row b * N it stands for (gemm.h
+      // drop_row_mul), so the tail gives the dense block's numbers under dropout too.
       float* ao_c = reinterpret_cast<float*>(w.dao);          // backward scratch, free during a forward
       float* ln2_c = reinterpret_cast<float*>(full ? ls.ln2 : w.ln);
       float* u_c = reinterpret_cast<float*>(keep ? ls.u : w.u);
@@ -450,17 +462,20 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
         // residual operand: the cls rows of the dense residual stream, read in place (row b at b * N * D: no gather launch)
         GemmArgs g = gemm_args(ao_c, c.V(c.L(l, y.proj_w)), x_mid, B, D, D, D, D, D);
         g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = N * D;
+        with_drop(g, l, DROP_SITE_PROJ, N);
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
       }
       RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2_c, D, RMCL_F32, m2, r2, B, D, 0, s));
       {
         GemmArgs g = gemm_args(ln2_c, c.V(c.L(l, y.fc1_w)), h_c, B, d->mlp, D, D, D, d->mlp);
         g.epi = EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT; g.bias = c.V(c.L(l, y.fc1_b)); g.C2 = u_c;
+        with_drop(g, l, DROP_SITE_HIDDEN, N);
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
       }
       {
         GemmArgs g = gemm_args(h_c, c.V(c.L(l, y.fc2_w)), xo_c, B, D, d->mlp, d->mlp, d->mlp, D);
         g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.fc2_b)); g.aux = x_mid; g.ld_aux = D;
+        with_drop(g, l, DROP_SITE_FC2, N);
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 1, s));
       }
       // final LayerNorm of the cls rows, written to their places in xn (row b * N); the other rows of xn are NOT written
@@ -471,7 +486,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     {
       GemmArgs g = gemm_args(ao, c.W(c.L(l, y.proj_w)), x_mid, M, D, D, D, D, D);
       g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.proj_b)); g.aux = x; g.ld_aux = D; g.tag = GEMM_TAG_PROJ;
-      if (folded) { g.epi |= EPI_ROWSTAT; g.C2 = w.xb_mid; g.ln_part = w.part_mid; g.ln_nparts = nparts; }
+      if (folded) { g.epi |= EPI_ROWSTAT; g.C2 = w.xb_mid; g.ln_part = w.part_mid; g.ln_nparts = nparts; g.ln_center = centred ? m1 : nullptr; }
       with_drop(g, l, DROP_SITE_PROJ);
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
     }
@@ -479,7 +494,8 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
       GemmArgs g = gemm_args(w.xb_mid, fw + ((long)l * fold_rows + 3 * D) * D, h, M, d->mlp, D, D, D, d->mlp);
       g.epi = EPI_LNFOLD | EPI_GELU | (u ? EPI_SAVE_PREACT : 0); g.C2 = u; g.tag = GEMM_TAG_FC1;
       g.ln_s = sc_l + 3 * D; g.ln_c = sc_l + fold_rows + 3 * D; g.ln_part = w.part_mid; g.ln_nparts = nparts; g.ln_cols = D; g.ln_eps = 1e-6f;
-      g.ln_mean = keep ? m2 : nullptr; g.ln_rstd = keep ? r2 : nullptr;
+      g.ln_mean = m2; g.ln_rstd = r2; g.ln_center = centred ? m1 : nullptr;
+      with_drop(g, l, DROP_SITE_HIDDEN);
       RMCL_TRY(gemm(c, g, dt, dt, 1, 1));
     } else {
       RMCL_TRY(rmcl_ln_fwd(x_mid, D, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), 1e-6f, ln2, D, dt, m2, r2, M, D, 0, s));
@@ -491,7 +507,7 @@ int rmcl_encoder_forward(const rmcl_dims* d, int mode, const float* params32, co
     {
       GemmArgs g = gemm_args(h, c.W(c.L(l, y.fc2_w)), x_out, M, D, d->mlp, d->mlp, d->mlp, D);
       g.epi = EPI_BIAS | EPI_RESIDUAL; g.bias = c.V(c.L(l, y.fc2_b)); g.aux = x_mid; g.ld_aux = D; g.tag = GEMM_TAG_FC2;
-      if (folded && l + 1 < d->layers) { g.epi |= EPI_ROWSTAT; g.C2 = w.xb_in; g.ln_part = w.part_in; g.ln_nparts = nparts; }
+      if (folded && l + 1 < d->layers) { g.epi |= EPI_ROWSTAT; g.C2 = w.xb_in; g.ln_part = w.part_in; g.ln_nparts = nparts; g.ln_center = centred ? m2 : nullptr; }
       with_drop(g, l, DROP_SITE_FC2);
       RMCL_TRY(gemm(c, g, dt, RMCL_F32, 1, 1));
     }
@@ -527,7 +543,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   // final LayerNorm backward -> dx (the residual-stream gradient, fp32)
   const float* dy = dxn;
   const bool tail = cls_only == 2;               // the forward of this stash used the cls-only tail (compact last-layer rows)
-  RMCL_REQUIRE(!tail || (drop_p == 0.f && d->B <= 1024), "encoder_backward: the cls-only tail needs dropout off and B <= 1024");
+  RMCL_REQUIRE(!tail || d->B <= 1024, "encoder_backward: the cls-only tail needs B <= 1024");
   if (cls_only && !tail) {
     hipError_t e = hipMemsetAsync(w.dxn_full, 0, (size_t)M * D * sizeof(float), s);
     if (e != hipSuccess) { rmcl_set_error(hipGetErrorString(e)); return (int)e; }
@@ -593,18 +609,27 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       float* dln_c = w.dln;
       float* ao_c = reinterpret_cast<float*>(w.dqkv2);
       float* dao_c = reinterpret_cast<float*>(w.du2);
+      // dropout: the gradient entering fc2 / proj is the residual-stream gradient times the mask of that branch's output - the mask of
+      // the DENSE cls row b * N (forward: drop_row_mul = N); dxc itself keeps flowing down the residual path unmasked
+      const float* dy2 = dxc;                                 // d(fc2 output)
+      if (dth) {
+        float* m2 = reinterpret_cast<float*>(w.dS);           // (attention-backward scratch: free until the attention backward below)
+        RMCL_TRY(rmcl_dropout_rows(dxc, m2, B, D, N, rmcl_site_seed(drop_seed, l, DROP_SITE_FC2), dth, dinv, s));
+        dy2 = m2;
+      }
       {
-        GemmArgs g = gemm_args(dxc, c.V(c.L(l, y.fc2_w)), du_c, B, mlp, D, D, mlp, mlp);               // du = (dx W2) * gelu'(u)
+        GemmArgs g = gemm_args(dy2, c.V(c.L(l, y.fc2_w)), du_c, B, mlp, D, D, mlp, mlp);               // du = (dx W2) * gelu'(u) [* hidden mask]
         g.epi = EPI_DGELU; g.aux = u_c; g.ld_aux = mlp;
+        if (dth) { g.epi |= EPI_DROP_BWD; g.drop_seed = rmcl_site_seed(drop_seed, l, DROP_SITE_HIDDEN); g.drop_thresh = dth; g.drop_inv_keep = dinv; g.drop_row_mul = N; }
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 0, s));
       }
       if (full) {
-        GemmArgs g = gemm_args(dxc, h_c, Gp(c.L(l, y.fc2_w)), D, mlp, B, D, mlp, mlp);                   // dW2 += dx^T h
+        GemmArgs g = gemm_args(dy2, h_c, Gp(c.L(l, y.fc2_w)), D, mlp, B, D, mlp, mlp);                   // dW2 += dx^T h
         g.epi = EPI_ACCUM;
         const bool cs = rmcl_gemm_tn_shortk_takes(g);                                                    // bias gradient from the same launch
         if (cs) { g.epi |= EPI_COLSUM; g.colsum = Gp(c.L(l, y.fc2_b)); }
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
-        if (!cs) RMCL_TRY(rmcl_colsum(dxc, D, RMCL_F32, Gp(c.L(l, y.fc2_b)), B, D, s));
+        if (!cs) RMCL_TRY(rmcl_colsum(dy2, D, RMCL_F32, Gp(c.L(l, y.fc2_b)), B, D, s));
       }
       {
         GemmArgs g = gemm_args(du_c, c.V(c.L(l, y.fc1_w)), dln_c, B, D, mlp, mlp, D, D);                 // dln2 = du W1
@@ -620,18 +645,24 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
       }
       RMCL_TRY(rmcl_ln_bwd(dln_c, D, RMCL_F32, ls.x_mid, D, ls.mean2, ls.rstd2, c.V(c.L(l, y.ln2_w)), c.V(c.L(l, y.ln2_b)), dxc, D, 1,
                            full ? Gp(c.L(l, y.ln2_w)) : nullptr, full ? Gp(c.L(l, y.ln2_b)) : nullptr, B, D, 0, s));   // dxc = d x_mid
+      const float* dyp = dxc;                                 // d(proj output)
+      if (dth) {
+        float* mp = reinterpret_cast<float*>(w.dS) + (size_t)B * D;
+        RMCL_TRY(rmcl_dropout_rows(dxc, mp, B, D, N, rmcl_site_seed(drop_seed, l, DROP_SITE_PROJ), dth, dinv, s));
+        dyp = mp;
+      }
       {
-        GemmArgs g = gemm_args(dxc, c.V(c.L(l, y.proj_w)), dao_c, B, D, D, D, D, D);                     // dao = dx Wproj
+        GemmArgs g = gemm_args(dyp, c.V(c.L(l, y.proj_w)), dao_c, B, D, D, D, D, D);                     // dao = dx Wproj
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 1, 0, s));
       }
       if (full) {
         RMCL_TRY(rmcl_rows_gather_cast(ls.ao, dt, ao_c, B, D, N, 0, s));
-        GemmArgs g = gemm_args(dxc, ao_c, Gp(c.L(l, y.proj_w)), D, D, B, D, D, D);                       // dWproj += dx^T ao
+        GemmArgs g = gemm_args(dyp, ao_c, Gp(c.L(l, y.proj_w)), D, D, B, D, D, D);                       // dWproj += dx^T ao
         g.epi = EPI_ACCUM;
         const bool cs = rmcl_gemm_tn_shortk_takes(g);
         if (cs) { g.epi |= EPI_COLSUM; g.colsum = Gp(c.L(l, y.proj_b)); }
         RMCL_TRY(rmcl_launch_gemm_exact(g, RMCL_F32, RMCL_F32, 0, 0, s));
-        if (!cs) RMCL_TRY(rmcl_colsum(dxc, D, RMCL_F32, Gp(c.L(l, y.proj_b)), B, D, s));
+        if (!cs) RMCL_TRY(rmcl_colsum(dyp, D, RMCL_F32, Gp(c.L(l, y.proj_b)), B, D, s));
       }
       HIP_TRY(hipMemsetAsync(w.dx, 0, (size_t)M * D * sizeof(float), s));
       RMCL_TRY(rmcl_scatter_rows(dxc, w.dx, B, D, 1, N, 0, 0, s));

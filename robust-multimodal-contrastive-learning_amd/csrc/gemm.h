@@ -57,12 +57,18 @@ struct GemmArgs {
   int tag;                // profiling class (GEMM_TAG_*), 0 = untagged
   uint32_t drop_seed, drop_thresh;   // dropout site seed, p * 2^32
   float drop_inv_keep;               // 1 / (1 - p)
+  int drop_row_mul;                  // exact skinny GEMMs on COMPACT rows (cls-only tail): row r of this GEMM is dense row r * drop_row_mul, and the
+                                     // mask index is (r * drop_row_mul) * ld + n - the same mask the dense block draws for that row.  0 = 1
   // LayerNorm fold (EPI_LNFOLD / EPI_ROWSTAT)
   const float* ln_s;                 // [N] column sums of W'
   const float* ln_c;                 // [N] W beta + bias
   float* ln_part;                    // [M][ln_nparts][2] partial (sum, sum of squares) of the LN input rows
   float* ln_mean;                    // consumer, optional: [M] mean / rstd written by the tile_n == 0 tiles (stash for the backward)
   float* ln_rstd;
+  const float* ln_center;            // optional [M] per-row centre c_m (LN(x) = LN(x - c) exactly): the producer stores bf16(x - c) and the
+                                     // partial sums of (x - c), so the operand's rounding scales with the row's SPREAD, not with its offset;
+                                     // the consumer adds c back to the mean it stashes.  The encoder passes the row mean of the row's previous
+                                     // LayerNorm (already in the stash).  NULL: c = 0 (the round-2 form)
   int ln_nparts;                     // partials per row (4 per 192-column tile of the producer)
   int ln_cols;                       // row width of the LN input (768)
   float ln_eps;

@@ -171,13 +171,14 @@ __global__ __launch_bounds__(256) void gemm_exact_kernel(GemmArgs g) {
         if (row < g.M && col < g.N) {
           float v = g.alpha * acc[i][j][r];
           if ((epi & EPI_BIAS) && first_slice) v += g.bias[col];
-          if (epi & EPI_DROP_BWD) v *= drop_scale(g.drop_seed, (uint32_t)((long)row * g.ld_aux + col), g.drop_thresh, g.drop_inv_keep);
+          const long drow = (long)row * (g.drop_row_mul > 0 ? g.drop_row_mul : 1);
+          if (epi & EPI_DROP_BWD) v *= drop_scale(g.drop_seed, (uint32_t)(drow * g.ld_aux + col), g.drop_thresh, g.drop_inv_keep);
           if (epi & EPI_DGELU) v *= gelu_erf_grad(to_f32<TI>(reinterpret_cast<const TI*>(aux)[(long)row * g.ld_aux + col]));
           const long ci = (long)row * g.ldc + col;
           if (epi & EPI_SAVE_PREACT) C2[ci] = from_f32<TO>(v);
           if (epi & EPI_GELU) v = gelu_erf(v);
           if (epi & EPI_TANH) v = tanhf(v);
-          if (epi & EPI_DROPOUT) v *= drop_scale(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep);
+          if (epi & EPI_DROPOUT) v *= drop_scale(g.drop_seed, (uint32_t)(drow * g.ldc + col), g.drop_thresh, g.drop_inv_keep);
           if (epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(aux)[(long)row * g.ld_aux + col];
           if (epi & EPI_ATOMIC) {
             if constexpr (sizeof(TO) == 4) atomicAdd(reinterpret_cast<float*>(C) + ci, v);
@@ -399,6 +400,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs g) {
       if (g.epi & EPI_GELU) v = gelu_erf(v);
       if (g.epi & EPI_TANH) v = tanhf(v);
       if (g.epi & EPI_DGELU) v *= gelu_erf_grad(reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n]);
+      const long drow = (long)row * (g.drop_row_mul > 0 ? g.drop_row_mul : 1);                       // dense row of this compact row (gemm.h)
+      if (g.epi & EPI_DROP_BWD) v *= drop_scale(g.drop_seed, (uint32_t)(drow * g.ld_aux + n), g.drop_thresh, g.drop_inv_keep);
+      if (g.epi & EPI_DROPOUT) v *= drop_scale(g.drop_seed, (uint32_t)(drow * g.ldc + n), g.drop_thresh, g.drop_inv_keep);
       if (g.epi & EPI_RESIDUAL) v += reinterpret_cast<const float*>(g.aux)[(long)row * g.ld_aux + n];
       if (g.epi & EPI_ACCUM) v += C[ci];
       C[ci] = v;
@@ -514,6 +518,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g)
     if (g.epi & EPI_GELU) v = gelu_erf(v);
     if (g.epi & EPI_TANH) v = tanhf(v);
     if (g.epi & EPI_DGELU) v *= gelu_erf_grad(aux[it]);
+    const long drow = (long)row * (g.drop_row_mul > 0 ? g.drop_row_mul : 1);                         // dense row of this compact row (gemm.h)
+    if (g.epi & EPI_DROP_BWD) v *= drop_scale(g.drop_seed, (uint32_t)(drow * g.ld_aux + n), g.drop_thresh, g.drop_inv_keep);
+    if (g.epi & EPI_DROPOUT) v *= drop_scale(g.drop_seed, (uint32_t)(drow * g.ldc + n), g.drop_thresh, g.drop_inv_keep);
     if (g.epi & EPI_RESIDUAL) v += aux[it];
     if (g.epi & EPI_ACCUM) v += oldc[it];
     C[ci] = v;
@@ -523,7 +530,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g)
 
 bool rmcl_gemm_skinny_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc) {
   return a_kc && dt_in == RMCL_F32 && dt_out == RMCL_F32 && g.M <= 1024 && g.K % 16 == 0 && g.K >= 64 && g.splitk <= 1 &&
-         g.nb1 * g.nb2 == 1 && (g.epi & ~(EPI_BIAS | EPI_TANH | EPI_ACCUM | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_RESIDUAL | EPI_DUP)) == 0 &&
+         g.nb1 * g.nb2 == 1 && (g.epi & ~(EPI_BIAS | EPI_TANH | EPI_ACCUM | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_RESIDUAL | EPI_DUP | EPI_DROPOUT | EPI_DROP_BWD)) == 0 &&
+         (!(g.epi & EPI_DROP_BWD) || (g.epi & EPI_DGELU)) &&
          !((g.epi & EPI_DUP) && (g.epi & EPI_SAVE_PREACT)) &&
          !((g.epi & EPI_DGELU) && (g.epi & EPI_RESIDUAL)) && g.lda % 4 == 0 && g.ldb % 4 == 0 &&
          ((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0;

@@ -334,7 +334,8 @@ int rmcl_launch_gemm_big(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipS
 int rmcl_gemm_route_code(const GemmArgs& g, int dt_out, int a_kc, int b_kc) {
   if (g_gemm_cfg == 80 && rmcl_gemm_dp_supported(g, a_kc, b_kc) && !((g.epi & EPI_RESIDUAL) && dt_out != RMCL_F32)) return 3;
   // 192x384 tiles where they make exact rounds (N = 3072 at M = 64*185: 496 tiles = 2 x 248)
-  if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248 / g_gemm_share) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc)) return 2;
+  if ((g_gemm_cfg == 70 || (g_gemm_cfg < 0 && rmcl_gemm_sw_fill(g, 248 / g_gemm_share) >= 0.95)) && rmcl_gemm_sw_supported(g, a_kc, b_kc) &&
+      !((g.epi & (EPI_DROPOUT | EPI_DROP_BWD)) && dt_out != RMCL_BF16)) return 2;      // (its dropout epilogues write bf16)
   // 192x192 ping-pong tiles for the activation GEMMs (M = B*185 rows) whenever they fill the CU rounds
   if ((g_gemm_cfg == 60 || (g_gemm_cfg < 0 && rmcl_gemm_st_fill(g, 256 / g_gemm_share) >= 0.7)) && rmcl_gemm_st_supported(g, a_kc, b_kc)) return 1;
   if (g_gemm_cfg == 50 && rmcl_gemm_pp_supported(g, a_kc, b_kc)) return 4;

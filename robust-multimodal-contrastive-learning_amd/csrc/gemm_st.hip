@@ -554,7 +554,7 @@ bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
     if (!b_kc || (g.epi & ~EPI_LNFOLD) || !g.ln_s || !g.ln_c || !g.ln_part || g.ln_nparts % 2 || g.ln_nparts <= 0 || g.ln_cols <= 0) return false;
   }
   if (g.epi & EPI_ROWSTAT) {                                      // producer: fp32 residual-stream output of [rows][K] x [cols][K]
-    if (!b_kc || (g.epi & ~(EPI_ROWSTAT | EPI_BIAS | EPI_RESIDUAL)) || !(g.epi & EPI_RESIDUAL) || !g.ln_part || !g.C2 || g.ln_nparts != 4 * (g.N / ST_T))
+    if (!b_kc || (g.epi & ~(EPI_ROWSTAT | EPI_BIAS | EPI_RESIDUAL | EPI_DROPOUT)) || !(g.epi & EPI_RESIDUAL) || !g.ln_part || !g.C2 || g.ln_nparts != 4 * (g.N / ST_T))
       return false;
   }
   return true;
@@ -616,17 +616,18 @@ static int launch_st(const GemmArgs& g, int dt_out, hipStream_t s) {
   return launch_st2<B_KC, ST_AUX_NONE>(g, dt_out, s);
 }
 
-template <int AUX, typename TO, int LNF>
+template <int AUX, typename TO, int LNF, bool DROP = false>
 static int launch_st_lnf(const GemmArgs& g, hipStream_t s) {
   static bool attr = false;
-  constexpr int LDS = ST_LDS + (LNF == 1 ? 2048 : 0);
+  constexpr int LDS = ST_LDS + (LNF != 0 ? 2048 : 0);     // + the epilogue's row statistics (consumer) / row centres (producer)
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_st_kernel<true, true, AUX, TO, false, 2, LNF>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_st_kernel<true, true, AUX, TO, DROP, 2, LNF>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    RMCL_REQUIRE(e == hipSuccess, "gemm_st: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     attr = true;
   }
   const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = cdiv(g.M, tm);
   const int grid = min(tm * tn, max(8, st_num_cus() - g_st_reserve_cus));
-  RMCL_LAUNCH((gemm_st_kernel<true, true, AUX, TO, false, 2, LNF>), dim3(grid), dim3(512), LDS, s, g, tm, tn, rows, g_st_xflags);
+  RMCL_LAUNCH((gemm_st_kernel<true, true, AUX, TO, DROP, 2, LNF>), dim3(grid), dim3(512), LDS, s, g, tm, tn, rows, g_st_xflags);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -638,7 +639,8 @@ int rmcl_launch_gemm_st(const GemmArgs& g, int dt_out, int a_kc, int b_kc, hipSt
   }
   if (g.epi & EPI_ROWSTAT) {
     RMCL_REQUIRE(a_kc && b_kc && dt_out == RMCL_F32, "gemm_st: the row-statistics producer writes the fp32 residual stream");
-    return launch_st_lnf<ST_AUX_RES, float, 2>(g, s);
+    // (dropout on the branch output, before the residual add: its own instantiation - training-realistic passes only)
+    return (g.epi & EPI_DROPOUT) ? launch_st_lnf<ST_AUX_RES, float, 2, true>(g, s) : launch_st_lnf<ST_AUX_RES, float, 2>(g, s);
   }
   if (!a_kc) {
     RMCL_REQUIRE(dt_out == RMCL_F32 && !b_kc, "gemm_st: the [K][M] x [K][N] form writes fp32");

@@ -53,7 +53,9 @@ __device__ __forceinline__ int st_tile_id(int b, int r, int G, int T) {
 // barrier apart), and both execute the same number (2 + 2 * chunks), so the skew survives the epilogue.
 // LNF = 1: LayerNorm-folded consumer (EPI_LNFOLD): v = rstd_m * (acc - mean_m * s_n) + c_n, row statistics from the
 //          producer's partials (this group's 96 rows, one thread each, into `rowstat`: 192 x (mean, rstd) in LDS)
-// LNF = 2: producer (EPI_ROWSTAT): bf16 copy of the fp32 output + per-row partial sums of this wave's 48 columns
+// LNF = 2: producer (EPI_ROWSTAT): bf16 copy of the fp32 output + per-row partial sums of this wave's 48 columns; with
+//          g.ln_center both are taken of (x - c_m) (gemm.h: LN is shift-invariant, so any per-row centre is exact) - the centres of
+//          the group's 96 rows are parked in `rowstat` (one float per tile row) behind the epilogue's first barrier
 template <int AUX, typename TO, bool DROP, int LNF = 0, bool ACCPRE = false>
 __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const GemmArgs& g, const STTile& T, int wm, int wn, int lane, int wave,
                                                 char* scratch, float* rowstat = nullptr) {
@@ -99,6 +101,8 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       const int row = wm * 96 + tgs;
       const long m = min(T.m0 + row, g.M - 1);
       const float4* pp = reinterpret_cast<const float4*>(g.ln_part + m * (long)(g.ln_nparts * 2));
+      const bool stash_m = T.n0 == 0 && g.ln_mean && T.m0 + row < T.m_end;
+      const float cen = (stash_m && g.ln_center) ? g.ln_center[m] : 0.f;   // the partials are sums of (x - c): the TRUE mean is mean + c
       float s1 = 0.f, s2 = 0.f;
       if (g.ln_nparts == 16) {                                 // (the step's shape: all 8 loads in flight together, not 8 L2 round trips)
         float4 v[8];
@@ -113,8 +117,13 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       const float rstd = rsqrtf(fmaxf(s2 * inv - mean * mean, 0.f) + g.ln_eps);
       rowstat[2 * row] = mean;
       rowstat[2 * row + 1] = rstd;
-      if (T.n0 == 0 && g.ln_mean && T.m0 + row < T.m_end) { g.ln_mean[m] = mean; g.ln_rstd[m] = rstd; }
+      if (stash_m) { g.ln_mean[m] = mean + cen; g.ln_rstd[m] = rstd; }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  if constexpr (LNF == 2) {
+    const int tgs = (wave & 3) * 64 + lane;
+    if (tgs < 96) rowstat[wm * 96 + tgs] = g.ln_center ? g.ln_center[min(T.m0 + wm * 96 + tgs, g.M - 1)] : 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   ST_STAMP(3);
@@ -124,6 +133,11 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
   if constexpr (LNF == 1) {                                    // mean / rstd of this lane's six rows, read once
 #pragma unroll
     for (int i = 0; i < 6; ++i) rs[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
+  }
+  float cen6[LNF == 2 ? 6 : 1];
+  if constexpr (LNF == 2) {                                    // centres of this lane's six rows
+#pragma unroll
+    for (int i = 0; i < 6; ++i) cen6[i] = rowstat[wm * 96 + i * 16 + (lane & 15)];
   }
   // ACCPRE (the weight-gradient launch, C += tile): the OLD values of the whole tile are fetched in ONE batch ahead of the chunk loop.
   // Inside the store loop every iteration was "LDS read, global load, wait, add, store": 18 serial HBM round trips per tile = 22 us of
@@ -185,8 +199,9 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
         }
         if (AUX == ST_AUX_RES) { v[0] += res[il][j].x; v[1] += res[il][j].y; v[2] += res[il][j].z; v[3] += res[il][j].w; }
         if constexpr (LNF == 2) {
-          ps1 += (v[0] + v[1]) + (v[2] + v[3]);
-          ps2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          const float c0 = cen6[i], d0 = v[0] - c0, d1 = v[1] - c0, d2 = v[2] - c0, d3 = v[3] - c0;
+          ps1 += (d0 + d1) + (d2 + d3);
+          ps2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
         // image: row il*16 + lane%16, element column wn*48 + j*16 + 4*(lane/16); 16-byte chunk index XOR (row & 7)
         const int row = il * 16 + (lane & 15);
@@ -233,10 +248,11 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
             *reinterpret_cast<float4*>(dst) = o;
-            if constexpr (LNF == 2) {                          // bf16 copy of the residual stream: the next GEMM's A operand
+            if constexpr (LNF == 2) {                          // bf16 copy of the (centred) residual stream: the next GEMM's A operand
+              const float c0 = rowstat[wm * 96 + ch * ROWS + row];
               uint2 pk;
-              pk.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
-              pk.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+              pk.x = (uint32_t)f2bf(o.x - c0) | ((uint32_t)f2bf(o.y - c0) << 16);
+              pk.y = (uint32_t)f2bf(o.z - c0) | ((uint32_t)f2bf(o.w - c0) << 16);
               *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C2) + (long)m * g.ldc + T.n0 + (cp ^ (row & 7)) * 4) = pk;
             }
           } else {

@@ -189,7 +189,10 @@ __device__ __forceinline__ void sw_store4(TO* p, const float (&v)[4]) {
 
 // LNF = 1: LayerNorm folded into this GEMM (EPI_LNFOLD, gemm.h): A = bf16 copy of the residual stream, B = W * gamma;
 // v = rstd_m * (acc - mean_m * s_n) + c_n with the row statistics summed from the producer's partials into LDS.
-template <bool B_KC, int AUX, typename TO, int LNF = 0>
+// DROP (bf16 outputs only): the dropout epilogues of the training-realistic configuration (drop_rate 0.1, config.py:57) as separate
+// instantiations - EPI_DROPOUT on fc1's GELU output, EPI_DROP_BWD (that mask again) on fc2-dX - so that the dropout-free kernels carry
+// none of their state; masks are counter-based (rmcl_common.h), indexed by the dense element index like every other kernel's.
+template <bool B_KC, int AUX, typename TO, int LNF = 0, bool DROP = false>
 __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, int tiles_n, int rows_per_tile) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, lane = t & 63;
@@ -262,8 +265,10 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
   // when this kernel starts - fetched here, under the latency of the first k-tile's LDS-DMA, instead of at the head of the
   // epilogue (tools/st_trace.py: chunk 0 of the epilogue 5.7 us against 3.4 us for chunk 1, the difference being this round trip)
   float4 pst[LNF == 1 ? 8 : 1];
+  float cen = 0.f;                                              // centre of the row's partial sums (gemm.h ln_center): only the stashed mean needs it
   if constexpr (LNF == 1) {
     if (t < 192) {
+      if (n0 == 0 && g.ln_mean && g.ln_center) cen = g.ln_center[min((long)m0 + t, (long)g.M - 1)];
       const float4* pp = reinterpret_cast<const float4*>(g.ln_part + min((long)m0 + t, (long)g.M - 1) * (long)(g.ln_nparts * 2));
       if (g.ln_nparts == 16) {
 #pragma unroll
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
       float* rowstat0 = reinterpret_cast<float*>(smem + SW_LDS);
       rowstat0[2 * t] = mean;
       rowstat0[2 * t + 1] = rstd;
-      if (n0 == 0 && g.ln_mean && m0 + t < m_end) { g.ln_mean[m] = mean; g.ln_rstd[m] = rstd; }
+      if (n0 == 0 && g.ln_mean && m0 + t < m_end) { g.ln_mean[m] = mean + cen; g.ln_rstd[m] = rstd; }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (published by the barrier below; first read in the epilogue)
   }
@@ -411,6 +416,13 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
               v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
               v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
             }
+            if constexpr (DROP) {
+              if (epi & EPI_DROP_BWD) {                              // mask of the forward's hidden dropout, indexed like the stash
+                const uint32_t di = (uint32_t)((long)(mb + i * 16) * g.ld_aux + nb + j * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, di + r, g.drop_thresh, g.drop_inv_keep);
+              }
+            }
             const int e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);        // 8-byte unit (4 bf16) in the 384-column row
             const int off = row * ROWB + (((e8 >> 1) ^ (row & 7)) * 16) + (e8 & 1) * 8;
             if (stash) {
@@ -422,6 +434,13 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
             if (epi & EPI_GELU) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+            }
+            if constexpr (DROP) {
+              if (epi & EPI_DROPOUT) {
+                const uint32_t ci = (uint32_t)((long)(mb + i * 16) * g.ldc + nb + j * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, ci + r, g.drop_thresh, g.drop_inv_keep);
+              }
             }
             uint2 pk;
             pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
@@ -511,7 +530,8 @@ bool rmcl_gemm_sw_supported(const GemmArgs& g, int a_kc, int b_kc) {
   if (!a_kc || g.nb1 > 1 || g.nb2 > 1 || g.splitk > 1) return false;
   if (g.N % 384 != 0 || g.K % 64 != 0 || g.K < 128) return false;
   if ((long)g.M * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
-  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_LNFOLD)) return false;   // (residual epilogue: 72 more live registers spill; N = 768 anyway)
+  if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_LNFOLD | EPI_DROPOUT | EPI_DROP_BWD)) return false;   // (residual epilogue: 72 more live registers spill; N = 768 anyway)
+  if ((g.epi & EPI_DROP_BWD) && !(g.epi & EPI_DGELU)) return false;          // (dropout epilogues: bf16 outputs only - the router checks dt_out)
   if (g.epi & EPI_LNFOLD) {
     if (!b_kc || (g.epi & (EPI_BIAS | EPI_DGELU)) || !g.ln_s || !g.ln_c || !g.ln_part || g.ln_nparts % 2 || g.ln_nparts <= 0 || g.ln_cols <= 0) return false;
   }
@@ -524,21 +544,26 @@ double rmcl_gemm_sw_fill(const GemmArgs& g, int cus) {
   return (double)tiles / (double)(cdiv(tiles, (long)cus) * cus);
 }
 
-template <bool B_KC, int AUX, typename TO>
+template <bool B_KC, int AUX, typename TO, bool DROP = false>
 static int launch_sw3(const GemmArgs& g, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sw_kernel<B_KC, AUX, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sw_kernel<B_KC, AUX, TO, 0, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
+    RMCL_REQUIRE(e == hipSuccess, "gemm_sw: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     attr = true;
   }
   const int tm = cdiv(g.M, 192), tn = g.N / 384, rows = cdiv(g.M, tm);
-  RMCL_LAUNCH((gemm_sw_kernel<B_KC, AUX, TO>), dim3(tm * tn), dim3(512), SW_LDS, s, g, tm, tn, rows);
+  RMCL_LAUNCH((gemm_sw_kernel<B_KC, AUX, TO, 0, DROP>), dim3(tm * tn), dim3(512), SW_LDS, s, g, tm, tn, rows);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
 
 template <bool B_KC, int AUX>
 static int launch_sw2(const GemmArgs& g, int dt_out, hipStream_t s) {
+  if (g.epi & (EPI_DROPOUT | EPI_DROP_BWD)) {
+    RMCL_REQUIRE(dt_out == RMCL_BF16, "gemm_sw: the dropout epilogues write bf16");
+    return launch_sw3<B_KC, AUX, bf16_t, true>(g, s);
+  }
   return dt_out == RMCL_F32 ? launch_sw3<B_KC, AUX, float>(g, s) : launch_sw3<B_KC, AUX, bf16_t>(g, s);
 }
 
@@ -548,15 +573,17 @@ static int launch_sw(const GemmArgs& g, int dt_out, hipStream_t s) {
   return launch_sw2<B_KC, SW_AUX_NONE>(g, dt_out, s);
 }
 
+template <bool DROP>
 static int launch_sw_lnf(const GemmArgs& g, hipStream_t s) {
   static bool attr = false;
   constexpr int LDS = SW_LDS + 2048;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1, DROP>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    RMCL_REQUIRE(e == hipSuccess, "gemm_sw: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     attr = true;
   }
   const int tm = cdiv(g.M, 192), tn = g.N / 384, rows = cdiv(g.M, tm);
-  RMCL_LAUNCH((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1>), dim3(tm * tn), dim3(512), LDS, s, g, tm, tn, rows);
+  RMCL_LAUNCH((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1, DROP>), dim3(tm * tn), dim3(512), LDS, s, g, tm, tn, rows);
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -564,7 +591,7 @@ static int launch_sw_lnf(const GemmArgs& g, hipStream_t s) {
 int rmcl_launch_gemm_sw(const GemmArgs& g, int dt_out, int b_kc, hipStream_t s) {
   if (g.epi & EPI_LNFOLD) {
     RMCL_REQUIRE(b_kc && dt_out == RMCL_BF16, "gemm_sw: the LayerNorm-folded form is [rows][K] x [cols][K] with bf16 output");
-    return launch_sw_lnf(g, s);
+    return (g.epi & EPI_DROPOUT) ? launch_sw_lnf<true>(g, s) : launch_sw_lnf<false>(g, s);
   }
   return b_kc ? launch_sw<true>(g, dt_out, s) : launch_sw<false>(g, dt_out, s);
 }

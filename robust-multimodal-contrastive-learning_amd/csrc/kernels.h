@@ -13,6 +13,7 @@ int rmcl_slab_reduce(const float* slab, float* out, long n, int nz, hipStream_t 
 int rmcl_gemm_fast_get_cfg();
 void rmcl_gemm_skinny_set_form(int v);     // gemm_exact.hip: 0 = row-split skinny kernel only
 bool rmcl_gemm_routes_to_tile192(const GemmArgs& g, int a_kc, int b_kc);
+bool rmcl_lnfold_centred();          // rmcl_tune_set key 11 (api.cpp): the shift-robust form of the LayerNorm fold is on (default)
 int rmcl_gemm_route_code(const GemmArgs& g, int dt_out, int a_kc, int b_kc);   // 0 128x128, 1 gemm_st, 2 gemm_sw, 3 gemm_dp, 4 / 5 256x256
 // LayerNorm fold (gemm.h EPI_LNFOLD): per layer W' = bf16(W * gamma) for qkv (3D rows) then fc1 (mlp rows), and s / c vectors
 int rmcl_ln_fold_launch(const float* p32, long layer0, long stride, int layers, long ln1_w, long ln1_b, long qkv_w, long qkv_b, long ln2_w,
@@ -62,6 +63,7 @@ int rmcl_text_embed_fwd(const long* ids, const float* word, const float* pos, co
                         const float* beta, const float* vtype0, float eps, float* x, float* e_save, float* mean, float* rstd,
                         int B, int L, int N, int D, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
 int rmcl_dropout_apply(float* x, long n, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
+int rmcl_dropout_rows(const float* in, float* out, int rows, int cols, long row_mul, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
 int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, float* dpos, float* dbtype0, int B, int L, int D,
                             long pad_id, hipStream_t s);
 int rmcl_gather_rows(const float* in, float* out, int R, int D, int rows_per, long stride_outer, long off, hipStream_t s);

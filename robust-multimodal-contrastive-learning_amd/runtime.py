@@ -249,7 +249,7 @@ class Engine:
         # W' = W * gamma (bf16) + the s / c vectors per arena, re-derived whenever the fp32 masters change
         self.fold = {}
         self.fold_stale = {"q": True, "k": True}
-        if self.dtype == L.BF16 and os.environ.get("RMCL_NO_LN_FOLD", "0") != "1" and float(cfg.get("drop_rate", 0.0)) == 0.0:
+        if self.dtype == L.BF16 and os.environ.get("RMCL_NO_LN_FOLD", "0") != "1":
             nw, ns = lib.rmcl_ln_fold_elems(C.byref(d0), 0), lib.rmcl_ln_fold_elems(C.byref(d0), 1)
             for a in ("q", "k"):
                 wf, sc = z(nw, torch.bfloat16), z(ns)
@@ -264,6 +264,7 @@ class Engine:
         self.dropout_on = False            # set by the module per step (self.training)
         self.seed_base = int(cfg.get("seed", 0)) + 1
         self.pass_counter = 0
+        self.pass_log = None               # a list here records every encoder pass (tests/test_path_gpu.py: the dropout masks of a whole step)
         self._lut = None                                                   # 256-entry normalisation table of the uint8 feed path
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.dw_stream = torch.cuda.Stream(device=self.device)
@@ -317,10 +318,12 @@ class Engine:
         (tools/two_stream_test.py: 12-layer forward 2.93 ms as one chain, 2.58-2.70 ms as two).  The passes of the PGD loop are
         independent per sample (the loss couples them only through the constant 1 / B), so each lane runs its own K-step loop.
         RMCL_LANES=0 turns this off, RMCL_LANES=1 forces it for any even B (tests); default: even B >= 32, dense full-size images,
-        bf16 passes, dropout off."""
+        bf16 passes.  Dropout (round 4): every lane's pass draws its own seed (`encoder_forward`), remembered with the lane's stash, so
+        forward and backward of a lane agree; the masks of a lane are indexed by the lane's own rows - a different, equally valid draw
+        than the one-chain step's (tests hand the materialised per-lane masks to the oracle)."""
         mode = os.environ.get("RMCL_LANES", "auto")
         n = int(os.environ.get("RMCL_LANE_COUNT", "2")) if n is None else n
-        if mode == "0" or pb.B % n or pb.geom is not None or self.dropout_on or pb.dtype != L.BF16 or self.exact:
+        if mode == "0" or pb.B % n or pb.geom is not None or pb.dtype != L.BF16 or self.exact:
             return None
         if mode != "1" and pb.B < 32:
             return None
@@ -462,8 +465,15 @@ class Engine:
         ps, S = self.cfg["patch_size"], self.cfg["image_size"]
         data = u8.data.to(self.device, non_blocking=True).contiguous()
         B, Hh, Ww, _ = data.shape
-        if ps != 32 or Hh % ps or Ww % ps or bool((u8.sizes % ps != 0).any()):
-            raise ValueError(f"uint8 batches need sides that are multiples of the 32-pixel patch (got {tuple(data.shape)}, sizes {u8.sizes.tolist()})")
+        sz = torch.as_tensor(u8.sizes)
+        if sz.dim() != 2 or tuple(sz.shape) != (B, 2):
+            raise ValueError(f"Uint8Batch.sizes must be [B, 2] = (height, width) per sample (got {tuple(sz.shape)} for a batch of {B})")
+        if ps != 32 or Hh % ps or Ww % ps or bool((sz % ps != 0).any()):
+            raise ValueError(f"uint8 batches need sides that are multiples of the 32-pixel patch (got {tuple(data.shape)}, sizes {sz.tolist()})")
+        if bool((sz[:, 0] < 1).any()) or bool((sz[:, 0] > Hh).any()) or bool((sz[:, 1] < 1).any()) or bool((sz[:, 1] > Ww).any()):
+            # the ingest kernel addresses img + ((b * Hmax + y) * Wmax + x) * 3 from these extents: an extent outside the padded
+            # batch (a hand-built batch, swapped (w, h)) would read past the sample
+            raise ValueError(f"Uint8Batch.sizes must satisfy 1 <= h <= {Hh}, 1 <= w <= {Ww} (got {sz.tolist()})")
         gh, gw = Hh // ps, Ww // ps
         if gh * gw > 1024:
             raise ValueError(f"at most 1024 patches per image ({gh}x{gw} given)")
@@ -534,10 +544,11 @@ class Engine:
     def encoder_forward(self, pb: PassBuffers, key: bool, mode: int, patchesT: torch.Tensor, cls_tail: bool = False):
         """cls_tail: the caller reads only the cls row of every sample of pb.xn (the contrastive objectives: pooler -> head); the
         last block then runs its row-wise part on B rows (include/rmcl.h RMCL_MODE_CLS_TAIL).  Remembered per (buffers, mode):
-        the matching encoder_backward picks the compact form by itself.  Off with dropout (masks are indexed by dense rows)."""
+        the matching encoder_backward picks the compact form by itself.  Under dropout the compact rows draw the masks of the dense
+        rows they stand for (csrc/gemm.h drop_row_mul): the tail gives the dense block's numbers there too."""
         if self.lp_stale:
             self.refresh_shadows()
-        tail = bool(cls_tail) and not self.dropout_on and pb.B <= 1024 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"
+        tail = bool(cls_tail) and pb.B <= 1024 and os.environ.get("RMCL_NO_CLS_TAIL", "0") != "1"
         pb.tail[mode] = tail
         # dropout (reference: live in every train-mode forward incl. the key encoder and the PGD copies, SURVEY
         # quirk 6): a fresh seed per pass, remembered per stash so the matching backward regenerates the masks
@@ -545,6 +556,8 @@ class Engine:
         seed = (self.seed_base * 2654435761 + self.pass_counter * 40503) & 0xFFFFFFFF
         p = self.drop_p if self.dropout_on else 0.0
         pb.drop[mode] = (seed, p)
+        if self.pass_log is not None:                                  # (tests: which pass drew which masks)
+            self.pass_log.append({"seed": seed, "p": p, "mode": mode, "key": bool(key), "B": pb.B, "lane": getattr(pb, "lane", None), "tail": tail})
         p32, plp = (self.k32, self.k_lp) if key else (self.q32, self.q_lp)
         stash = {L.MODE_INFER: None, L.MODE_DATA: pb.stash_data, L.MODE_FULL: pb.stash_full}[mode]
         check(lib.rmcl_encoder_forward(C.byref(pb.d), mode | (L.MODE_CLS_TAIL if tail else 0), P(p32), P(plp), P(pb.text_ids), P(pb.text_mask), P(patchesT),

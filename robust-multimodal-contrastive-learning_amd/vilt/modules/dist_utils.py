@@ -304,9 +304,12 @@ class StepGradSync:
         if self.open <= 0:
             # two forwards before their backwards: begin_step() of the second forgot the first one's closure, the first backward
             # has already reduced the arena, and this one would add the summed arena over the ranks again (gradients x world size)
+            why = ("the first backward has already reduced the gradient arena over the ranks and this one would add the summed arena again "
+                   "(gradients x world size)") if (dist.is_available() and dist.is_initialized() and world_size() > 1) else \
+                  "the step's closure count no longer matches its backwards"
             raise RuntimeError("StepGradSync: a deferred backward ran that the current step did not register - a loss of an EARLIER "
-                               "forward was back-propagated after the next forward began; run every loss.backward() of a step before "
-                               "the next training_step (or accumulate with sync_grads=False)")
+                               f"forward was back-propagated after the next forward began ({why}); run every loss.backward() of a step "
+                               "before the next training_step (or accumulate with sync_grads=False)")
         self.open -= 1
         if self.open > 0 or not enabled:
             return

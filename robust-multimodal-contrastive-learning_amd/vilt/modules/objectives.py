@@ -222,36 +222,49 @@ def compute_moco_contrastive(pl_module, batch):
     # PGD step 0 runs the query encoder on img + delta_0 = img: with dropout off that IS the clean query forward
     # (:267-275), so it is computed once (common sub-expression) and its logits give prediction_original.
     fuse_clean = pl_module.image_view and not pl_module.text_view and not eng.dropout_on and not clean_view
-    # two half-batch chains (Engine.lanes) where the whole front of the step - key forward, K PGD iterations - is per sample: each
-    # lane runs its key forward and then its PGD loop, lane 0 on this stream, lane 1 on the side stream
-    use_lanes = fuse_clean and eng.pgd_bufs(pb) is pb and eng.lanes(pb) is not None
+    # two half-batch chains (Engine.lanes) where the PGD loop is the step's front: each lane runs its own K iterations, lane 0 on this
+    # stream, lane 1 on the side stream.  With dropout ON the clean query forward cannot be shared with PGD step 0 (the reference draws
+    # a fresh mask for each, objectives.py:267 vs pgd_attack_vilt.py:145): it then follows the key forward on the key stream, in its own
+    # buffers, beside the lanes
+    use_lanes = (pl_module.image_view and not pl_module.text_view and not clean_view and eng.pgd_bufs(pb) is pb and eng.lanes(pb) is not None)
     # with the lanes on this stream and the side stream, the key forward takes the (idle) weight-gradient stream: three chains
-    key_stream = eng.dw_stream if (use_lanes and os.environ.get("RMCL_KEY_LANES", "0") != "1") else side
+    key_stream = eng.dw_stream if (use_lanes and (os.environ.get("RMCL_KEY_LANES", "0") != "1" or not fuse_clean)) else side
     key_lanes = eng.lanes(pk) if (use_lanes and key_stream is side) else None
+    k_ready = None                          # event: the keys are in pb.k (None: wait for the whole key stream)
     if key_lanes is not None:
         eng.fold_of(True)                                   # (refreshed on the main stream before the fork)
         side.wait_stream(main)
         check(lib.rmcl_tune_set(10, len(key_lanes)), "tune_set")
-        per = key_lanes[0].B * pb.d.P
-        for i, kl in enumerate(key_lanes):
-            with torch.cuda.stream(side if i else main):
-                eng.encoder_forward(kl, key=True, mode=L.MODE_INFER, patchesT=op[i * per:(i + 1) * per], cls_tail=True)
-                eng.heads_forward(kl, key=True, wgrad=False)
-        check(lib.rmcl_tune_set(10, 1), "tune_set")
+        try:
+            per = key_lanes[0].B * pb.d.P
+            for i, kl in enumerate(key_lanes):
+                with torch.cuda.stream(side if i else main):
+                    eng.encoder_forward(kl, key=True, mode=L.MODE_INFER, patchesT=op[i * per:(i + 1) * per], cls_tail=True)
+                    eng.heads_forward(kl, key=True, wgrad=False)
+        finally:
+            check(lib.rmcl_tune_set(10, 1), "tune_set")      # (process-global routing state: restored on every path)
     else:
+        if use_lanes and not fuse_clean:
+            eng.fold_of(False)                              # the clean query pass will read the query fold on the key stream: refresh it before the fork
         key_stream.wait_stream(main)
         with torch.cuda.stream(key_stream):
             eng.encoder_forward(pk, key=True, mode=L.MODE_INFER, patchesT=op, cls_tail=True)
             eng.heads_forward(pk, key=True, wgrad=False)
+            k_ready = torch.cuda.Event()
+            k_ready.record(key_stream)
     gather_box = {}
 
     def join_key_stream():
-        main.wait_stream(key_stream)
+        if k_ready is not None:
+            main.wait_event(k_ready)
+        else:
+            main.wait_stream(key_stream)
         # asynchronous key all-gather (RCCL's own stream): overlaps everything until the enqueue (one rank: the keys themselves)
         gather_box["g"] = dist_utils.KeyGather(pb.k.clone() if dist_utils.world_size() > 1 else pb.k) if pl_module.training else None
 
     k = pb.k
     clean = {}
+    clean_on_key = False
     loss = 0
     loss_num = 0
     if clean_view:
@@ -265,6 +278,18 @@ def compute_moco_contrastive(pl_module, batch):
         pl_module.log("moco_loss/clean_loss", loss_c.detach())
         loss = loss + loss_c
         loss_num += 1
+    elif not fuse_clean and use_lanes and k_ready is not None:
+        # clean query (:267-275) behind the key forward on the key stream, in buffers of its own (the lanes' passes use pb's)
+        pc = eng.twin(pb, "clean_q")
+        pc.text_ids, pc.text_mask, pc.k = pb.text_ids, pb.text_mask, pb.k
+        clean = {"prediction": torch.empty(B, dtype=torch.float32, device=eng.device), "q": torch.empty_like(pb.q)}
+        with torch.cuda.stream(key_stream):
+            eng.encoder_forward(pc, key=False, mode=L.MODE_INFER, patchesT=op, cls_tail=True)
+            eng.heads_forward(pc, key=False, wgrad=False)
+            eng.infonce(pc, 0.0, want_dq=False, metrics=False)
+            clean["prediction"].copy_(pc.rows[:, 1])
+            clean["q"].copy_(pc.q)
+        clean_on_key = True
     elif not fuse_clean:
         eng.encoder_forward(pb, key=False, mode=L.MODE_INFER, patchesT=op, cls_tail=True)     # clean query
         eng.heads_forward(pb, key=False)
@@ -289,8 +314,13 @@ def compute_moco_contrastive(pl_module, batch):
             pl_module.pgd_attacker.attack_patches(pl_module, pb, None, clean_out=clean, clean_op=op)
             prediction_original = clean["prediction"]
         elif fuse_clean:
-            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, before_first_loss=join_key_stream, clean_out=clean, clean_op=op, key_stream=key_stream)
+            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, before_first_loss=join_key_stream, clean_out=clean, clean_op=op,
+                                                  key_stream=key_stream, key_event=k_ready)
             prediction_original = clean["prediction"]
+        elif clean_on_key:
+            pl_module.pgd_attacker.attack_patches(pl_module, pb, None, before_first_loss=join_key_stream, clean_op=op, key_stream=key_stream,
+                                                  key_event=k_ready)
+            main.wait_stream(key_stream)                    # the clean query's prediction / q (key stream) are read from here on
         else:
             pl_module.pgd_attacker.attack_patches(pl_module, pb, k, clean_op=op)        # compute_pgd (:319-323)
         check(lib.rmcl_delta_channel_norm(P(pb.delta), P(eng.zero_scalar(pb)), I64(pb.delta.shape[0]), 3,

@@ -55,15 +55,37 @@ class _InferFeatures(torch.autograd.Function):
         return None, None, None, None, None, None, None
 
 
+class _SlotClosure:
+    """The backward closure of one differentiable ``infer`` call together with its stash slot: the slot becomes free again when the
+    backward has run or when autograd drops the graph (the closure is garbage-collected with the autograd node)."""
+
+    def __init__(self, fn, busy: set, slot: int):
+        self.fn, self.busy, self.slot = fn, busy, slot
+
+    def __call__(self, *grads):
+        try:
+            self.fn(*grads)
+        finally:
+            self.busy.discard(self.slot)
+
+    def __del__(self):
+        self.busy.discard(self.slot)
+
+
 class ViLTransformerSS(nn.Module):
+    MAX_PENDING_INFER = 4
+
     def __init__(self, config, device="cuda:0", compute_dtype="bf16", exact=False, pgd_dtype=None):
         super().__init__()
         self.hparams = types.SimpleNamespace(config=config)
         self.config = config
         self.engine = Engine(config, device, compute_dtype, exact, pgd_dtype)
         eng = self.engine
+        if config.get("ln_fold") is False:
+            eng.fold = {}
         self.current_tasks = []
         self.logged = {}
+        self._infer_busy = set()               # stash slots of differentiable infer() calls whose backward is pending
         # query parameters = views into the flat fp32 arena; .grad = views into the gradient arena
         for name, off, shape in eng.specs:
             if name.startswith("itm_score") and config["loss_names"].get("itm", 0) <= 0:
@@ -154,13 +176,13 @@ class ViLTransformerSS(nn.Module):
             warnings.warn(f"load_path={path}: {len(res.missing_keys)} model tensors not in the checkpoint (kept: "
                           f"{', '.join(sorted(res.missing_keys)[:6])}{' ...' if len(res.missing_keys) > 6 else ''}); "
                           f"{len(unexpected)} checkpoint tensors unused ({', '.join(unexpected[:6])}{' ...' if len(unexpected) > 6 else ''})")
-        # LayerNorm fold (bf16 INFER / DATA passes feed bf16(x) of the RAW residual stream to the folded GEMM): exact enough while row
-        # means are small against the row spread (seed-initialised weights: tests/test_parity2_gpu.py); a trained checkpoint's stream
-        # can carry a large common-mode offset, where bf16(x) loses the spread (tests/test_kernels_gpu.py
-        # test_layernorm_fold_precision_on_offset_rows).  So: off after a checkpoint load unless config["ln_fold"] is True.
-        if self.hparams.config.get("ln_fold") is not True and self.engine.fold:
-            self.engine.fold = {}
-            self.load_report["ln_fold"] = "off after load_path (config['ln_fold'] = True keeps it)"
+        # LayerNorm fold after a checkpoint load.  Round 3 switched it off here: the folded GEMM ate bf16(x) of the RAW residual stream,
+        # whose rounding grows with the row's common-mode offset (a trained checkpoint's stream is not zero-mean).  Since round 4 the
+        # producers store bf16(x - c) with c = the row mean of the row's previous LayerNorm (LN(x) = LN(x - c) exactly; gemm.h
+        # ln_center), so the operand's rounding follows the row's spread whatever its offset (tests/test_kernels_gpu.py
+        # test_layernorm_fold_precision_on_offset_rows: fold within 2x of the separate LayerNorm at 10 and 50 sigma) and the fold STAYS
+        # ON.  config["ln_fold"] = False switches it off (separate LayerNorm kernels in every pass).
+        self.load_report["ln_fold"] = "on (shift-robust form)" if self.engine.fold else "off"
         return res
 
     # ---- initialisation (objectives.init_weights :1505-1516, ViT _init_weights :512-519) ----
@@ -277,7 +299,11 @@ class ViLTransformerSS(nn.Module):
         # the FULL stash and the returned features carry a backward into the gradient arena (the momentum pass never does: k_* get no
         # gradients, vilt_module.py:270-273)
         need_grad = (not key) and torch.is_grad_enabled()
-        pb = eng.bind_batch(text_ids, text_masks, batch["image"][0], tag="infer" if need_grad else "moco")
+        # every differentiable call whose backward is still pending keeps its OWN FULL stash (a second infer() of the same batch
+        # size must not overwrite the activations the first one's backward will read); the slot is returned by the backward, or
+        # when autograd drops the graph
+        slot = self._infer_slot_take() if need_grad else None
+        pb = eng.bind_batch(text_ids, text_masks, batch["image"][0], tag=f"infer{slot}" if need_grad else "moco")
         op = eng.make_operand(pb)
         eng.encoder_forward(pb, key=key, mode=L.MODE_FULL if need_grad else L.MODE_INFER, patchesT=op)
         eng.heads_forward(pb, key=key, want_q=False)
@@ -309,8 +335,11 @@ class ViLTransformerSS(nn.Module):
                 eng.encoder_backward(pb, L.MODE_FULL, op, dxn.view(pb.B * N, d.D), cls_only=False, dpatches=None)
                 self.after_backward()
 
-            self.step_sync.begin_step()
-            feats = _InferFeatures.apply(self.grad_anchor, backward, self.grad_prescale(), *feats)
+            # the step belongs to whoever opened it (forward() / training_step); a stand-alone infer() opens one only when no
+            # deferred backward of an earlier call is still outstanding - it never wipes their registrations
+            if self.step_sync.open <= 0:
+                self.step_sync.begin_step()
+            feats = _InferFeatures.apply(self.grad_anchor, _SlotClosure(backward, self._infer_busy, slot), self.grad_prescale(), *feats)
         ret = {
             "text_feats": feats[0],
             "image_feats": feats[1],
@@ -325,6 +354,14 @@ class ViLTransformerSS(nn.Module):
             ret["image_labels"] = None
             ret["text_labels"] = batch.get("text_labels")
         return ret
+
+    def _infer_slot_take(self) -> int:
+        for slot in range(self.MAX_PENDING_INFER):
+            if slot not in self._infer_busy:
+                self._infer_busy.add(slot)
+                return slot
+        raise RuntimeError(f"infer(): {self.MAX_PENDING_INFER} differentiable calls are still waiting for their backward (each keeps a full "
+                           "activation stash); back-propagate or drop their outputs first, or call infer() under torch.no_grad() for inference")
 
     def infer(self, batch, mask_text=False, mask_image=False, image_token_type_idx=1, image_embeds=None, image_masks=None):
         """vilt_module.py:275-351.  Differentiable like the reference's when autograd is on (``text_feats`` / ``image_feats`` /

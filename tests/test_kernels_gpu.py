@@ -672,38 +672,48 @@ def test_layernorm_fold_gemm_pair_matches_layernorm_then_linear(N2, gelu, cfg):
     assert rel_err(o2, z) < 1.2e-2          # bf16 operands and output (the separate LayerNorm -> bf16 -> GEMM path has the same class)
 
 
-@pytest.mark.parametrize("case", ["init_like", "outlier_channel", "offset_10", "offset_50"])
+@pytest.mark.parametrize("case", ["init_like", "outlier_channel", "offset_10", "offset_50", "offset_50_drift"])
 def test_layernorm_fold_precision_on_offset_rows(case):
-    """What the fold costs on residual streams that are NOT zero-mean (a trained checkpoint's can be: large common-mode offset,
-    outlier channels).  The folded GEMM eats bf16(x) of the RAW stream and subtracts mean * s afterwards, so the rounding of x
-    scales with |x|, not with the row's spread: error ~ 2^-9 * |mean| / std in units of the normalised activations, where the
-    separate path (fp32 LayerNorm, then bf16) has 2^-9.  Both paths against fp64 here; the fold must stay in the separate path's
-    error class on zero-mean rows and on outlier channels, and within the predicted bound on offset rows - which is why
-    ViLTransformerSS switches the fold off after a load_path checkpoint unless config["ln_fold"] is True."""
-    M, D, N2 = 1480, 768, 2304
+    """The fold on residual streams that are NOT zero-mean (a trained checkpoint's can be: large common-mode offset, outlier
+    channels).  Round 3's form fed bf16(x) of the RAW stream to the folded GEMM: its rounding scales with |x|, i.e. error
+    ~ 2^-9 * |mean| / std in units of the normalised activations (1.8e-2 at 10 sigma, 7.1e-2 at 50 sigma against 3.5e-3 for the
+    separate fp32 LayerNorm -> bf16 path).  Round 4: the producer stores bf16(x - c) and the partial sums of (x - c), c = the row
+    mean of the row's PREVIOUS LayerNorm (LN(x) = LN(x - c) exactly), which is what the encoder passes run.  Here c = the mean of the
+    producer's residual INPUT (`prev`) while the producer adds a branch of unit scale on top - in "offset_50_drift" a branch whose own
+    row means drift by up to +-2 sigma, so c is visibly off the true mean.  Both paths against fp64; the centred fold must stay within
+    2x of the separate path in EVERY case; the uncentred form is measured beside it and recorded."""
+    M, D, N2, K1 = 1480, 768, 2304, 128
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(M, D, generator=g)
+    prev = torch.randn(M, D, generator=g)
     if case == "outlier_channel":
-        x[:, 17] += 60.0                                             # one massive-activation channel
+        prev[:, 17] += 60.0                                          # one massive-activation channel
     elif case.startswith("offset"):
-        x += float(case.split("_")[1])
-    x = x.to(DEV)
-    zeroA = torch.zeros(M, 128, dtype=torch.bfloat16, device=DEV)
-    zeroW = torch.zeros(D, 128, dtype=torch.bfloat16, device=DEV)
+        prev += float(case.split("_")[1])
+    A = (torch.randn(M, K1, generator=g) * 0.3).to(torch.bfloat16)
+    W1 = (torch.randn(D, K1, generator=g) * 0.3).to(torch.bfloat16)   # branch = A W1^T: rows of standard deviation ~1
+    b1 = torch.zeros(D)
+    prev, A, W1, b1 = prev.to(DEV), A.to(DEV), W1.to(DEV), b1.to(DEV)
+    drift = ((torch.rand(M, 1, generator=g) * 4 - 2).to(DEV) if case.endswith("drift") else torch.zeros(M, 1, device=DEV))
+    prev_in = prev + drift                                           # what the producer adds its branch to; c is taken BEFORE the drift
+    center = prev.mean(1).contiguous()
     out, outb = torch.empty(M, D, device=DEV), torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
     nparts = 4 * (D // 192)
     part = torch.zeros(M, nparts, 2, device=DEV)
+    gamma, beta = 1.0 + rnd(D, seed=5, scale=0.1), rnd(D, seed=6, scale=0.1)
+    W2, b2 = rnd(N2, D, seed=7, scale=0.05), rnd(N2, seed=8, scale=0.1)
+    wf = (W2 * gamma).to(torch.bfloat16)
+    s_, c_ = wf.float().sum(1), W2 @ beta + b2
+    res = {}
     lib.rmcl_tune_set(0, 60)                                         # M = 8 x 185: the 192-row tile kernels by request
     try:
-        check(lib.rmcl_linear_rowstat(P(zeroA), P(zeroW), P(torch.zeros(D, device=DEV)), P(x), P(out), P(outb), P(part), M, D, 128, stream()))
-        assert torch.equal(out, x)
-        gamma, beta = 1.0 + rnd(D, seed=5, scale=0.1), rnd(D, seed=6, scale=0.1)
-        W2, b2 = rnd(N2, D, seed=7, scale=0.05), rnd(N2, seed=8, scale=0.1)
-        wf = (W2 * gamma).to(torch.bfloat16)
-        s_, c_ = wf.float().sum(1), W2 @ beta + b2
-        o_fold = torch.empty(M, N2, dtype=torch.bfloat16, device=DEV)
-        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
-        check(lib.rmcl_linear_lnfold(P(outb), P(wf), P(s_), P(c_), P(part), nparts, P(o_fold), None, M, N2, D, 0, F(1e-6), P(mean), P(rstd), stream()))
+        for name, cen in (("centred", center), ("uncentred", None)):
+            check(lib.rmcl_linear_rowstat_c(P(A), P(W1), P(b1), P(prev_in), P(cen), P(out), P(outb), P(part), M, D, K1, stream()))
+            x = out.clone()
+            o_fold = torch.empty(M, N2, dtype=torch.bfloat16, device=DEV)
+            mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+            check(lib.rmcl_linear_lnfold_c(P(outb), P(wf), P(s_), P(c_), P(part), nparts, P(cen), P(o_fold), None, M, N2, D, 0, F(1e-6),
+                                           P(mean), P(rstd), stream()))
+            res[name] = (o_fold, mean.clone(), rstd.clone())
         # separate path: fp32 LayerNorm -> bf16 -> bf16 GEMM + bias (what the FULL pass runs)
         ln = torch.empty(M, D, dtype=torch.bfloat16, device=DEV)
         m2, r2 = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
@@ -714,19 +724,21 @@ def test_layernorm_fold_precision_on_offset_rows(case):
     xd = x.double()
     mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
     ref = ((xd - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()) @ W2.double().t() + b2.double()
-    e_fold, e_sep = rel_err(o_fold, ref), rel_err(o_sep, ref)
+    e_fold, e_raw, e_sep = rel_err(res["centred"][0], ref), rel_err(res["uncentred"][0], ref), rel_err(o_sep, ref)
     ratio = float((mu.abs() / var.sqrt()).mean())
+    # the stashed statistics (the backward's LayerNorm reads them) are those of the TRUE rows, whatever the centre
+    np.testing.assert_allclose(res["centred"][1].cpu().numpy(), mu[:, 0].cpu().numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(res["centred"][2].cpu().numpy(), (1 / torch.sqrt(var + 1e-6))[:, 0].cpu().numpy(), rtol=2e-4)
     import json, os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "lnfold_precision.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     data = json.load(open(path)) if os.path.exists(path) else {}
-    data[case] = {"fold_rel_err": e_fold, "separate_rel_err": e_sep, "mean_over_std": ratio}
+    data[case] = {"fold_centred_rel_err": e_fold, "fold_uncentred_rel_err": e_raw, "separate_rel_err": e_sep, "mean_over_std": ratio}
     json.dump(data, open(path, "w"), indent=1)
     assert e_sep < 1.2e-2
-    if case in ("init_like", "outlier_channel"):
-        assert e_fold < max(1.2e-2, 2.0 * e_sep), (e_fold, e_sep)
-    else:
-        assert e_fold < 4e-3 * (1.0 + ratio) + 1.2e-2, (e_fold, e_sep, ratio)     # grows with |mean| / std: 2^-9-ish per unit
+    assert e_fold < max(6e-3, 2.0 * e_sep), (case, e_fold, e_sep, e_raw)       # the round-3 review's bar: <= 2x the separate path
+    if case in ("offset_10", "offset_50"):
+        assert e_raw > 2.0 * e_fold, (case, e_raw, e_fold)                     # (the uncentred form is what loses the spread)
 
 
 @pytest.mark.parametrize("wire", ["f32", "bf16"])

@@ -545,6 +545,102 @@ def test_bs64_step_on_the_benchmarked_kernels_against_the_cpu_oracle(objective):
     assert worst < 1.5e-2 and e["grad_cosine_min"] > 0.998, (e, cosines)
 
 
+def test_dropout_step_with_lanes_and_tail_against_the_oracle_with_the_same_masks(monkeypatch):
+    """The reference's real recipe (drop_rate = 0.1, config.py:57; dropout live in EVERY train-mode forward incl. the key encoder and
+    the PGD copies) at bs = 64 on the bf16 engine with the round-4 fast paths ON under dropout: half-batch lanes for
+    the PGD loop (each lane draws its own pass seeds), the clean query forward behind the key forward on the key stream, the cls-only
+    tail (compact rows draw the dense rows' masks).  torch's RNG stream cannot be matched, so the HIP masks of every pass of the step
+    are materialised (rmcl_dropout_mask_apply, seeds from Engine.pass_log) and handed to the CPU oracle as explicit masks; loss, keys,
+    queries, the perturbation and the parameter gradients must then agree like the dropout-free bs = 64 step does."""
+    import ctypes as C
+    from rmcl_amd._lib import lib, check, P, I64, F
+    from rmcl_amd.runtime import stream_ptr
+    monkeypatch.setenv("RMCL_LANES", "1")
+    B, Lr, Kq, K, pdrop = 64, 2, 2048, 2, 0.1
+    ocfg = O.default_config(num_layers=Lr, num_negative=Kq, per_gpu_batchsize=B, adv_steps_img=K, momentum=0.95, image_view=True, text_view=False)
+    cfg = task_moco(num_layers=Lr, num_negative=Kq, adv_steps_img=K, per_gpu_batchsize=B, drop_rate=pdrop, image_view=True, text_view=False,
+                    num_gpus=1, num_nodes=1, momentum=0.95)
+    m = ViLTransformerSS(cfg, device=DEV, compute_dtype="bf16")
+    p = O.init_params(ocfg, 21, k_seed=22)
+    m.load_state_dict({n: t.to(DEV) for n, t in p.items()}, strict=False)
+    m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
+    m.train()
+    m.engine.cfg["dense_images"] = True
+    batch = O.synthetic_batch(ocfg, B, 23, ragged_text=True)
+    eng = m.engine
+    eng.pass_log = []
+    m.zero_grad()
+    loss = m.training_step(dev_batch(batch), 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    log, eng.pass_log = eng.pass_log, None
+    # the step's passes: key (INFER), clean query (INFER), K x [lane 0, lane 1] (DATA), attacked view (FULL)
+    assert [e["key"] for e in log] == [True] + [False] * (2 + 2 * K)
+    assert [e["B"] for e in log] == [B, B] + [B // 2] * (2 * K) + [B] and [e["lane"] for e in log[2:2 + 2 * K]] == [0, 1] * K
+    assert all(e["tail"] and e["p"] == pdrop for e in log) and log[-1]["mode"] == L.MODE_FULL
+    assert len({e["seed"] for e in log}) == len(log)            # every pass (and every lane) its own draw
+    N, D = 185, 768
+
+    def masks(seed, Bp):
+        def one(shape, layer, site):
+            x = torch.ones(shape, device=DEV)
+            check(lib.rmcl_dropout_mask_apply(P(x), I64(x.numel()), C.c_uint32(seed), layer, site, F(pdrop), stream_ptr()))
+            return x.cpu()
+        d = {"text": one((Bp, 40, D), 0, 3), "image": one((Bp, 145, D), 0, 4)}
+        for l in range(Lr):
+            d[l] = {"proj": one((Bp, N, D), l, 0), "hidden": one((Bp, N, 4 * D), l, 1), "fc2": one((Bp, N, D), l, 2)}
+        return d
+
+    def cat(a, b):
+        return {k: (cat(a[k], b[k]) if isinstance(a[k], dict) else torch.cat([a[k], b[k]], 0)) for k in a}
+
+    drops = {"key": masks(log[0]["seed"], B), "clean": masks(log[1]["seed"], B), "img": masks(log[-1]["seed"], B),
+             "pgd": [cat(masks(log[2 + 2 * s]["seed"], B // 2), masks(log[3 + 2 * s]["seed"], B // 2)) for s in range(K)]}
+    po = {n: t.clone() for n, t in p.items()}
+    for n, t in po.items():
+        if not n.startswith("k_"):
+            t.requires_grad_(True)
+    queue = O.init_queue(ocfg, 0)
+    ref = O.compute_moco_contrastive(po, ocfg, batch, queue, 0, training=True, drops=drops)
+    ref["moco_loss"].backward()
+    pb = eng.bufs(B)
+    assert getattr(pb, "_lanes", None) is not None, "the lanes did not run"
+    e = {"loss": abs(float(loss) - float(ref["moco_loss"])), "loss_ref": float(ref["moco_loss"])}
+    e["k"] = float((pb.k.cpu() - ref["k"]).abs().max())
+    e["q"] = float((pb.q.cpu() - ref["q_img_attack"]).abs().max())
+    e["q_clean"] = float((m.engine.bufs(B, "clean_q").q.cpu() - ref["q_original"]).abs().max())
+    eps = ocfg["adv_max_norm_img"]
+    dimg = torch.empty(B, 3, 384, 384, device=DEV)
+    check(lib.rmcl_im2patch_f32(P(dimg), P(pb.delta), B, 3, 384, 384, 32, 1, stream_ptr()), "im2patch")
+    d, dr = dimg.cpu(), ref["delta"]
+    sat_ref = dr.abs() >= eps * (1 - 1e-6)
+    same = ((d.abs() >= eps * (1 - 1e-6)) == sat_ref) & (~sat_ref | (torch.sign(d) == torch.sign(dr)))
+    e["delta_same_saturation_frac"] = float(same.float().mean())
+    e["delta_mean_abs_diff_over_eps"] = float((d - dr).abs().mean()) / eps
+    params = dict(m.named_parameters())
+    worst, worst_name, n_cmp = 0.0, "", 0
+    for n, t in po.items():
+        if t.grad is None or n not in params or params[n].grad is None or float(t.grad.norm()) < 1e-9:
+            continue
+        rel = abs(float(params[n].grad.norm()) - float(t.grad.norm())) / float(t.grad.norm())
+        n_cmp += 1
+        if rel > worst:
+            worst, worst_name = rel, n
+    assert n_cmp > 30, n_cmp
+    e["grad_norm_rel_worst"], e["grad_norm_rel_worst_name"] = worst, worst_name
+    cos = []
+    for n in ("transformer.blocks.0.attn.qkv.weight", "transformer.blocks.1.mlp.fc1.weight", "transformer.blocks.1.mlp.fc2.weight",
+              "transformer.blocks.1.attn.proj.weight", "transformer.patch_embed.proj.weight"):
+        a, b = params[n].grad.detach().cpu().flatten().double(), po[n].grad.flatten().double()
+        cos.append(float((a * b).sum() / (a.norm() * b.norm())))
+    e["grad_cosine_min"] = min(cos)
+    record("bs64_dropout_lanes_tail_vs_oracle", **e)
+    # bounds like the dropout-free bs = 64 step (bf16 GEMM operands against an fp32 oracle)
+    assert e["loss"] < 0.03 and e["k"] < 6e-3 and e["q"] < 6e-3 and e["q_clean"] < 6e-3, e
+    assert e["delta_same_saturation_frac"] > 0.97 and e["delta_mean_abs_diff_over_eps"] < 0.04, e
+    assert worst < 1.5e-2 and e["grad_cosine_min"] > 0.998, e
+
+
 # -------------------------------------------------------------------------------------------------------------------
 # LayerNorm folded into the qkv / fc1 GEMMs (INFER / DATA passes at the 192-row-tile shapes, i.e. B = 64): against the
 # separate-LayerNorm path on the same weights, and both against the fp32 CPU oracle
@@ -629,7 +725,7 @@ def test_validation_step_matches_oracle_and_leaves_the_queue_alone():
 def test_load_path_checkpoint_protocol(tmp_path):
     """config["load_path"] (vilt_module.py:134-160): strict=False semantics - tensors absent from the file keep their values and
     are reported, a tensor of another shape is an ERROR like in the reference, the file is read with weights_only=True; and the
-    LayerNorm fold is off after a checkpoint load unless config["ln_fold"] is True."""
+    LayerNorm fold (shift-robust since round 4) stays ON after a checkpoint load unless config["ln_fold"] is False."""
     ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=4, adv_steps_img=1)
     m, p = make_module(ocfg, 7, "bf16", k_seed=8)
     assert m.engine.fold
@@ -648,8 +744,9 @@ def test_load_path_checkpoint_protocol(tmp_path):
     m2 = fresh(full)
     assert torch.equal(m2.engine.q32, m.engine.q32) and torch.equal(m2.engine.k32, m.engine.k32)
     assert not m2.load_report["missing"] and not m2.load_report["unexpected"]
-    assert not m2.engine.fold and "ln_fold" in m2.load_report          # trained weights: separate LayerNorm kernels
-    assert fresh(full, ln_fold=True).engine.fold
+    assert m2.engine.fold and m2.load_report["ln_fold"].startswith("on")    # the centred fold does not depend on zero-mean rows
+    m3 = fresh(full, ln_fold=False)
+    assert not m3.engine.fold and m3.load_report["ln_fold"] == "off"        # separate LayerNorm kernels by request
     with pytest.warns(UserWarning, match="not in the checkpoint"):
         m4 = fresh(partial)
     assert all(k.startswith("k_") for k in m4.load_report["missing"]) and len(m4.load_report["missing"]) > 10

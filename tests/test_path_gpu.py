@@ -621,22 +621,23 @@ def test_two_closure_step_reduces_once_on_one_rank():
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,Bn,layers", [("f32", 5, 2), ("bf16", 64, 3)])
-def test_cls_only_tail_equals_the_dense_last_block(dtype, Bn, layers):
+@pytest.mark.parametrize("dtype,Bn,layers,pdrop", [("f32", 5, 2, 0.0), ("bf16", 64, 3, 0.0), ("f32", 5, 2, 0.25), ("bf16", 64, 2, 0.1)])
+def test_cls_only_tail_equals_the_dense_last_block(dtype, Bn, layers, pdrop):
     """RMCL_MODE_CLS_TAIL (include/rmcl.h): with only the cls rows of the encoder output read, the last block's row-wise part
     runs on B rows - cls features, the PGD data gradient (DATA mode) and every parameter gradient (FULL mode, incl. the last
     layer's fc1 / fc2 / proj / LayerNorm tensors reduced over B rows) must equal the dense pass up to summation order
-    (f32) / up to the bf16 rounding of the dense last block (bf16: the tail keeps fp32 operands)."""
+    (f32) / up to the bf16 rounding of the dense last block (bf16: the tail keeps fp32 operands).  pdrop > 0 (round 4): the compact
+    rows draw the dropout masks of the dense rows they stand for, so with the pass seeds rewound the same holds under dropout."""
     from rmcl_amd import _lib as L
     ocfg = O.default_config(num_layers=layers, num_negative=1024, per_gpu_batchsize=Bn)
-    cfg = task_moco(num_layers=layers, num_negative=1024, per_gpu_batchsize=Bn, drop_rate=0.0, image_view=True, num_gpus=1, num_nodes=1)
+    cfg = task_moco(num_layers=layers, num_negative=1024, per_gpu_batchsize=Bn, drop_rate=pdrop, image_view=True, num_gpus=1, num_nodes=1)
     m = ViLTransformerSS(cfg, device=DEV, compute_dtype=dtype)
     p = O.init_params(ocfg, 3)
     m.load_state_dict({n: t.to(DEV) for n, t in p.items()}, strict=False)
     m.proj_queue.copy_(O.init_queue(ocfg, 0).to(DEV))
     batch = O.synthetic_batch(ocfg, Bn, 4, ragged_text=True)
     eng = m.engine
-    eng.dropout_on = False
+    eng.dropout_on = pdrop > 0
     pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], batch["image"][0])
     op = eng.make_operand(pb, out=pb.patchesT_full)
     k = torch.nn.functional.normalize(torch.randn(Bn, 128, generator=torch.Generator().manual_seed(1)), dim=1)
@@ -644,10 +645,11 @@ def test_cls_only_tail_equals_the_dense_last_block(dtype, Bn, layers):
     res = {}
     for tail in (False, True):
         out = {}
+        eng.pass_counter = 0                                     # the same pass seeds (= the same masks) for both forms
         for mode in (L.MODE_INFER, L.MODE_DATA, L.MODE_FULL):
             eng.zero_grads()
             eng.encoder_forward(pb, key=False, mode=mode, patchesT=op, cls_tail=tail)
-            assert pb.tail[mode] == tail
+            assert pb.tail[mode] == tail and pb.drop[mode][1] == pdrop
             eng.heads_forward(pb, key=False)
             out[("cls", mode)] = pb.cls.clone()
             if mode == L.MODE_INFER:
