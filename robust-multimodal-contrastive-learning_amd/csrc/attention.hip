@@ -668,11 +668,8 @@ long rmcl_attn_stat_elems(int B, int H, int N) { return (long)B * H * nkt_for(N)
 
 template <int NKT, int QW> static int launch_fwd_w(const bf16_t* qkv, const int* mask, bf16_t* out, float* lse, int B, int N, int H, hipStream_t s) {
   const size_t lds = (size_t)2 * NKT * 16 * 128 + NKT * 16 * 4;
-  static bool attr = false;                                    // (once per instantiation: the call costs the host tens of microseconds)
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((attn_fwd_kernel<NKT, QW>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static RmclLdsOnce once;                                     // (once per instantiation and device: the call costs the host ~170 us)
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>((attn_fwd_kernel<NKT, QW>)), (int)lds));
   RMCL_LAUNCH((attn_fwd_kernel<NKT, QW>), dim3(B * H), dim3(QW * 64), lds, s, qkv, mask, out, lse, N, H);
   RMCL_CHECK_LAUNCH();
   return 0;
@@ -691,11 +688,8 @@ template <int NKT, int TPW> static int launch_bwd_fused_t(const bf16_t* qkv, con
                                                           bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
   constexpr int NKP = NKT * 16, NSUB = (NKP + 63) / 64, NW = NKT / TPW;
   const size_t lds = (size_t)(3 + NSUB) * NKP * 128 + 2 * NKP * 4 + NW * 256;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NKT, TPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static RmclLdsOnce once;
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>(attn_bwd_fused_kernel<NKT, TPW>), (int)lds));
   const int P = B * H, grid = g_attn_bwd_persist > 0 ? min(P, g_attn_bwd_persist) : P;
   RMCL_LAUNCH((attn_bwd_fused_kernel<NKT, TPW>), dim3(grid), dim3(NW * 64), lds, s, qkv, mask, dout, out, lse, dqkv, N, H, P);
   RMCL_CHECK_LAUNCH();
@@ -712,12 +706,9 @@ template <int NKT> static int launch_bwd(const bf16_t* qkv, const int* mask, con
                                          bf16_t* dqkv, int B, int N, int H, hipStream_t s) {
   const size_t lds1 = (size_t)3 * NKT * 16 * 128 + NKT * 16 * 4, lds2 = (size_t)2 * NKT * 16 * 128 + 2 * NKT * 16 * 4;
   constexpr int NW = 4;                                      // (6 waves x 2 key tiles at NKT = 12 measured slower: 51.8 vs 44.0 us)
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((attn_bwd_dkv_kernel<NKT, NW>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    attr = true;
-  }
+  static RmclLdsOnce once1, once2;
+  RMCL_TRY(rmcl_set_max_lds(once1, reinterpret_cast<const void*>(attn_bwd_dq_kernel<NKT>), (int)lds1));
+  RMCL_TRY(rmcl_set_max_lds(once2, reinterpret_cast<const void*>((attn_bwd_dkv_kernel<NKT, NW>)), (int)lds2));
   RMCL_LAUNCH(attn_bwd_dq_kernel<NKT>, dim3(B * H), dim3(ATT_DQW * 64), lds1, s, qkv, mask, dout, lse, delta, dqkv, N, H);
   RMCL_CHECK_LAUNCH();
   RMCL_LAUNCH((attn_bwd_dkv_kernel<NKT, NW>), dim3(B * H), dim3(NW * 64), lds2, s, qkv, mask, dout, lse, delta, dqkv, N, H);

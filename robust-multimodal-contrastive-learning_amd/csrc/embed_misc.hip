@@ -55,8 +55,7 @@ __global__ __launch_bounds__(256) void text_embed_fwd_kernel(const long* __restr
                              (v[i].z - mu) * rs * ww.z + bb.z, (v[i].w - mu) * rs * ww.w + bb.w);
       if (dthresh) {                                          // BertEmbeddings.dropout, before the ViLT token type
         const uint32_t di = (uint32_t)((long)r * D + c);
-        o.x *= drop_scale(dseed, di, dthresh, dinv); o.y *= drop_scale(dseed, di + 1, dthresh, dinv);
-        o.z *= drop_scale(dseed, di + 2, dthresh, dinv); o.w *= drop_scale(dseed, di + 3, dthresh, dinv);
+        drop_scale4(dseed, di, dthresh, dinv, o.x, o.y, o.z, o.w);
       }
       *reinterpret_cast<float4*>(xr + c) = make_float4(o.x + tt.x, o.y + tt.y, o.z + tt.z, o.w + tt.w);
     }
@@ -193,8 +192,7 @@ __global__ __launch_bounds__(256) void image_assemble_fwd_kernel(const float* __
   float4 o = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
   if (dthresh) {                                              // pos_drop (vision_transformer.py:667), before the token type
     const uint32_t di = (uint32_t)(((long)b * (P + 1) + tok) * D + c);
-    o.x *= drop_scale(dseed, di, dthresh, dinv); o.y *= drop_scale(dseed, di + 1, dthresh, dinv);
-    o.z *= drop_scale(dseed, di + 2, dthresh, dinv); o.w *= drop_scale(dseed, di + 3, dthresh, dinv);
+    drop_scale4(dseed, di, dthresh, dinv, o.x, o.y, o.z, o.w);
   }
   *reinterpret_cast<float4*>(x + ((long)b * N + L + tok) * D + c) = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
 }

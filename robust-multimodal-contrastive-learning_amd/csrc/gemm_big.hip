@@ -210,12 +210,9 @@ bool rmcl_gemm_big_supported(const GemmArgs& g, int a_kc, int b_kc) {
 
 template <bool A_KC, bool B_KC>
 static int launch_big(const GemmArgs& g, int dt_out, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<A_KC, B_KC, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<A_KC, B_KC, bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE_BYTES);
-    attr = true;
-  }
+  static RmclLdsOnce once_f, once_b;
+  RMCL_TRY(rmcl_set_max_lds(once_f, reinterpret_cast<const void*>(gemm_big_kernel<A_KC, B_KC, float>), 2 * G_STAGE_BYTES));
+  RMCL_TRY(rmcl_set_max_lds(once_b, reinterpret_cast<const void*>(gemm_big_kernel<A_KC, B_KC, bf16_t>), 2 * G_STAGE_BYTES));
   const int tm = cdiv(g.M, GBM2), tn = g.N / GBN2;
   dim3 grid(tm * tn, g.splitk > 1 ? g.splitk : 1);
   if (dt_out == RMCL_F32) RMCL_LAUNCH((gemm_big_kernel<A_KC, B_KC, float>), grid, dim3(512), 2 * G_STAGE_BYTES, s, g, tm, tn);

@@ -212,12 +212,9 @@ int g_dp_stagger = 0;                 // rmcl_tune_set key 7: start delay of the
 
 template <int AUX, typename TO, int LNF>
 static int launch_dp3(const GemmArgs& g, hipStream_t s) {
-  static bool attr = false;
   constexpr int LDS = DP_LDS + 2048;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_dp_kernel<AUX, TO, LNF>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr = true;
-  }
+  static RmclLdsOnce once;
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>((gemm_dp_kernel<AUX, TO, LNF>)), LDS));
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;

@@ -197,8 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles
             }
             if (DROP && (epi & EPI_DROP_BWD)) {
               const uint32_t di = (uint32_t)((long)m * g.ld_aux + n);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, di + r, g.drop_thresh, g.drop_inv_keep);
+              drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
             }
             if (epi & EPI_DGELU) {
               const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + (long)m * g.ld_aux + n);
@@ -221,8 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fast_kernel(GemmArgs g, int tiles
               for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
             }
             if (DROP && (epi & EPI_DROPOUT)) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, (uint32_t)ci + r, g.drop_thresh, g.drop_inv_keep);
+              drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
             }
             if (epi & EPI_RESIDUAL) {
               const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(g.aux) + (long)m * g.ld_aux + n);
@@ -298,12 +296,9 @@ bool rmcl_gemm_fast_supported(const GemmArgs& g, int dt_in, int dt_out, int a_kc
 
 template <bool A_KC, bool B_KC, bool DROP>
 static int launch_fast(const GemmArgs& g, int dt_out, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, float, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, bf16_t, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    attr = true;
-  }
+  static RmclLdsOnce once_f, once_b;
+  RMCL_TRY(rmcl_set_max_lds(once_f, reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, float, DROP>), 2 * STAGE_BYTES));
+  RMCL_TRY(rmcl_set_max_lds(once_b, reinterpret_cast<const void*>(gemm_fast_kernel<A_KC, B_KC, bf16_t, DROP>), 2 * STAGE_BYTES));
   const int tm = cdiv(g.M, FBM), tn = g.N / FBN, nwg = tm * tn;
   const int total = nwg * (g.splitk > 1 ? g.splitk : 1);
   int per_cu = (g_gemm_cfg >= 1 && g_gemm_cfg <= 4) ? g_gemm_cfg : 2;

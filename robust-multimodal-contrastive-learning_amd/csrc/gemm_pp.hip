@@ -246,12 +246,9 @@ bool rmcl_gemm_pp_supported(const GemmArgs& g, int a_kc, int b_kc) {
 }
 
 int rmcl_launch_gemm_pp(const GemmArgs& g, int dt_out, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pp_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PP_BUF);
-    attr = true;
-  }
+  static RmclLdsOnce once_f, once_b;
+  RMCL_TRY(rmcl_set_max_lds(once_f, reinterpret_cast<const void*>(gemm_pp_kernel<float>), 2 * PP_BUF));
+  RMCL_TRY(rmcl_set_max_lds(once_b, reinterpret_cast<const void*>(gemm_pp_kernel<bf16_t>), 2 * PP_BUF));
   const int tm = cdiv(g.M, 256), tn = g.N / 256;
   if (dt_out == RMCL_F32) RMCL_LAUNCH((gemm_pp_kernel<float>), dim3(tm * tn), dim3(512), 2 * PP_BUF, s, g, tm, tn);
   else RMCL_LAUNCH((gemm_pp_kernel<bf16_t>), dim3(tm * tn), dim3(512), 2 * PP_BUF, s, g, tm, tn);

@@ -240,8 +240,7 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
                     g.alpha * acc[i][j][3] + bias[j].w};
       if (DROP && (epi & EPI_DROP_BWD)) {                    // mask of the forward's hidden dropout, indexed like the stash
         const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, di + r, g.drop_thresh, g.drop_inv_keep);
+        drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
       }
       if (AUX == ST_AUX_DGELU) {
         const uint2 u = pre[i][j];
@@ -255,8 +254,7 @@ __device__ __forceinline__ void st_epilogue(const f32x4 (&acc)[6][3], const Gemm
         for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
       }
       if (DROP && (epi & EPI_DROPOUT)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, (uint32_t)ci + r, g.drop_thresh, g.drop_inv_keep);
+        drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
       }
       if (AUX == ST_AUX_RES) { v[0] += res[i][j].x; v[1] += res[i][j].y; v[2] += res[i][j].z; v[3] += res[i][j].w; }
       if constexpr (sizeof(TO) == 4) {
@@ -526,11 +524,8 @@ __global__ __launch_bounds__(512) void gemm_dw_group_kernel(DwGroupArgs a) {
 }
 
 int rmcl_launch_dw_group(const DwGroupArgs& a, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-    attr = true;
-  }
+  static RmclLdsOnce once;
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>(gemm_dw_group_kernel), ST_LDS));
   const int ntiles = a.tile_base[4];
   RMCL_REQUIRE(a.K % 64 == 0 && a.K >= 256, "dw_group: tokens must be a multiple of 64 (>= 256)");
   RMCL_REQUIRE(ntiles >= a.nslots * ((a.D + 255) / 256), "dw_group: too few tiles for the LayerNorm finish");
@@ -580,12 +575,9 @@ static int st_num_cus() {
 
 template <bool A_KC, bool B_KC, int AUX, typename TO, bool DROP = false>
 static int launch_st3(const GemmArgs& g, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<A_KC, B_KC, AUX, TO, DROP, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<A_KC, B_KC, AUX, TO, DROP, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-    attr = true;
-  }
+  static RmclLdsOnce once2, once1;
+  RMCL_TRY(rmcl_set_max_lds(once2, reinterpret_cast<const void*>(gemm_st_kernel<A_KC, B_KC, AUX, TO, DROP, 2>), ST_LDS));
+  RMCL_TRY(rmcl_set_max_lds(once1, reinterpret_cast<const void*>(gemm_st_kernel<A_KC, B_KC, AUX, TO, DROP, 1>), ST_LDS));
   // a tile costs the same whether 185 or 192 of its rows are live, so the fewest row tiles win; they share M evenly
   const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = A_KC ? cdiv(g.M, tm) : ST_T;
   const int items = tm * tn * (g.splitk > 1 ? g.splitk : 1);
@@ -618,13 +610,9 @@ static int launch_st(const GemmArgs& g, int dt_out, hipStream_t s) {
 
 template <int AUX, typename TO, int LNF, bool DROP = false>
 static int launch_st_lnf(const GemmArgs& g, hipStream_t s) {
-  static bool attr = false;
   constexpr int LDS = ST_LDS + (LNF != 0 ? 2048 : 0);     // + the epilogue's row statistics (consumer) / row centres (producer)
-  if (!attr) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_st_kernel<true, true, AUX, TO, DROP, 2, LNF>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    RMCL_REQUIRE(e == hipSuccess, "gemm_st: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    attr = true;
-  }
+  static RmclLdsOnce once;
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>((gemm_st_kernel<true, true, AUX, TO, DROP, 2, LNF>)), LDS));
   const int tm = cdiv(g.M, ST_T), tn = g.N / ST_T, rows = cdiv(g.M, tm);
   const int grid = min(tm * tn, max(8, st_num_cus() - g_st_reserve_cus));
   RMCL_LAUNCH((gemm_st_kernel<true, true, AUX, TO, DROP, 2, LNF>), dim3(grid), dim3(512), LDS, s, g, tm, tn, rows, g_st_xflags);

@@ -179,8 +179,7 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
         }
         if (DROP && (epi & EPI_DROP_BWD)) {
           const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, di + r, g.drop_thresh, g.drop_inv_keep);
+          drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
         }
         if (AUX == ST_AUX_DGELU) {
           const uint2 u = pre[il][j];
@@ -194,8 +193,7 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
           for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
         }
         if (DROP && (epi & EPI_DROPOUT)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, (uint32_t)ci + r, g.drop_thresh, g.drop_inv_keep);
+          drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
         }
         if (AUX == ST_AUX_RES) { v[0] += res[il][j].x; v[1] += res[il][j].y; v[2] += res[il][j].z; v[3] += res[il][j].w; }
         if constexpr (LNF == 2) {

@@ -419,8 +419,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
             if constexpr (DROP) {
               if (epi & EPI_DROP_BWD) {                              // mask of the forward's hidden dropout, indexed like the stash
                 const uint32_t di = (uint32_t)((long)(mb + i * 16) * g.ld_aux + nb + j * 16);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, di + r, g.drop_thresh, g.drop_inv_keep);
+                drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
               }
             }
             const int e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);        // 8-byte unit (4 bf16) in the 384-column row
@@ -438,8 +437,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
             if constexpr (DROP) {
               if (epi & EPI_DROPOUT) {
                 const uint32_t ci = (uint32_t)((long)(mb + i * 16) * g.ldc + nb + j * 16);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= drop_scale(g.drop_seed, ci + r, g.drop_thresh, g.drop_inv_keep);
+                drop_scale4(g.drop_seed, ci, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
               }
             }
             uint2 pk;
@@ -546,12 +544,8 @@ double rmcl_gemm_sw_fill(const GemmArgs& g, int cus) {
 
 template <bool B_KC, int AUX, typename TO, bool DROP = false>
 static int launch_sw3(const GemmArgs& g, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_sw_kernel<B_KC, AUX, TO, 0, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS);
-    RMCL_REQUIRE(e == hipSuccess, "gemm_sw: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    attr = true;
-  }
+  static RmclLdsOnce once;
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>(gemm_sw_kernel<B_KC, AUX, TO, 0, DROP>), SW_LDS));
   const int tm = cdiv(g.M, 192), tn = g.N / 384, rows = cdiv(g.M, tm);
   RMCL_LAUNCH((gemm_sw_kernel<B_KC, AUX, TO, 0, DROP>), dim3(tm * tn), dim3(512), SW_LDS, s, g, tm, tn, rows);
   RMCL_CHECK_LAUNCH();
@@ -575,13 +569,9 @@ static int launch_sw(const GemmArgs& g, int dt_out, hipStream_t s) {
 
 template <bool DROP>
 static int launch_sw_lnf(const GemmArgs& g, hipStream_t s) {
-  static bool attr = false;
   constexpr int LDS = SW_LDS + 2048;
-  if (!attr) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1, DROP>)), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    RMCL_REQUIRE(e == hipSuccess, "gemm_sw: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    attr = true;
-  }
+  static RmclLdsOnce once;
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1, DROP>)), LDS));
   const int tm = cdiv(g.M, 192), tn = g.N / 384, rows = cdiv(g.M, tm);
   RMCL_LAUNCH((gemm_sw_kernel<true, SW_AUX_NONE, bf16_t, 1, DROP>), dim3(tm * tn), dim3(512), LDS, s, g, tm, tn, rows);
   RMCL_CHECK_LAUNCH();

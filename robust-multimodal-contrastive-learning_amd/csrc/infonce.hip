@@ -821,32 +821,23 @@ int rmcl_infonce(const float* q, const float* k, const float* queue, int B, int 
   float* part = reinterpret_cast<float*>(workspace);
   float* dq_part = part + (long)ns * Bpad * NPART;
   const size_t lds = (PD * ILD + 2 * RT * ILD + SLICE + RT) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static RmclLdsOnce once1;
+  RMCL_TRY(rmcl_set_max_lds(once1, reinterpret_cast<const void*>(infonce_partial_kernel), (int)lds));
   int nparts = ns;
   if (form != 0 && Kq % (SL2 * NS2) == 0 && g_infonce_fold >= 1) {
     // split-bf16 matrix cores (form 1: with the queue-distance metrics; 2: without - the PGD passes read dq only)
     nparts = (int)(Kq / (SL2 * NS2));
     const size_t lds3 = 4 * NCE3_IMG + (RT * 132 + 4 * SL2 + 3 * RT) * sizeof(float);
-    static bool attr3 = false;
-    if (!attr3) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-      attr3 = true;
-    }
+    static RmclLdsOnce once3a, once3b;
+    RMCL_TRY(rmcl_set_max_lds(once3a, reinterpret_cast<const void*>(infonce_partial3_kernel<true>), (int)lds3));
+    RMCL_TRY(rmcl_set_max_lds(once3b, reinterpret_cast<const void*>(infonce_partial3_kernel<false>), (int)lds3));
     if (form == 2) RMCL_LAUNCH(infonce_partial3_kernel<false>, dim3(nparts, Bpad / RT), dim3(256), lds3, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
     else RMCL_LAUNCH(infonce_partial3_kernel<true>, dim3(nparts, Bpad / RT), dim3(256), lds3, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
   } else if (Kq % (SL2 * NS2) == 0 && g_infonce_fold >= 1) {           // 256 columns per workgroup, four folded 64-column sub-slices
     nparts = (int)(Kq / (SL2 * NS2));
     const size_t lds2 = (2 * PD * ILD2 + RT * ILD2 + 4 * SL2 + 3 * RT) * sizeof(float);
-    static bool attr2 = false;
-    if (!attr2) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(infonce_partial2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      attr2 = true;
-    }
+    static RmclLdsOnce once2;
+    RMCL_TRY(rmcl_set_max_lds(once2, reinterpret_cast<const void*>(infonce_partial2_kernel), (int)lds2));
     RMCL_LAUNCH(infonce_partial2_kernel, dim3(nparts, Bpad / RT), dim3(256), lds2, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);
   } else {
     RMCL_LAUNCH(infonce_partial_kernel, dim3(ns, Bpad / RT), dim3(256), lds, s, q, queue, Kq, B, 1.0f / T, part, dq_part, Bpad);

@@ -67,11 +67,8 @@ int rmcl_ipot(const float* cost, const int* txt_valid, const int* img_valid, flo
               int iters, hipStream_t s) {
   const size_t lds = ((size_t)2 * Li * (Lt + 1) + 2 * Lt + 2 * Li) * sizeof(float);
   RMCL_REQUIRE(lds <= 150 * 1024, "ipot: problem too large for LDS");
-  static size_t attr = 0;
-  if (lds > attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(ipot_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = lds;
-  }
+  static RmclLdsOnce once;                                     // (raised again when a larger problem arrives)
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>(ipot_kernel), (int)lds));
   RMCL_LAUNCH(ipot_kernel, dim3(B), dim3(256), lds, s, cost, txt_valid, img_valid, T, Lt, Li, ld, beta, iters);
   RMCL_CHECK_LAUNCH();
   return 0;

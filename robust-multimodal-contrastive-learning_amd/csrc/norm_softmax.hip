@@ -164,8 +164,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
                          // already multiplied by the dropout mask of the branch output it flows into
           if (dthresh) {
             const uint32_t di = (uint32_t)((long)row * lddx + c);
-            o.x *= drop_scale(dseed, di, dthresh, dinv); o.y *= drop_scale(dseed, di + 1, dthresh, dinv);
-            o.z *= drop_scale(dseed, di + 2, dthresh, dinv); o.w *= drop_scale(dseed, di + 3, dthresh, dinv);
+            drop_scale4(dseed, di, dthresh, dinv, o.x, o.y, o.z, o.w);
           }
           if (copy_f32) {
             *reinterpret_cast<float4*>(reinterpret_cast<float*>(dx_copy) + (long)row * lddx + c) = o;

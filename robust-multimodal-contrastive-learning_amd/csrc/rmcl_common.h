@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <atomic>
 
 #define RMCL_F32 0
 #define RMCL_BF16 1
@@ -92,8 +93,23 @@ __host__ __device__ __forceinline__ uint32_t rmcl_rng_hash(uint32_t seed, uint32
 __host__ __device__ __forceinline__ uint32_t rmcl_site_seed(uint32_t seed, int layer, int site) {
   return rmcl_rng_hash(seed ^ 0xA511E9B3u, (uint32_t)(layer * 8 + site + 1));
 }
+// Round 4: ONE 32-bit hash serves the element PAIR (idx >> 1): element idx is kept iff its 16-bit half of the hash is >= thresh >> 16
+// (p resolved to 2^-16: 0.1 -> 0.09999).  The integer multiplies of the hash were what the dropout epilogues cost (fc1 +10 us per launch
+// for 144 elements per lane); epilogues that hold four consecutive elements call drop_scale4 - two hashes instead of four.
+__host__ __device__ __forceinline__ bool rmcl_drop_keep(uint32_t seed, uint32_t idx, uint32_t thresh) {
+  const uint32_t h = rmcl_rng_hash(seed, idx >> 1);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= (thresh >> 16);
+}
 __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
-  return rmcl_rng_hash(seed, idx) >= thresh ? inv_keep : 0.f;
+  return rmcl_drop_keep(seed, idx, thresh) ? inv_keep : 0.f;
+}
+// v[0..3] *= mask of elements idx .. idx + 3, idx a multiple of 4 (every caller: column offsets and leading dimensions are multiples of 4)
+__device__ __forceinline__ void drop_scale4(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep, float& v0, float& v1, float& v2, float& v3) {
+  const uint32_t h0 = rmcl_rng_hash(seed, idx >> 1), h1 = rmcl_rng_hash(seed, (idx >> 1) + 1u), t = thresh >> 16;
+  v0 *= (h0 & 0xffffu) >= t ? inv_keep : 0.f;
+  v1 *= (h0 >> 16) >= t ? inv_keep : 0.f;
+  v2 *= (h1 & 0xffffu) >= t ? inv_keep : 0.f;
+  v3 *= (h1 >> 16) >= t ? inv_keep : 0.f;
 }
 enum { DROP_SITE_PROJ = 0, DROP_SITE_HIDDEN = 1, DROP_SITE_FC2 = 2, DROP_SITE_TEXT = 3, DROP_SITE_IMAGE = 4 };
 
@@ -129,6 +145,25 @@ __device__ __forceinline__ s16x4 lds_read_tr16_asm(uint32_t a) {
 #ifdef __cplusplus
 extern "C" void rmcl_set_error(const char* msg);
 #endif
+
+// Dynamic-LDS limit of a kernel, set once per (launcher, device) - hipFuncSetAttribute costs the host ~170 us, so not per launch - and
+// again when a larger size is asked for.  Keyed by the current device (a second device in the process would otherwise launch with the
+// default limit), safe to race (the call is idempotent; ctypes releases the GIL around these entry points), and the HIP status is
+// surfaced through rmcl_last_error instead of being dropped.   Use:  static RmclLdsOnce once; RMCL_TRY(rmcl_set_max_lds(once, fn, bytes));
+struct RmclLdsOnce { std::atomic<int> bytes[16]; };
+static inline int rmcl_set_max_lds(RmclLdsOnce& o, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  dev &= 15;
+  if (o.bytes[dev].load(std::memory_order_acquire) >= bytes) return 0;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    rmcl_set_error(hipGetErrorString(e));
+    return (int)e;
+  }
+  o.bytes[dev].store(bytes, std::memory_order_release);
+  return 0;
+}
 
 // Launch with a clean error slate: hipGetLastError() is per-thread sticky state that other HIP users in
 // the process (torch) may have left set; clear it first so RMCL_CHECK_LAUNCH reports OUR launch only.
