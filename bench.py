@@ -257,6 +257,9 @@ def main():
                     help="N > 1: on = per-layer buckets reduced on the communication stream while the backward runs; off = one blocking "
                          "pass over the arena after the backward (the comparison run)")
     ap.add_argument("--no-feed-bench", action="store_true", help="skip the input-pipeline feed-rate measurement (tools/feed_bench.py, N = 1 only)")
+    ap.add_argument("--rehearse-short-batch", action="store_true",
+                    help="rehearsal runs only: one extra, untimed step on a HALF-size last batch after the timed steps - the gathered keys then "
+                         "number world * B / 2 != per_step_bs and the enqueue must be skipped on every rank (objectives.py:242-243)")
     ap.add_argument("--no-realistic", action="store_true",
                     help="skip the second, short leg of the default run: the same step in the reference's real recipe (drop_rate 0.1 after a "
                          "load_path-style checkpoint load, TRAIN.md:21 / config.py:57) -> `training_realistic` in the JSON line")
@@ -406,6 +409,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss.detach())
+    short = None
+    if args.rehearse_short_batch:
+        half = synthetic_batch(cfg, max(2, B // 2), 4321 + rank, device)
+        ptr0 = model.queue_ptr
+        lossh = model.training_step(half, args.warmup + args.steps)
+        lossh.backward()
+        opt.step()
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        short = {"batch": max(2, B // 2), "queue_ptr_before": ptr0, "queue_ptr_after": model.queue_ptr, "enqueue_skipped": model.queue_ptr == ptr0,
+                 "loss_finite": bool(torch.isfinite(lossh.detach()))}
     consistent, digest = None, None
     if use_dist and (share_gpu or backend != "nccl"):          # rehearsal: the ranks' parameters and queues must be bit-identical
         eng = model.engine
@@ -467,6 +481,10 @@ def main():
                                    f"M={B * 185}; {kern_n} replayed launches, avg {kern_ms / max(kern_n, 1):.4f} ms"},
             "step_mfma_frac": round(step_flops / (elapsed / args.steps) / PEAK_BF16, 4),
         }
+        if short is not None:
+            out["short_last_batch"] = short
+        out["queue_ptr"] = model.queue_ptr
+        out["lanes"] = "on" if getattr(model.engine.bufs(B), "_lanes", None) is not None else "off"
         if per_rank is not None:
             # what an N > 1 run needs to explain itself: per-rank step time, the stream time the step stood still waiting for
             # communication, and what was sent (max over ranks of the waits: the slowest rank sets the step)

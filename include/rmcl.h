@@ -109,6 +109,23 @@ int rmcl_linear_rowstat_c(const void* A, const void* W, const float* bias, const
 int rmcl_linear_lnfold_c(const void* xb, const void* wf, const float* s, const float* c, const float* part, int nparts, const float* center,
                          void* out, void* preact, int M, int N, int K, int gelu, float eps, float* mean, float* rstd, void* stream);
 
+/* PROTOTYPE (round 4): up to four bf16 GEMMs out[M,N_i] = epi(A_i[M,K_i] W_i[N_i,K_i]^T ...) of one activation row tile chained inside
+ * ONE launch - the row-wise part of an encoder layer between two attention calls (reference op chain: vision_transformer.py:279-285
+ * Mlp, :330-331 proj, :371-375 Block).  Stage i + 1 reads what stage i wrote (its A / residual pointers name stage i's outputs); groups
+ * of four workgroups on one XCD carry a 191-row tile through all stages and synchronise through `tickets` (4 * 64 + 1 uint32, zeroed
+ * once by the caller; `epoch` = 1, 2, 3, ... counts the launches made with that buffer).  epi: EPI_BIAS [| EPI_GELU | EPI_SAVE_PREACT]
+ * (bf16 output), EPI_BIAS | EPI_RESIDUAL | EPI_ROWSTAT (fp32 output + bf16 copy `out2` + row partials `part`), EPI_LNFOLD (as
+ * rmcl_linear_lnfold_c).  flags bit 0: placement-independent hand-off (agent-scope release per stage); 0 relies on the four blocks
+ * b, b + 8, b + 16, b + 24 sharing an XCD - check with `xcc` ([grid] int32, optional).  stamps: optional [4][4] int64 wall-clock stamps of
+ * block `stamp_wg`.  Measured against separate launches in tools/chain_bench.py; not used by the encoder passes.   */
+typedef struct rmcl_chain_stage {
+  const void* A; const void* W; const float* bias; const float* residual; void* out; void* out2; float* part; const float* center;
+  const float* ln_s; const float* ln_c; float* mean; float* rstd;
+  int N, K, epi, nparts; float ln_eps;
+} rmcl_chain_stage;
+int rmcl_gemm_chain(const rmcl_chain_stage* stages, int n, int M, uint32_t* tickets, uint32_t epoch, int flags, int32_t* xcc, int64_t* stamps,
+                    int stamp_wg, void* stream);
+
 /* Element offsets into a parameter arena.  Names follow the reference state dict. */
 typedef struct rmcl_layout {
   int64_t word, pos, btype, eln_w, eln_b;      /* text_embeddings.{word,position,token_type}_embeddings, LayerNorm */

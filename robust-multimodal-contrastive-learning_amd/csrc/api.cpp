@@ -412,6 +412,21 @@ int rmcl_gemm(const void* A, const void* B, void* C, void* C2, const float* bias
   g.alpha = alpha; g.epi = epi; g.splitk = splitk < 1 ? 1 : splitk; g.nb1 = 1; g.nb2 = 1;
   return rmcl_launch_gemm(g, dt_in, dt_out, a_kc, b_kc, exact, (hipStream_t)stream);
 }
+int rmcl_gemm_chain(const rmcl_chain_stage* st, int n, int M, uint32_t* tickets, uint32_t epoch, int flags, int32_t* xcc, int64_t* stamps,
+                    int stamp_wg, void* stream) {
+  RMCL_REQUIRE(st && n >= 1 && n <= 4 && tickets && epoch >= 1, "gemm_chain: bad argument");
+  ChainArgs a{};
+  a.n = n; a.ticket = tickets; a.target = 4u * epoch; a.flags = flags; a.xcc = xcc; a.stamps = (long long*)stamps; a.stamp_wg = stamp_wg;
+  for (int i = 0; i < n; ++i) {
+    const rmcl_chain_stage& q = st[i];
+    GemmArgs g = ga(q.A, q.W, q.out, M, q.N, q.K, q.K, q.K, q.N);
+    g.epi = q.epi; g.bias = q.bias; g.aux = q.residual; g.ld_aux = q.N; g.C2 = q.out2;
+    g.ln_part = q.part; g.ln_nparts = (q.epi & EPI_ROWSTAT) ? 4 * (q.N / 192) : q.nparts; g.ln_center = q.center;
+    g.ln_s = q.ln_s; g.ln_c = q.ln_c; g.ln_cols = q.K; g.ln_eps = q.ln_eps; g.ln_mean = q.mean; g.ln_rstd = q.rstd;
+    a.g[i] = g;
+  }
+  return rmcl_launch_gemm_chain(a, (hipStream_t)stream);
+}
 int rmcl_gemm_route(int M, int N, int K, int epi, int dt_out, int a_kc, int b_kc) {
   GemmArgs g{};
   g.M = M; g.N = N; g.K = K; g.epi = epi; g.splitk = 1; g.nb1 = 1; g.nb2 = 1; g.alpha = 1.0f;

@@ -545,8 +545,10 @@ bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
   }
   if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_ACCUM | EPI_DROPOUT | EPI_DROP_BWD | EPI_LNFOLD | EPI_ROWSTAT)) return false;
   if ((g.epi & EPI_RESIDUAL) && (g.epi & EPI_DGELU)) return false;
-  if (g.epi & EPI_LNFOLD) {                                       // consumer: plain bias-less bf16 GEMM on [rows][K] x [cols][K]
-    if (!b_kc || (g.epi & ~EPI_LNFOLD) || !g.ln_s || !g.ln_c || !g.ln_part || g.ln_nparts % 2 || g.ln_nparts <= 0 || g.ln_cols <= 0) return false;
+  if (g.epi & EPI_LNFOLD) {                                       // consumer: bias-less bf16 GEMM on [rows][K] x [cols][K] (+ GELU / pre-activation stash)
+    if (!b_kc || (g.epi & ~(EPI_LNFOLD | EPI_GELU | EPI_SAVE_PREACT)) || ((g.epi & EPI_SAVE_PREACT) && !g.C2) || !g.ln_s || !g.ln_c || !g.ln_part ||
+        g.ln_nparts % 2 || g.ln_nparts <= 0 || g.ln_cols <= 0)
+      return false;
   }
   if (g.epi & EPI_ROWSTAT) {                                      // producer: fp32 residual-stream output of [rows][K] x [cols][K]
     if (!b_kc || (g.epi & ~(EPI_ROWSTAT | EPI_BIAS | EPI_RESIDUAL | EPI_DROPOUT)) || !(g.epi & EPI_RESIDUAL) || !g.ln_part || !g.C2 || g.ln_nparts != 4 * (g.N / ST_T))
@@ -654,4 +656,189 @@ int rmcl_launch_gemm_st_slab(const GemmArgs& g0, float* slab, float* out, hipStr
   g.epi = 0;
   RMCL_TRY(rmcl_launch_gemm_st(g, RMCL_F32, 0, 0, s));
   return rmcl_slab_reduce(slab, out, (long)g.M * g.N, sk, s);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PROTOTYPE (round 4, review item 2): a ROW TILE CARRIED THROUGH SEVERAL GEMMs INSIDE ONE LAUNCH ("chain").
+//
+// Everything between two attention calls of an encoder layer is row-wise: proj (+residual) -> fc1 (+GELU) -> fc2 (+residual) -> the next
+// layer's qkv.  As separate launches every GEMM fills the chip by itself: all workgroups run prologue, k-loop and (HBM-bound) epilogue in
+// lockstep, a kernel boundary (drain + ~1.5 us + the write-back of everything the launch left dirty in the L2s) sits between them, and a
+// consumer finds its operand in the Infinity Cache at best.  Here a GROUP of four workgroups on ONE XCD (blocks b, b + 8, b + 16, b + 24:
+// the dispatcher deals blocks round-robin over the 8 XCDs) owns a row tile (191 rows: one sample) for the whole chain; member c computes
+// column tiles c, c + 4, ... of every stage, and the stages are ordered by a global-memory ticket per (stage, row tile): a member adds 1
+// after its stores have drained, the next stage starts when the ticket shows all four.  Groups need nothing from each other, so they drift
+// apart (one group's store-heavy epilogue under another group's k-loop), the producer -> consumer panel (<= 1.2 MB per group) is read out
+// of the XCD's own L2, and there is no grid-wide drain between the GEMMs.
+//
+// Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility).  Producer: plain stores -> every storing wave's vmcnt(0) -> workgroup
+// barrier -> ONE lane: [flags & 1: agent-scope release = write-back of the XCD L2's dirty lines, placement-independent] -> relaxed
+// agent-scope add to the ticket.  Consumer: ONE lane polls the ticket (relaxed, L1-bypassing), then ONE agent-scope acquire (invalidates
+// this CU's L1: the operand arrives by LDS-DMA through it) -> vmcnt(0) -> workgroup barrier.  With flags & 1 == 0 the group relies on its
+// four members sharing an XCD (their L2 is then the coherence point: no write-back); the launcher's caller verifies the placement
+// (`xcc` output) - a wrong guess would be WRONG, not slow, which is why this form stays behind the prototype entry point.
+// Spins are bounded (give-up word ticket[CHAIN_ERR]); tickets only grow (target = 4 x launch epoch), so nothing is re-zeroed per launch.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st_tile_setup_rc(STTile& T, const GemmArgs& g, int tr, int tc, int rows_per_tile, int wave, int lane) {
+  asm volatile("" : "+v"(lane));
+  T.kt0 = 0;
+  T.nk = g.K / 64;
+  T.zoff = 0;
+  T.m0 = tr * rows_per_tile;
+  T.n0 = tc * ST_T;
+  T.m_end = min(g.M, T.m0 + rows_per_tile);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int row = (wave * 3 + q) * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ (row & 7);
+    T.oa[q] = (uint32_t)min(T.m0 + row, g.M - 1) * (uint32_t)g.lda + chunk * 8;
+    T.ob[q] = (uint32_t)min(T.n0 + row, g.N - 1) * (uint32_t)g.ldb + chunk * 8;
+  }
+}
+
+__global__ __launch_bounds__(512) void gemm_chain_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int b = blockIdx.x;
+  const int grp = (b & 7) + 8 * (b >> 5), mem = (b >> 3) & 3;   // blocks b, b + 8, b + 16, b + 24 (one XCD): one row tile
+  if (a.xcc && t == 0) {                                         // placement record: which XCD this block really runs on
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    a.xcc[b] = (int)(id & 0xf);
+  }
+  if (grp >= a.tiles_m) return;
+  const bool stamp = a.stamps != nullptr && b == a.stamp_wg && t == 0;
+  STCtx c;
+  c.wave = wave;
+  c.kstep_a = 64;
+  c.kstep_b = 64;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int sw = ((4 * s + (lane >> 4)) ^ (lane & 7)) * 16;
+    c.aoff[s] = (wm * 96 + (lane & 15)) * 128 + sw;
+    c.boff[s] = (wn * 48 + (lane & 15)) * 128 + sw;
+  }
+  float* rowstat = reinterpret_cast<float*>(smem + ST_LDS);
+  for (int st = 0; st < a.n; ++st) {
+    const GemmArgs& g = a.g[st];
+    if (stamp) a.stamps[st * 4 + 0] = wall_clock64();
+    if (st > 0) {
+      if (t == 0) {
+        const unsigned* tk = a.ticket + (st - 1) * CHAIN_TICKETS + grp;
+        int spins = 0;
+        while (__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.target) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 22)) {                            // (~1 s: a member never arrived - give up loudly instead of hanging the queue)
+            __hip_atomic_fetch_or(a.ticket + CHAIN_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+    }
+    if (stamp) a.stamps[st * 4 + 1] = wall_clock64();
+    c.A = reinterpret_cast<const bf16_t*>(g.A);
+    c.B = reinterpret_cast<const bf16_t*>(g.B);
+    const int tn = g.N / ST_T;
+    int tc = mem;
+    STTile cur, nxt;
+    st_tile_setup_rc(cur, g, grp, tc, a.rows_per_tile, wave, lane);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { c.oa[q] = cur.oa[q]; c.ob[q] = cur.ob[q]; }
+    st_stage_op(c.A, c.oa, 0, smem, wave);
+    st_stage_op(c.B, c.ob, 0, smem + ST_OP_BYTES, wave);
+    st_stage_op(c.A, c.oa, c.kstep_a, smem + ST_STAGE, wave);
+    st_stage_op(c.B, c.ob, c.kstep_b, smem + ST_STAGE + ST_OP_BYTES, wave);
+    st_wait_vm<6>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 1) __builtin_amdgcn_s_barrier();                 // skew: group 1 runs one barrier behind group 0
+    __builtin_amdgcn_sched_barrier(0);
+    int sc = 0, sn = 2;
+    for (;;) {
+      const int ntc = tc + 4;
+      const bool more = ntc < tn;
+      f32x4 acc[6][3];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int nk = cur.nk;
+      for (int it = 0; it + 2 < nk; ++it) {
+        st_tile<0, true, true, 2>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, it + 2);
+        sc = sc == 2 ? 0 : sc + 1;
+        sn = sn == 2 ? 0 : sn + 1;
+      }
+      if (more) {                                              // the k-tile stream continues with this member's next column tile
+        st_tile_setup_rc(nxt, g, grp, ntc, a.rows_per_tile, wave, lane);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { c.oa[q] = nxt.oa[q]; c.ob[q] = nxt.ob[q]; }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          st_tile<0, true, true, 2>(acc, c, smem + sc * ST_STAGE, smem + sn * ST_STAGE, e);
+          sc = sc == 2 ? 0 : sc + 1;
+          sn = sn == 2 ? 0 : sn + 1;
+        }
+      } else {
+        st_tile<1, true, true, 2>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+        sc = sc == 2 ? 0 : sc + 1;
+        st_tile<2, true, true, 2>(acc, c, smem + sc * ST_STAGE, nullptr, 0);
+      }
+      const int s_free = more ? (sc == 0 ? 2 : sc - 1) : sc;
+      char* scratch = smem + s_free * ST_STAGE + wm * (ST_STAGE / 2);
+      if (g.epi & EPI_ROWSTAT) st_epilogue_lds<ST_AUX_RES, float, false, 2>(acc, g, cur, wm, wn, lane, wave, scratch, rowstat);
+      else if (g.epi & EPI_LNFOLD) st_epilogue_lds<ST_AUX_NONE, bf16_t, false, 1>(acc, g, cur, wm, wn, lane, wave, scratch, rowstat);
+      else st_epilogue_lds<ST_AUX_NONE, bf16_t, false, 0>(acc, g, cur, wm, wn, lane, wave, scratch, rowstat);
+      if (!more) break;
+      cur = nxt;
+      tc = ntc;
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                 // un-skew: both wave groups have passed the same number of barriers
+    if (stamp) a.stamps[st * 4 + 2] = wall_clock64();
+    // publish this member's part of the stage
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave: its stores have been written
+    __syncthreads();
+    if (t == 0) {
+      if ((a.flags & 1) && st + 1 < a.n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // placement-independent form: write back the XCD L2's dirty lines
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      // EVERY stage's ticket advances by one per member and launch (also the last stage's and those of unused stages below), so that
+      // `target = 4 x launches` holds for every stage whatever the stage count of the earlier launches was
+      __hip_atomic_fetch_add(a.ticket + st * CHAIN_TICKETS + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (stamp) a.stamps[st * 4 + 3] = wall_clock64();
+  }
+  if (t == 0)
+    for (int st = a.n; st < 4; ++st) __hip_atomic_fetch_add(a.ticket + st * CHAIN_TICKETS + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int rmcl_launch_gemm_chain(const ChainArgs& a0, hipStream_t s) {
+  ChainArgs a = a0;
+  RMCL_REQUIRE(a.n >= 1 && a.n <= 4 && a.ticket, "gemm_chain: 1..4 stages and a ticket buffer");
+  const int M = a.g[0].M;
+  a.tiles_m = cdiv(M, ST_T);
+  a.rows_per_tile = cdiv(M, a.tiles_m);
+  RMCL_REQUIRE(a.tiles_m <= CHAIN_TICKETS, "gemm_chain: at most 64 row tiles (M <= 12288)");
+  for (int i = 0; i < a.n; ++i) {
+    const GemmArgs& g = a.g[i];
+    RMCL_REQUIRE(g.A && g.B && g.C && g.M == M && g.N % ST_T == 0 && g.K % 64 == 0 && g.K >= 128, "gemm_chain: bad stage shape");
+    RMCL_REQUIRE((long)g.M * g.lda < (1L << 31) && (long)g.N * g.ldb < (1L << 31), "gemm_chain: operand too large for 32-bit offsets");
+    RMCL_REQUIRE(!(g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_ROWSTAT | EPI_LNFOLD)), "gemm_chain: unsupported epilogue");
+    RMCL_REQUIRE(!(g.epi & EPI_ROWSTAT) || ((g.epi & EPI_RESIDUAL) && g.aux && g.C2 && g.ln_part && g.ln_nparts == 4 * (g.N / ST_T)), "gemm_chain: producer stage");
+    RMCL_REQUIRE(!(g.epi & EPI_RESIDUAL) || (g.epi & EPI_ROWSTAT), "gemm_chain: a residual stage is a row-statistics producer (fp32 output)");
+    RMCL_REQUIRE(!(g.epi & EPI_LNFOLD) || (g.ln_s && g.ln_c && g.ln_part && g.ln_nparts > 0 && g.ln_nparts % 2 == 0 && g.ln_cols > 0), "gemm_chain: folded stage");
+  }
+  constexpr int LDS = ST_LDS + 2048;
+  static RmclLdsOnce once;
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>(gemm_chain_kernel), LDS));
+  const int grid = 32 * cdiv(a.tiles_m, 8);
+  RMCL_LAUNCH(gemm_chain_kernel, dim3(grid), dim3(512), LDS, s, a);
+  RMCL_CHECK_LAUNCH();
+  return 0;
 }

@@ -51,6 +51,20 @@ struct DwGroupArgs {
   long g_gamma[3], g_beta[3];
 };
 int rmcl_launch_dw_group(const DwGroupArgs& a, hipStream_t s);
+// gemm_st.hip, prototype: up to four GEMMs of one row tile chained inside one launch (tickets: [4][64] counters + the give-up word)
+enum { CHAIN_TICKETS = 64, CHAIN_ERR = 4 * 64 };
+struct ChainArgs {
+  GemmArgs g[4];
+  int n;                       // stages
+  int tiles_m, rows_per_tile;  // (set by the launcher)
+  unsigned* ticket;            // [4][CHAIN_TICKETS] + 1 words, zeroed ONCE by the caller; they only grow
+  unsigned target;             // 4 x (launches made with this ticket buffer, this one included)
+  int flags;                   // bit 0: agent-scope release before every ticket (placement-independent hand-off)
+  int* xcc;                    // optional [grid]: XCC_ID of every block (placement check)
+  long long* stamps;           // optional [4][4]: wall clock (100 MHz) of block `stamp_wg` per stage: entered, ticket seen, body done, published
+  int stamp_wg;
+};
+int rmcl_launch_gemm_chain(const ChainArgs& a, hipStream_t s);
 int rmcl_softmax_fwd(const float* S, long lds, const int* mask, void* P, long ldp, int dt, int Z, int N, int H, hipStream_t s);
 int rmcl_softmax_bwd(const void* P, long ldp, const float* dP, long lddp, void* dS, long ldds, int dt, int Z, int N,
                      float scale, hipStream_t s);

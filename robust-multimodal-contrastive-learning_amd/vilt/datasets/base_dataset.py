@@ -229,51 +229,69 @@ class BaseDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.index_mapper)
 
-    def get_raw_image(self, index, image_key="image"):
+    # ---- sample protocol (the dict keys and the order of the RNG draws are the reference's, base_dataset.py:86-165: collate and the
+    #      golden fixture tests/golden/dataset.npz depend on both; the code below is this build's own) ----
+    def _decode(self, row: int, column: str):
         from PIL import Image
-        row, _ = self.index_mapper[index]
-        return Image.open(io.BytesIO(self.table[image_key][row].as_py())).convert("RGB")
+        return Image.open(io.BytesIO(self.table[column][row].as_py())).convert("RGB")
+
+    def _views(self, row: int, column: str) -> list:
+        """every configured transform applied to ONE decode of the image in `row`"""
+        picture = self._decode(row, column)
+        return [view(picture) for view in self.transforms]
+
+    def _any_entry(self) -> int:
+        """a uniformly drawn entry of the index (false samples, replacement of a broken record): ONE random.randint per call"""
+        return random.randint(0, len(self.index_mapper) - 1)
+
+    def _tokenise(self, caption: str, pad: bool):
+        extra = {"padding": "max_length"} if pad else {}
+        return self.tokenizer(caption, truncation=True, max_length=self.max_text_len, return_special_tokens_mask=True, **extra)
+
+    def get_raw_image(self, index, image_key="image"):
+        return self._decode(self.index_mapper[index][0], image_key)
 
     def get_image(self, index, image_key="image"):
-        image = self.get_raw_image(index, image_key=image_key)
-        return {"image": [tr(image) for tr in self.transforms], "img_index": self.index_mapper[index][0],
-                "cap_index": self.index_mapper[index][1], "raw_index": index}
+        row, cap = self.index_mapper[index]
+        return {"image": self._views(row, image_key), "img_index": row, "cap_index": cap, "raw_index": index}
 
     def get_false_image(self, rep, image_key="image"):
-        random_index = random.randint(0, len(self.index_mapper) - 1)
-        image = self.get_raw_image(random_index, image_key=image_key)
-        return {f"false_image_{rep}": [tr(image) for tr in self.transforms]}
+        row, _ = self.index_mapper[self._any_entry()]
+        return {f"false_image_{rep}": self._views(row, image_key)}
 
     def get_text(self, raw_index):
-        index, caption_index = self.index_mapper[raw_index]
-        text = self.all_texts[index][caption_index]
-        encoding = self.tokenizer(text, padding="max_length", truncation=True, max_length=self.max_text_len, return_special_tokens_mask=True)
-        return {"text": (text, encoding), "img_index": index, "cap_index": caption_index, "raw_index": raw_index}
+        row, cap = self.index_mapper[raw_index]
+        caption = self.all_texts[row][cap]
+        return {"text": (caption, self._tokenise(caption, pad=True)), "img_index": row, "cap_index": cap, "raw_index": raw_index}
 
     def get_false_text(self, rep):
-        random_index = random.randint(0, len(self.index_mapper) - 1)
-        index, caption_index = self.index_mapper[random_index]
-        text = self.all_texts[index][caption_index]
-        encoding = self.tokenizer(text, truncation=True, max_length=self.max_text_len, return_special_tokens_mask=True)
-        return {f"false_text_{rep}": (text, encoding)}
+        row, cap = self.index_mapper[self._any_entry()]
+        caption = self.all_texts[row][cap]
+        return {f"false_text_{rep}": (caption, self._tokenise(caption, pad=False))}        # (the reference pads only the true caption)
+
+    def _assemble(self, index) -> dict:
+        sample = self.get_image(index)
+        if not self.image_only:
+            text = self.get_text(index)
+            sample["replica"] = text["cap_index"] > 0             # a second / third caption of an image already seen
+            sample.update(text)
+        for rep in range(self.draw_false_image):                   # draws in this order: all false images, then all false texts
+            sample.update(self.get_false_image(rep))
+        for rep in range(self.draw_false_text):
+            sample.update(self.get_false_text(rep))
+        return sample
 
     def get_suite(self, index):
+        """The sample at `index`; a record that cannot be read or decoded is reported and replaced by a randomly drawn one, again and
+        again until one loads (the reference's behaviour, base_dataset.py:147-164 - a corrupt shard must not end an epoch)."""
+        entry = index
         while True:
             try:
-                ret = dict()
-                ret.update(self.get_image(index))
-                if not self.image_only:
-                    txt = self.get_text(index)
-                    ret.update({"replica": True if txt["cap_index"] > 0 else False})
-                    ret.update(txt)
-                for i in range(self.draw_false_image):
-                    ret.update(self.get_false_image(i))
-                for i in range(self.draw_false_text):
-                    ret.update(self.get_false_text(i))
-                return ret
-            except Exception as e:                               # (a corrupt record: take another sample, base_dataset.py:161-164)
-                print(f"Error while read file idx {index} in {self.names[0]} -> {e}")
-                index = random.randint(0, len(self.index_mapper) - 1)
+                return self._assemble(entry)
+            except Exception as err:
+                shard = self.names[0] if self.names else "<no shard>"
+                print(f"[BaseDataset] entry {entry} of {shard} could not be loaded ({type(err).__name__}: {err}); drawing another sample")
+                entry = self._any_entry()
 
     def __getitem__(self, index):
         return self.get_suite(index)

@@ -174,6 +174,23 @@ def test_two_rank_gather_enqueue_allreduce():
         assert torch.equal(a["queue"], b["queue"]) and torch.equal(a["keys"], b["keys"])
 
 
+def test_eight_rank_gather_enqueue_and_gradient_paths():
+    """World size 8 - the size the product targets (BASELINE configs[3]) - on the CPU over gloo: rank-major gather of 8 x B keys, three
+    enqueues of 8 x B-key blocks leaving all eight queues bit-identical, the skip rule, bucketed mean, the per-layer buckets; then the
+    step reducer (1, 2, 3 closures, accumulation, bf16 buckets) and the one-hop reduce-scatter / all-gather with its padded slices."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(8, os.path.join(d, "init"), d), nprocs=8, join=True)
+        outs = [torch.load(os.path.join(d, f"r{r}.pt")) for r in range(8)]
+        assert all(torch.equal(outs[0]["queue"], o["queue"]) and torch.equal(outs[0]["keys"], o["keys"]) for o in outs[1:])
+        assert outs[0]["keys"].shape[0] == 8 * 4
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_step_sync, args=(8, os.path.join(d, "init"), d), nprocs=8, join=True)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_direct, args=(8, os.path.join(d, "init"), d), nprocs=8, join=True)
+        outs = [torch.load(os.path.join(d, f"d{r}.pt")) for r in range(8)]
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
 def test_queue_advance_rejects_wraparound():
     from rmcl_amd.vilt.modules import dist_utils
     with pytest.raises(RuntimeError):

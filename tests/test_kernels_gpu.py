@@ -741,6 +741,79 @@ def test_layernorm_fold_precision_on_offset_rows(case):
         assert e_raw > 2.0 * e_fold, (case, e_raw, e_fold)                     # (the uncentred form is what loses the spread)
 
 
+@pytest.mark.parametrize("release", [1, 0])
+def test_chained_row_tile_gemms_equal_the_separate_launches(release):
+    """gemm_chain_kernel (round-4 prototype, include/rmcl.h rmcl_gemm_chain): proj producer (+residual, centred row partials) -> fc1
+    (LayerNorm-folded, GELU, pre-activation stash) -> fc2 producer -> qkv (LayerNorm-folded) of one row tile inside ONE launch, groups of
+    four workgroups synchronised by global-memory tickets, against the same four GEMMs as separate launches: the same tiles, k order and
+    epilogue code, so every output must be BIT-identical - with the agent-scope release per stage and with the same-XCD hand-off (the blocks'
+    XCC ids are read back: the four blocks of every group must share an XCD for that form to be valid), over two consecutive launches on
+    one ticket buffer, the second with three stages (tickets of unused stages advance too)."""
+    import ctypes as C
+
+    class Stage(C.Structure):
+        _fields_ = [(n, C.c_void_p) for n in ("A", "W", "bias", "residual", "out", "out2", "part", "center", "ln_s", "ln_c", "mean", "rstd")] + \
+                   [("N", C.c_int), ("K", C.c_int), ("epi", C.c_int), ("nparts", C.c_int), ("ln_eps", C.c_float)]
+
+    M, D, Hm = 11840, 768, 3072
+    att = rnd(M, D, seed=1).to(torch.bfloat16)
+    x = rnd(M, D, seed=2, scale=2.0) + 3.0
+    Wo, bo = rnd(D, D, seed=3, scale=0.05).to(torch.bfloat16), rnd(D, seed=4)
+    W2, b2 = rnd(D, Hm, seed=5, scale=0.03).to(torch.bfloat16), rnd(D, seed=6)
+    g1, be1, W1, b1 = 1.0 + rnd(D, seed=7, scale=0.1), rnd(D, seed=8, scale=0.1), rnd(Hm, D, seed=9, scale=0.05), rnd(Hm, seed=10, scale=0.1)
+    g2, be2, Wq, bq = 1.0 + rnd(D, seed=11, scale=0.1), rnd(D, seed=12, scale=0.1), rnd(3 * D, D, seed=13, scale=0.05), rnd(3 * D, seed=14, scale=0.1)
+    wf1, wfq = (W1 * g1).to(torch.bfloat16), (Wq * g2).to(torch.bfloat16)
+    s1, c1, sq, cq = wf1.float().sum(1), W1 @ be1 + b1, wfq.float().sum(1), Wq @ be2 + bq
+    cen = x.mean(1).contiguous()                                    # centre of the first producer: the row mean of its residual input
+    E = L
+    nparts = 4 * (D // 192)
+
+    def buffers():
+        f32 = lambda *s: torch.zeros(*s, device=DEV)
+        b16 = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=DEV)
+        return dict(y=f32(M, D), yb=b16(M, D), p1=f32(M, nparts, 2), h=b16(M, Hm), u=b16(M, Hm), m2=f32(M), r2=f32(M), xo=f32(M, D), xob=b16(M, D),
+                    p2=f32(M, nparts, 2), qkv=b16(M, 3 * D), m1=f32(M), r1=f32(M))
+
+    def separate(o, n):
+        check(lib.rmcl_linear_rowstat_c(P(att), P(Wo), P(bo), P(x), P(cen), P(o["y"]), P(o["yb"]), P(o["p1"]), M, D, D, stream()))
+        check(lib.rmcl_linear_lnfold_c(P(o["yb"]), P(wf1), P(s1), P(c1), P(o["p1"]), nparts, P(cen), P(o["h"]), P(o["u"]), M, Hm, D, 1, F(1e-6),
+                                       P(o["m2"]), P(o["r2"]), stream()))
+        check(lib.rmcl_linear_rowstat_c(P(o["h"]), P(W2), P(b2), P(o["y"]), P(o["m2"]), P(o["xo"]), P(o["xob"]), P(o["p2"]), M, D, Hm, stream()))
+        if n == 4:
+            check(lib.rmcl_linear_lnfold_c(P(o["xob"]), P(wfq), P(sq), P(cq), P(o["p2"]), nparts, P(o["m2"]), P(o["qkv"]), None, M, 3 * D, D, 0, F(1e-6),
+                                           P(o["m1"]), P(o["r1"]), stream()))
+
+    def stages(o):
+        q = lambda t: None if t is None else t.data_ptr()
+        return (Stage * 4)(
+            Stage(q(att), q(Wo), q(bo), q(x), q(o["y"]), q(o["yb"]), q(o["p1"]), q(cen), None, None, None, None, D, D, E.EPI_BIAS | E.EPI_RESIDUAL | E.EPI_ROWSTAT, 0, 1e-6),
+            Stage(q(o["yb"]), q(wf1), None, None, q(o["h"]), q(o["u"]), q(o["p1"]), q(cen), q(s1), q(c1), q(o["m2"]), q(o["r2"]), Hm, D,
+                  E.EPI_LNFOLD | E.EPI_GELU | E.EPI_SAVE_PREACT, nparts, 1e-6),
+            Stage(q(o["h"]), q(W2), q(b2), q(o["y"]), q(o["xo"]), q(o["xob"]), q(o["p2"]), q(o["m2"]), None, None, None, None, D, Hm,
+                  E.EPI_BIAS | E.EPI_RESIDUAL | E.EPI_ROWSTAT, 0, 1e-6),
+            Stage(q(o["xob"]), q(wfq), None, None, q(o["qkv"]), None, q(o["p2"]), q(o["m2"]), q(sq), q(cq), q(o["m1"]), q(o["r1"]), 3 * D, D, E.EPI_LNFOLD, nparts, 1e-6))
+
+    tickets = torch.zeros(4 * 64 + 1, dtype=torch.int32, device=DEV)
+    xcc = torch.full((256,), -1, dtype=torch.int32, device=DEV)
+    lib.rmcl_tune_set(0, 60)                                         # the separate launches on the same 192 x 192 tiles
+    try:
+        for epoch, n in ((1, 4), (2, 3), (3, 4)):
+            ref, got = buffers(), buffers()
+            separate(ref, n)
+            check(lib.rmcl_gemm_chain(stages(got), n, M, P(tickets), C.c_uint32(epoch), release, P(xcc), None, 0, stream()), "gemm_chain")
+            torch.cuda.synchronize()
+            assert int(tickets[4 * 64]) == 0, "a workgroup gave up waiting for a ticket"
+            assert tickets[:4 * 64].view(4, 64)[:, :62].eq(4 * epoch).all(), tickets[:4 * 64].view(4, 64)[:, :8]
+            for k in ref:
+                if n == 3 and k in ("qkv", "m1", "r1"):
+                    continue
+                assert torch.equal(ref[k], got[k]), (epoch, n, k)
+    finally:
+        lib.rmcl_tune_set(0, -1)
+    ids = xcc.cpu().view(8, 4, 8)                                   # [row-tile block of 8 groups][member][xcd slot]
+    assert bool((ids == ids[:, :1, :]).all()), "blocks b, b + 8, b + 16, b + 24 did not share an XCD: the same-XCD hand-off form is invalid on this box"
+
+
 @pytest.mark.parametrize("wire", ["f32", "bf16"])
 def test_shard_sum_is_the_rank_order_sum(wire):
     """rmcl_shard_sum (owner side of the direct reduce-scatter): W pieces of one slice -> fp32 sum in rank order, and the

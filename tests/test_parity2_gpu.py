@@ -867,3 +867,30 @@ def test_two_rank_step_at_bs64_grouped_weight_gradients_under_the_overlapped_red
     for x, y in zip(a, b):                                   # sum, abs-sum of the parameter arena, sum of the queue
         assert abs(x - y) <= 2e-6 * max(abs(x), abs(y), 1.0), (a, b)
     record("two_rank_bs64", digest_overlap=a, digest_blocking=b, comm_exposed_ms=recs[0]["multi_gpu"]["comm_exposed_ms"])
+
+
+@pytest.mark.gpu
+def test_four_rank_step_with_forced_lanes_and_a_short_last_batch():
+    """The N > 1 interplay the product runs with - half-batch lanes (forced on at bs = 8: RMCL_LANES=1), the key all-gather joined on the
+    weight-gradient stream, per-layer gradient buckets gated on the backward's events - rehearsed with FOUR ranks sharing the one GPU
+    over gloo (the pool's process guard admits six GPU processes per box, this one included, so eight ranks cannot share the card; the
+    eight-rank bookkeeping - 64-key blocks, bucket arithmetic, the direct reduce - runs on the CPU in tests/test_dist_cpu.py): two steps,
+    then a half-size last batch whose gathered keys do not add up to per_step_bs, so the enqueue must be skipped on every rank
+    (objectives.py:242-243).  Ranks bit-identical; queue advanced by exactly two 32-key blocks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RMCL_BENCH_SHARE_GPU="1", RMCL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", RMCL_LANES="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                          "--master-port", "29741", os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "0",
+                          "--batch", "8", "--no-cpu-baseline", "--rehearse-short-batch"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["world_size"] == 4 and rec["config"]["global_batch"] == 32 and rec["ranks_bit_identical"] is True
+    assert rec["lanes"] == "on", rec
+    assert rec["queue_ptr"] == 2 * 32, rec                         # two enqueues of world * B = 32 keys; the short batch added none
+    sb = rec["short_last_batch"]
+    assert sb["enqueue_skipped"] is True and sb["queue_ptr_before"] == sb["queue_ptr_after"] == 64 and sb["loss_finite"], sb
+    assert rec["multi_gpu"]["grad_sync"]["mode"].startswith("overlapped")
