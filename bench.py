@@ -289,8 +289,10 @@ def main():
             pass
         for w in sorted({4, max(4, min(cores, 32))}):
             try:
+                # decode_uint8: workers only decode (MinMaxResize + normalisation on the device, round 4); pixelbert_uint8: workers also resize
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "feed_bench.py"), "--json", "--workers", str(w), "--images", "128",
-                                    "--seconds", "5", "--paths", "pixelbert_uint8"], capture_output=True, text=True, timeout=90)
+                                    "--seconds", "4", "--paths", "decode_uint8,pixelbert_uint8"] + (["--split"] if w == 4 else []),
+                                   capture_output=True, text=True, timeout=120)
                 feed[f"workers_{w}"] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
             except Exception as e:                              # the step measurement does not depend on it
                 feed[f"workers_{w}"] = {"error": repr(e)[:200]}
@@ -399,6 +401,21 @@ def main():
         torch.cuda.synchronize()
         ingest = {"pairs_per_s": round(10 * B / (e0.elapsed_time(e1) * 1e-3), 1), "bytes_over_pcie_per_batch": int(u8.data.numel()),
                   "what": "pinned uint8 batch -> device -> rmcl_image_u8_to_patches (normalise + zero-pad + patch rows), stream time per batch"}
+        # the decode-only path: decoded 640 x 480 / 480 x 640 bytes -> device -> MinMaxResize (PIL's integer bicubic, two passes) -> the above
+        from rmcl_amd.vilt.datasets import RawUint8Batch
+        rsz = torch.tensor([(480, 640) if i % 3 else (640, 480) for i in range(B)], dtype=torch.int32)
+        raw = RawUint8Batch(torch.randint(0, 256, (B, 640, 640, 3), dtype=torch.uint8).pin_memory(), rsz, 384, 640)
+        for _ in range(2):
+            eng.bind_batch(batch["text_ids"], batch["text_masks"], raw, tag="feed_raw")
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            eng.bind_batch(batch["text_ids"], batch["text_masks"], raw, tag="feed_raw")
+        e1.record()
+        torch.cuda.synchronize()
+        ingest["decode_only"] = {"pairs_per_s": round(10 * B / (e0.elapsed_time(e1) * 1e-3), 1), "bytes_over_pcie_per_batch": int(raw.data.numel()),
+                                 "what": "pinned decoded bytes at original size -> device -> rmcl_image_resize_u8 (MinMaxResize, PIL's integer "
+                                         "bicubic) -> rmcl_image_u8_to_patches, stream time per batch (incl. the host's table packing)"}
     per_rank = None
     if use_dist:
         mine = {"step_ms": 1e3 * elapsed / args.steps, "comm_exposed_ms": comm.get("comm_exposed", 0.0),

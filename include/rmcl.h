@@ -197,6 +197,17 @@ int rmcl_im2patch_sel(float* img, float* patches, const int32_t* sel, const int3
 int rmcl_image_u8_to_patches(const uint8_t* img, const int32_t* sizes, const int32_t* sel, const int32_t* counts, int sel_ld, int B, int n,
                              int Hmax, int Wmax, int patch_size, const float* lut, float* patches, void* stream);
 
+/* MinMaxResize on the device (reference: vilt/transforms/utils.py:5-26 -> PIL Image.resize(size, BICUBIC), called from
+ * transforms/pixelbert.py:9-18 in every loader worker).  src: decoded bytes of a batch, uint8 [B, Hs, Ws, 3], every sample in its top-left
+ * corner, src_sizes [B,2] = (h, w) per sample; dst: uint8 [B, Hd, Wd, 3] with dst_sizes [B,2] (multiples of 32: min_max_resize_size), zero
+ * outside a sample - exactly the batch rmcl_image_u8_to_patches takes; tmp: uint8 [B, Hs, Wd, 3] scratch.  The integer tables are PIL's
+ * (Pillow src/libImaging/Resample.c precompute_coeffs / normalize_coeffs_8bpc, built by vilt/transforms/resample.py): hbounds [B, Wd, 2] =
+ * (first source column, taps) and hk [B, Wd, ksh] = 22-bit fixed-point weights per output column, vbounds [B, Hd, 2] / vk [B, Hd, ksv]
+ * per output row.  Integer arithmetic throughout: the output bytes equal PIL's (tests/test_feed_gpu.py).                                  */
+int rmcl_image_resize_u8(const uint8_t* src, const int32_t* src_sizes, int B, int Hs, int Ws, const int32_t* dst_sizes, int Hd, int Wd,
+                         const int32_t* hbounds, const int32_t* hk, int ksh, const int32_t* vbounds, const int32_t* vk, int ksv, uint8_t* tmp,
+                         uint8_t* dst, void* stream);
+
 /* Owner-side sum of a direct reduce-scatter over the xGMI links (replaces the reduction DDP's all-reduce performs inside the
  * collective, run.py:96): pieces [n_pieces][piece_elems] of `dtype` (F32 or BF16), this rank's slice as every rank sent
  * it; out32 = their sum (fp32 accumulation, rank order); out_wire (may be NULL) = the sum rounded to `dtype`, the operand

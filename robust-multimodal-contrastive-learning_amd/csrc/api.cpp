@@ -306,6 +306,12 @@ int rmcl_image_u8_to_patches(const uint8_t* img, const int32_t* sizes, const int
   RMCL_REQUIRE((sel == nullptr) == (counts == nullptr), "image_u8_to_patches: sel and counts go together");
   return rmcl_u8_to_patches(img, sizes, sel, counts, sel_ld, B, n, Hmax, Wmax, lut, patches, (hipStream_t)stream);
 }
+int rmcl_image_resize_u8(const uint8_t* src, const int32_t* src_sizes, int B, int Hs, int Ws, const int32_t* dst_sizes, int Hd, int Wd,
+                         const int32_t* hbounds, const int32_t* hk, int ksh, const int32_t* vbounds, const int32_t* vk, int ksv, uint8_t* tmp,
+                         uint8_t* dst, void* stream) {
+  RMCL_REQUIRE(src && src_sizes && dst_sizes && hbounds && hk && vbounds && vk && tmp && dst, "image_resize_u8: NULL argument");
+  return rmcl_resize_u8(src, src_sizes, B, Hs, Ws, dst_sizes, Hd, Wd, hbounds, hk, ksh, vbounds, vk, ksv, tmp, dst, (hipStream_t)stream);
+}
 int rmcl_shard_sum(const void* pieces, int dtype, int n_pieces, int64_t piece_elems, float* out32, void* out_wire, void* stream) {
   RMCL_REQUIRE(pieces && (out32 || out_wire), "shard_sum: NULL argument");
   RMCL_REQUIRE(dtype == RMCL_F32 || dtype == RMCL_BF16, "shard_sum: dtype");

@@ -442,6 +442,8 @@ class Engine:
         """image: the float batch [B,3,H,W] of ``collate`` - or a ``Uint8Batch`` (``collate_uint8``): the decoded bytes, normalised,
         zero-padded and cut into patch rows by ONE kernel, the patch selection derived from the known extents (no selection
         launch, no device-to-host read of the counts)."""
+        if hasattr(image, "tables") and hasattr(image, "data"):                # RawUint8Batch: decoded bytes, MinMaxResize still owed
+            image = self.resize_raw(image)
         if hasattr(image, "sizes") and hasattr(image, "data"):
             return self._bind_uint8(text_ids, text_mask, image, tag, select)
         img = image.to(self.device, torch.float32).contiguous()
@@ -458,6 +460,24 @@ class Engine:
             check(lib.rmcl_im2patch_sel(P(img), P(pb.patches32), P(geom.sel), P(geom.counts), geom.sel.shape[1], B, geom.n, 3, Hh, Ww,
                                         ps, 0, stream_ptr()), "im2patch_sel")
         return pb
+
+    def resize_raw(self, raw):
+        """``RawUint8Batch`` (decoded bytes at their original sizes) -> ``Uint8Batch`` on the device: MinMaxResize with PIL's integer
+        arithmetic in two kernel passes (include/rmcl.h rmcl_image_resize_u8); the tables come from the host (cached per size pair)."""
+        from .vilt.datasets.base_dataset import Uint8Batch
+        tgt, hb, hk, vb, vk = raw.tables()
+        src = raw.data.to(self.device, non_blocking=True).contiguous()
+        B, Hs, Ws, _ = src.shape
+        Hd, Wd = vb.shape[1], hb.shape[1]                               # (the batch extent the tables were packed for)
+        dev = lambda t: t.to(self.device, non_blocking=True)
+        ssz, dsz, hb_d, hk_d, vb_d, vk_d = dev(raw.sizes.contiguous()), dev(tgt.contiguous()), dev(hb), dev(hk), dev(vb), dev(vk)
+        tmp = torch.empty(B, Hs, Wd, 3, dtype=torch.uint8, device=self.device)
+        dst = torch.empty(B, Hd, Wd, 3, dtype=torch.uint8, device=self.device)
+        check(lib.rmcl_image_resize_u8(P(src), P(ssz), B, Hs, Ws, P(dsz), Hd, Wd, P(hb_d), P(hk_d), hk.shape[2], P(vb_d), P(vk_d), vk.shape[2],
+                                       P(tmp), P(dst), stream_ptr()), "image_resize_u8")
+        out = Uint8Batch(dst, tgt)
+        out.keep_alive = (src, ssz, dsz, hb_d, hk_d, vb_d, vk_d, tmp)          # until the stream has consumed them
+        return out
 
     def _bind_uint8(self, text_ids, text_mask, u8, tag, select) -> PassBuffers:
         from .vilt.datasets.base_dataset import select_from_sizes

@@ -1,1 +1,2 @@
-from .base_dataset import collate, collate_uint8, Uint8Batch, BaseDataset, select_from_sizes, write_arrow_table  # noqa: F401
+from .base_dataset import (collate, collate_uint8, collate_raw_uint8, Uint8Batch, RawUint8Batch, RawView, BaseDataset, select_from_sizes,  # noqa: F401
+                           write_arrow_table)

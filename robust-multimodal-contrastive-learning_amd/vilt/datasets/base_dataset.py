@@ -115,6 +115,92 @@ class Uint8Batch:
         return x * inside[:, None].to(x.dtype)
 
 
+class RawView:
+    """What the "decode_uint8" transform returns: the DECODED image as uint8 [h, w, 3] at its original size plus the MinMaxResize it still
+    owes (shorter, longer) - a loader worker then only decodes; the bicubic resize runs on the device (``RawUint8Batch``)."""
+    __slots__ = ("pixels", "shorter", "longer")
+
+    def __init__(self, pixels: torch.Tensor, shorter: int, longer: int):
+        self.pixels, self.shorter, self.longer = pixels, int(shorter), int(longer)
+
+    @property
+    def shape(self):
+        return tuple(self.pixels.shape)
+
+
+class RawUint8Batch:
+    """One view of a collated batch as decoded, NOT yet resized bytes: ``data`` uint8 [B, Hs, Ws, 3] (every sample in its top-left
+    corner), ``sizes`` int32 [B, 2] = (h, w) as decoded, and the MinMaxResize parameters.  ``Engine.bind_batch`` resizes it on the device
+    with PIL's own integer arithmetic (include/rmcl.h rmcl_image_resize_u8; vilt/transforms/resample.py builds the tables) into the
+    ``Uint8Batch`` the byte path continues from; ``resized_on_host()`` does the same with PIL (callers outside the training step, tests)."""
+
+    def __init__(self, data: torch.Tensor, sizes: torch.Tensor, shorter: int, longer: int, extent=None):
+        """extent: (Hd, Wd) of the RESIZED batch when it must be larger than this view's own maximum - ``collate`` pads every image key
+        of a batch to ONE extent (base_dataset.py:192-206), e.g. "image" and "false_image_0" of the ITM objective."""
+        assert data.dtype == torch.uint8 and data.dim() == 4 and data.shape[3] == 3, tuple(data.shape)
+        self.data, self.sizes, self.shorter, self.longer = data, torch.as_tensor(sizes).to(torch.int32).cpu(), int(shorter), int(longer)
+        self.extent = None if extent is None else (int(extent[0]), int(extent[1]))
+        B, Hs, Ws, _ = data.shape
+        sz = self.sizes
+        if tuple(sz.shape) != (B, 2) or bool((sz < 1).any()) or bool((sz[:, 0] > Hs).any()) or bool((sz[:, 1] > Ws).any()):
+            raise ValueError(f"RawUint8Batch.sizes must be [B, 2] = (h, w) with 1 <= h <= {Hs}, 1 <= w <= {Ws} (got {sz.tolist()})")
+
+    @property
+    def target_sizes(self) -> torch.Tensor:
+        """[B, 2] = (h, w) after MinMaxResize (vilt/transforms/utils.py:5-26: multiples of 32)"""
+        from ..transforms import min_max_resize_size
+        out = [tuple(reversed(min_max_resize_size(int(w), int(h), self.shorter, self.longer))) for h, w in self.sizes.tolist()]
+        if any(h < 32 or w < 32 for h, w in out):
+            raise ValueError(f"MinMaxResize({self.shorter}, {self.longer}) leaves a side below one 32-pixel patch for sizes {self.sizes.tolist()}")
+        return torch.tensor(out, dtype=torch.int32)
+
+    def out_hw(self, tgt: torch.Tensor = None):
+        """(Hd, Wd) of the resized batch: this view's largest target, or the batch-wide extent given at construction"""
+        t = self.target_sizes if tgt is None else tgt
+        hd, wd = int(t[:, 0].max()), int(t[:, 1].max())
+        return (hd, wd) if self.extent is None else (max(hd, self.extent[0]), max(wd, self.extent[1]))
+
+    @property
+    def shape(self):
+        return (self.data.shape[0], 3) + self.out_hw()
+
+    def to(self, device, non_blocking: bool = True) -> "RawUint8Batch":
+        return RawUint8Batch(self.data.to(device, non_blocking=non_blocking), self.sizes, self.shorter, self.longer, self.extent)
+
+    def pin_memory(self) -> "RawUint8Batch":
+        return RawUint8Batch(self.data.pin_memory(), self.sizes, self.shorter, self.longer, self.extent)
+
+    def tables(self):
+        """PIL's integer resampling tables of every sample, packed for the device: (target sizes [B,2], hbounds [B,Wd,2], hk [B,Wd,ksh],
+        vbounds [B,Hd,2], vk [B,Hd,ksv]) int32 CPU tensors.  Per-axis tables are cached per (in, out) size pair."""
+        from ..transforms.resample import bicubic_coeffs_8bpc
+        tgt = self.target_sizes
+        B = tgt.shape[0]
+        Hd, Wd = self.out_hw(tgt)
+        per = [(bicubic_coeffs_8bpc(int(w), int(tw)), bicubic_coeffs_8bpc(int(h), int(th)))
+               for (h, w), (th, tw) in zip(self.sizes.tolist(), tgt.tolist())]
+        ksh, ksv = max(hk.shape[1] for (_, hk), _ in per), max(vk.shape[1] for _, (_, vk) in per)
+        hb, hk = np.zeros((B, Wd, 2), np.int32), np.zeros((B, Wd, ksh), np.int32)
+        vb, vk = np.zeros((B, Hd, 2), np.int32), np.zeros((B, Hd, ksv), np.int32)
+        for b, ((bh, kh), (bv, kv)) in enumerate(per):
+            hb[b, : bh.shape[0]], hk[b, : kh.shape[0], : kh.shape[1]] = bh, kh
+            vb[b, : bv.shape[0]], vk[b, : kv.shape[0], : kv.shape[1]] = bv, kv
+        return tgt, torch.from_numpy(hb), torch.from_numpy(hk), torch.from_numpy(vb), torch.from_numpy(vk)
+
+    def resized_on_host(self) -> "Uint8Batch":
+        from PIL import Image
+        tgt = self.target_sizes
+        out = torch.zeros((self.data.shape[0],) + self.out_hw(tgt) + (3,), dtype=torch.uint8)
+        src = self.data.cpu().numpy()
+        for b, ((h, w), (th, tw)) in enumerate(zip(self.sizes.tolist(), tgt.tolist())):
+            img = Image.fromarray(src[b, :h, :w]).resize((tw, th), resample=Image.BICUBIC)
+            out[b, :th, :tw] = torch.from_numpy(np.asarray(img).copy())
+        return Uint8Batch(out, tgt)
+
+    def float_image(self) -> torch.Tensor:
+        return self.resized_on_host().float_image()
+
+
 def select_from_sizes(sizes: torch.Tensor, gh: int, gw: int, ps: int = 32):
     """``rmcl_patch_select`` (vision_transformer.py:563-600) for a batch whose extents are KNOWN: with byte sources a pixel inside a
     sample is never exactly zero after Normalize ((2v - 255) / 255 is an odd multiple of 1/255, and so is every channel sum), so the
@@ -170,6 +256,37 @@ def collate_uint8(samples: List[dict], mlm_collator: Optional[Callable] = None) 
     return batch
 
 
+def collate_raw_uint8(samples: List[dict], mlm_collator: Optional[Callable] = None) -> Dict[str, object]:
+    """``collate`` for samples whose image views are ``RawView`` (transform key "decode_uint8"): every image key becomes a list of
+    ``RawUint8Batch`` - decoded bytes at their ORIGINAL sizes, one maximum extent over all image keys - for the device-side resize."""
+    names = {k for smp in samples for k in smp}
+    image_keys = [k for k in names if "image" in k]
+    stripped = [{k: v for k, v in smp.items() if k not in image_keys} for smp in samples]
+    batch = collate(stripped, mlm_collator)
+    if image_keys:
+        views = [rv for k in image_keys for smp in samples if smp.get(k) is not None for rv in smp[k]]
+        for rv in views:
+            if not isinstance(rv, RawView) or len(rv.shape) != 3 or rv.shape[2] != 3:
+                raise AssertionError(f"Collate error, a raw view should be decoded uint8 (H, W, 3), instead of given {getattr(rv, 'shape', type(rv))}")
+        hmax, wmax = max(rv.shape[0] for rv in views), max(rv.shape[1] for rv in views)
+        from ..transforms import min_max_resize_size
+        targets = [min_max_resize_size(rv.shape[1], rv.shape[0], rv.shorter, rv.longer) for rv in views]     # (w, h) after the resize
+        extent = (max(t[1] for t in targets), max(t[0] for t in targets))                                   # one extent over ALL image keys
+        for k in image_keys:
+            per_sample = [smp[k] for smp in samples]
+            out = []
+            for v in range(len(per_sample[0])):
+                data = torch.zeros(len(samples), hmax, wmax, 3, dtype=torch.uint8)
+                sizes = torch.zeros(len(samples), 2, dtype=torch.int32)
+                for b, vs in enumerate(per_sample):
+                    px = vs[v].pixels
+                    data[b, : px.shape[0], : px.shape[1]] = px
+                    sizes[b, 0], sizes[b, 1] = px.shape[0], px.shape[1]
+                out.append(RawUint8Batch(data, sizes, per_sample[0][v].shorter, per_sample[0][v].longer, extent))
+            batch[k] = out
+    return batch
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # arrow-table dataset: the protocol of the reference's BaseDataset (vilt/datasets/base_dataset.py:11-165)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -185,8 +302,9 @@ class BaseDataset(torch.utils.data.Dataset):
       * ``tokenizer``: any callable with the HF signature (the reference's datamodule attaches one loaded by name,
         datamodule_base.py:12-21 - not available offline; tests use BertTokenizer on a local vocabulary file).
 
-    ``transform_keys``: "pixelbert" (float CHW views, the reference's) or "pixelbert_uint8" (byte HWC views for the device-side
-    normalisation, collate with ``collate_uint8``).  Differences kept on purpose: the tables stay memory-mapped and the caption
+    ``transform_keys``: "pixelbert" (float CHW views, the reference's), "pixelbert_uint8" (byte HWC views for the device-side
+    normalisation, collate with ``collate_uint8``) or "decode_uint8" (decoded bytes at the original size: MinMaxResize too runs on the
+    device, collate with ``collate_raw_uint8``).  Differences kept on purpose: the tables stay memory-mapped and the caption
     column is read once with ``to_pylist`` (no pandas round trip); de-duplication keeps first-seen order (the reference's
     ``list(set(texts))`` order depends on the hash seed)."""
 
@@ -297,7 +415,10 @@ class BaseDataset(torch.utils.data.Dataset):
         return self.get_suite(index)
 
     def collate(self, batch, mlm_collator=None):
-        uint8 = any(torch.is_tensor(v) and v.dtype == torch.uint8 for smp in batch for k, vs in smp.items() if "image" in k and vs for v in vs)
+        views = [v for smp in batch for k, vs in smp.items() if "image" in k and vs for v in vs]
+        if any(isinstance(v, RawView) for v in views):
+            return collate_raw_uint8(batch, mlm_collator)
+        uint8 = any(torch.is_tensor(v) and v.dtype == torch.uint8 for v in views)
         return (collate_uint8 if uint8 else collate)(batch, mlm_collator)
 
 

@@ -59,8 +59,17 @@ def pixelbert_uint8_transform(size=800):
     return lambda img: torch.from_numpy(np.array(resize(img).convert("RGB"), dtype=np.uint8))
 
 
+def decode_uint8_transform(size=800):
+    """Decode only: callable(PIL image) -> ``RawView`` (uint8 [h, w, 3] at the ORIGINAL size + the MinMaxResize parameters of the pixelbert
+    transform).  The bicubic resize - after the JPEG decode the most expensive thing a loader worker does - moves to the device
+    (rmcl_image_resize_u8, PIL's own integer arithmetic: the bytes the worker would have produced)."""
+    from ..datasets.base_dataset import RawView
+    longer = int((1333 / 800) * size)
+    return lambda img: RawView(torch.from_numpy(np.array(img.convert("RGB"), dtype=np.uint8)), size, longer)
+
+
 # (the RandAugment variant is a training-time augmentation, out of scope)
-_transforms = {"pixelbert": pixelbert_transform, "pixelbert_uint8": pixelbert_uint8_transform}
+_transforms = {"pixelbert": pixelbert_transform, "pixelbert_uint8": pixelbert_uint8_transform, "decode_uint8": decode_uint8_transform}
 
 
 def keys_to_transforms(keys: list, size=224):

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 import rmcl_pkg  # noqa: F401,E402
 from oracle import rmcl_oracle as O  # noqa: E402
 from rmcl_amd._lib import lib, check, P  # noqa: E402
-from rmcl_amd.vilt.datasets import Uint8Batch, select_from_sizes  # noqa: E402
+from rmcl_amd.vilt.datasets import RawUint8Batch, Uint8Batch, select_from_sizes  # noqa: E402
 from rmcl_amd.vilt.transforms import normalize_lut  # noqa: E402
 from tests.test_parity2_gpu import make_module  # noqa: E402
 from tests.test_path_gpu import dev_batch  # noqa: E402
@@ -76,5 +76,66 @@ def test_training_step_on_a_byte_batch_equals_the_float_batch(sizes):
         res.append((float(loss), m.engine.g32.clone(), m.proj_queue.clone()))
     # identical patch rows in, so identical loss / keys; the gradient arena up to the order of its float atomics (bias sums, embeddings)
     # (the batch loss is an atomic sum over the rows: equal up to the order of 4 float adds)
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and torch.equal(res[0][2], res[1][2])
+    assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MinMaxResize on the device (round 4): rmcl_image_resize_u8 against PIL itself
+# ---------------------------------------------------------------------------------------------------------------------
+
+def raw_batch(sizes, seed, shorter=384, longer=640):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    Hs, Ws = max(h for h, _ in sizes), max(w for _, w in sizes)
+    data = torch.zeros(len(sizes), Hs, Ws, 3, dtype=torch.uint8)
+    for b, (h, w) in enumerate(sizes):
+        yy, xx = np.mgrid[0:h, 0:w]
+        smooth = 127 + 90 * np.sin(xx / 17.0)[..., None] * np.cos(yy / 23.0)[..., None]          # edges and gradients: the filter's negative lobes
+        img = (smooth + rng.normal(0, 40, (h, w, 3))).clip(0, 255).astype(np.uint8)               # overshoot both ways, the clip to a byte is exercised
+        data[b, :h, :w] = torch.from_numpy(img)
+    return RawUint8Batch(data, torch.tensor(sizes, dtype=torch.int32), shorter, longer)
+
+
+@pytest.mark.parametrize("sizes", [[(480, 640), (640, 480), (427, 640), (375, 500)], [(300, 451), (60, 50), (801, 799), (200, 1024), (900, 1200)],
+                                   [(384, 384), (384, 512)]])
+def test_device_min_max_resize_gives_pils_bytes(sizes):
+    """Decoded bytes at their original sizes -> rmcl_image_resize_u8 (two integer passes with PIL's tables) against PIL.Image.resize on
+    the same bytes (the reference's MinMaxResize, vilt/transforms/utils.py:5-26): bit-identical inside every sample, zero outside; up-
+    and down-scaling, mixed orientations, identity axes, the 640-pixel cap."""
+    ocfg = O.default_config(num_layers=1, num_negative=256, per_gpu_batchsize=len(sizes), adv_steps_img=1)
+    m, _ = make_module(ocfg, 5, "bf16")
+    raw = raw_batch(sizes, 7)
+    want = raw.resized_on_host()                                       # PIL
+    got = m.engine.resize_raw(raw.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(got.sizes, want.sizes) and tuple(got.data.shape) == tuple(want.data.shape)
+    assert torch.equal(got.data.cpu(), want.data)
+    if sizes[0] == (300, 451):                                          # and the reference's own pixels of this image (tests/golden/pipeline.npz)
+        from tests.golden_util import load
+        g = load("pipeline.npz")
+        one = RawUint8Batch(torch.from_numpy(g["pix_src"])[None], torch.tensor([[300, 451]]), 384, 640)
+        out = m.engine.resize_raw(one.to(DEV))
+        t = out.float_image()[0].cpu()
+        assert float((t[:, ::16, ::16] - torch.from_numpy(g["pix_out_sub"])).abs().max()) <= 1e-6
+
+
+def test_training_step_on_decoded_bytes_equals_the_host_resized_batch():
+    """batch["image"] = RawUint8Batch (what collate_raw_uint8 delivers: workers only decode) through training_step against the same batch
+    resized on the host with PIL and fed as a Uint8Batch: identical patch rows, so identical loss, queue and gradients (up to atomics)."""
+    sizes = [(480, 640), (640, 480), (427, 640), (375, 500)]
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=len(sizes), adv_steps_img=2)
+    batch = O.synthetic_batch(ocfg, len(sizes), 4, ragged_text=True)
+    raw = raw_batch(sizes, 11)
+    res = []
+    for kind in ("host", "device"):
+        m, _ = make_module(ocfg, 5, "bf16", k_seed=6)
+        b = dev_batch(dict(batch, image=[raw.resized_on_host().float_image()]))
+        b["image"] = [raw.resized_on_host() if kind == "host" else raw]
+        m.zero_grad()
+        loss = m.training_step(b, 0)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss), m.engine.g32.clone(), m.proj_queue.clone()))
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and torch.equal(res[0][2], res[1][2])
     assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 1e-6

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Host feed rate of the input pipeline (row f3): image-text pairs per second that `workers` DataLoader processes deliver as
 collated batches out of an arrow shard - decode (PIL), MinMaxResize to the 384 configuration (bicubic, multiples of 32),
-tokenise to 40 ids, collate - for the byte path ("pixelbert_uint8" + collate_uint8: uint8 HWC batches, normalised on the
-device) and the reference's float path ("pixelbert" + collate).  Synthetic shard: JPEG images of COCO's typical 640x480 /
+tokenise to 40 ids, collate - for the decode-only path ("decode_uint8" + collate_raw_uint8: decoded bytes at their original size,
+MinMaxResize AND normalisation on the device, round 4), the byte path ("pixelbert_uint8" + collate_uint8: resized uint8 HWC batches,
+normalised on the device) and the reference's float path ("pixelbert" + collate).  `--split` times the per-image stages of one
+worker in this process (decode / bicubic resize / float conversion / tokenise): what a worker's time is made of.  Synthetic shard: JPEG images of COCO's typical 640x480 /
 480x640 size (smooth fields + noise, quality 90, ~100 KB each), two captions per image out of the toy vocabulary.  Never touches
 the GPU (bench.py runs it as a child process BEFORE it initialises HIP, so the loader's forked workers are not GPU processes).
 
@@ -61,10 +63,40 @@ def measure(data_dir, transform, workers, batch, seconds):
             pairs += len(b["text"])
             im = b["image"][0]
             nbytes = (im.data if hasattr(im, "data") and hasattr(im, "sizes") else im).numel() * (1 if hasattr(im, "sizes") else 4)
+            if hasattr(im, "tables"):
+                im.tables()                                      # the consumer's share of the decode-only path: PIL's integer tables (cached per size pair)
             if time.perf_counter() - t0 >= seconds:
                 return pairs / (time.perf_counter() - t0), nbytes
         if t0 is not None and pairs == 0 and time.perf_counter() - t0 > 4 * seconds:
             return 0.0, nbytes
+
+
+def stage_split(data_dir, n=96):
+    """milliseconds per image of the stages of ONE worker (this process, one thread): arrow bytes -> decode -> resize -> tensor"""
+    import pyarrow as pa
+    from PIL import Image
+    from rmcl_amd.vilt.transforms.utils import min_max_resize_size, to_normalized_tensor
+    tab = pa.ipc.RecordBatchFileReader(pa.memory_map(os.path.join(data_dir, "feed.arrow"), "r")).read_all()
+    tok = WS.load_tokenizer(os.path.join(ROOT, "tests", "golden", "toy_vocab.txt"))
+    rows = [tab["image"][i % len(tab)].as_py() for i in range(n)]
+    caps = [tab["caption"][i % len(tab)].as_py()[0] for i in range(n)]
+    t = {"decode": 0.0, "resize_bicubic": 0.0, "to_uint8_tensor": 0.0, "to_float_tensor": 0.0, "tokenise": 0.0}
+    for raw, cap in zip(rows, caps):
+        t0 = time.perf_counter()
+        img = Image.open(io.BytesIO(raw)).convert("RGB")
+        img.load()
+        t1 = time.perf_counter()
+        small = img.resize(min_max_resize_size(img.size[0], img.size[1], 384, 640), resample=Image.BICUBIC)
+        t2 = time.perf_counter()
+        torch.from_numpy(np.array(small, dtype=np.uint8))
+        t3 = time.perf_counter()
+        to_normalized_tensor(small)
+        t4 = time.perf_counter()
+        tok(cap, padding="max_length", truncation=True, max_length=40, return_special_tokens_mask=True)
+        t5 = time.perf_counter()
+        for k, dt in zip(t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+            t[k] += dt
+    return {k: round(1e3 * v / n, 3) for k, v in t.items()}
 
 
 def main():
@@ -74,7 +106,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seconds", type=float, default=8.0)
     ap.add_argument("--json", action="store_true")
-    ap.add_argument("--paths", default="pixelbert_uint8,pixelbert")
+    ap.add_argument("--paths", default="decode_uint8,pixelbert_uint8,pixelbert")
+    ap.add_argument("--split", action="store_true", help="also time the per-image stages of one worker (decode / resize / conversion / tokenise)")
     args = ap.parse_args()
     torch.set_num_threads(1)
     with tempfile.TemporaryDirectory() as d:
@@ -82,7 +115,9 @@ def main():
         out = {"workers": args.workers, "batch": args.batch, "images_in_shard": args.images, "jpeg_kib_mean": round(kb, 1),
                "host_cores": len(os.sched_getaffinity(0)),
                "what": "DataLoader pairs/s: arrow bytes -> PIL decode -> MinMaxResize(384, 640) bicubic -> tokenise(40) -> collate, synthetic 640x480 JPEGs"}
-        for tr in args.paths.split(","):
+        if args.split:
+            out["ms_per_image_one_worker"] = stage_split(d)
+        for tr in filter(None, args.paths.split(",")):
             rate, nbytes = measure(d, tr, args.workers, args.batch, args.seconds)
             out[tr] = {"pairs_per_s": round(rate, 1), "batch_image_bytes": int(nbytes)}
     print(json.dumps(out) if args.json else json.dumps(out, indent=1), flush=True)
