@@ -469,14 +469,16 @@ class Engine:
         src = raw.data.to(self.device, non_blocking=True).contiguous()
         B, Hs, Ws, _ = src.shape
         Hd, Wd = vb.shape[1], hb.shape[1]                               # (the batch extent the tables were packed for)
-        dev = lambda t: t.to(self.device, non_blocking=True)
+        # the tables are freshly built pageable host arrays that die with this call: BLOCKING copies (an asynchronous copy out of
+        # pageable memory may still be reading it after the arrays are gone); the image bytes themselves belong to the caller's batch
+        dev = lambda t: t.to(self.device, non_blocking=False)
         ssz, dsz, hb_d, hk_d, vb_d, vk_d = dev(raw.sizes.contiguous()), dev(tgt.contiguous()), dev(hb), dev(hk), dev(vb), dev(vk)
         tmp = torch.empty(B, Hs, Wd, 3, dtype=torch.uint8, device=self.device)
         dst = torch.empty(B, Hd, Wd, 3, dtype=torch.uint8, device=self.device)
         check(lib.rmcl_image_resize_u8(P(src), P(ssz), B, Hs, Ws, P(dsz), Hd, Wd, P(hb_d), P(hk_d), hk.shape[2], P(vb_d), P(vk_d), vk.shape[2],
                                        P(tmp), P(dst), stream_ptr()), "image_resize_u8")
         out = Uint8Batch(dst, tgt)
-        out.keep_alive = (src, ssz, dsz, hb_d, hk_d, vb_d, vk_d, tmp)          # until the stream has consumed them
+        out.keep_alive = (raw.data, src, ssz, dsz, hb_d, hk_d, vb_d, vk_d, tmp)   # until the stream has consumed them
         return out
 
     def _bind_uint8(self, text_ids, text_mask, u8, tag, select) -> PassBuffers:
@@ -528,7 +530,7 @@ class Engine:
         check(lib.rmcl_image_u8_to_patches(P(data), P(sizes), P(geom.sel) if geom else None, P(geom.counts) if geom else None,
                                            geom.sel.shape[1] if geom else 0, B, geom.n if geom else gh * gw, Hh, Ww, ps, P(self._lut),
                                            P(pb.patches32), stream_ptr()), "image_u8_to_patches")
-        pb.keep_alive = (data, sizes)                                      # until the stream has consumed them
+        pb.keep_alive = (data, sizes, u8, getattr(u8, "keep_alive", None))      # until the stream has consumed them
         return pb
 
     def bind_text(self, like: PassBuffers, text_ids: torch.Tensor, text_mask: torch.Tensor, tag: str) -> PassBuffers:

@@ -133,6 +133,9 @@ def test_training_step_on_decoded_bytes_equals_the_host_resized_batch():
         b = dev_batch(dict(batch, image=[raw.resized_on_host().float_image()]))
         b["image"] = [raw.resized_on_host() if kind == "host" else raw]
         m.zero_grad()
+        # (427 x 640 resizes to 384 x 576 = 216 patches > max_image_len = 200: like the reference, a random subset of 200 is kept, drawn
+        # from the HOST generator (vision_transformer.py:633-636) - the same seed gives both runs the same subset)
+        torch.manual_seed(123)
         loss = m.training_step(b, 0)
         loss.backward()
         torch.cuda.synchronize()
