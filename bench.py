@@ -216,14 +216,22 @@ def realistic_leg(model, cfg, batch, args, device, ViLTransformerSS, steps=10, w
         opt2.zero_grad()
         return loss
 
-    for i in range(warmup):
-        step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = step(warmup + i)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def run():
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = step(warmup + i)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    dt, loss = run()
+    # opt-in variant: PGD step 0's forward also serves as the clean query forward under dropout (config["share_clean_forward"]; it changes
+    # only the LOGGED clean prediction, objectives.py): (4 + 2K) F per pair like the dropout-free step
+    m2.hparams.config["share_clean_forward"] = True
+    dt_shared, _ = run()
+    m2.hparams.config["share_clean_forward"] = False
     eng = m2.engine
     B = batch["text_ids"].shape[0]
     pb = eng.bufs(B)
@@ -231,7 +239,11 @@ def realistic_leg(model, cfg, batch, args, device, ViLTransformerSS, steps=10, w
             "ln_fold": m2.load_report.get("ln_fold"), "half_batch_lanes": "on" if getattr(pb, "_lanes", None) is not None else "off",
             "cls_only_tail": "on" if any(pb.tail.values()) else "off",
             "steps": steps, "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3), "pairs_per_s": round(B * steps / dt, 2),
-            "executed_F_per_pair": 5 + 2 * cfg["adv_steps_img"], "final_loss": round(float(loss.detach()), 4)}
+            "executed_F_per_pair": 5 + 2 * cfg["adv_steps_img"], "final_loss": round(float(loss.detach()), 4),
+            "opt_in_share_clean_forward": {"ms_per_step": round(1e3 * dt_shared / steps, 3), "pairs_per_s": round(B * steps / dt_shared, 2),
+                                           "executed_F_per_pair": 4 + 2 * cfg["adv_steps_img"],
+                                           "note": "config['share_clean_forward'] = True: the clean query's logged prediction comes from PGD step 0's forward "
+                                                   "(same dropout mask); loss / gradients / perturbation unchanged; default off = the reference's two draws"}}
 
 
 def main():
@@ -500,7 +512,7 @@ def main():
         }
         if short is not None:
             out["short_last_batch"] = short
-        out["queue_ptr"] = model.queue_ptr
+        out["queue_ptr"] = model.queue_ptr if hasattr(model, "proj_queue_ptr") else None
         out["lanes"] = "on" if getattr(model.engine.bufs(B), "_lanes", None) is not None else "off"
         if per_rank is not None:
             # what an N > 1 run needs to explain itself: per-rank step time, the stream time the step stood still waiting for

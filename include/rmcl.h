@@ -161,6 +161,9 @@ int rmcl_tune_set(int key, int value);
  * run.py:96 / pytorch_lightning ddp).  Layers finish in the order layers-1 .. 0.                                        */
 int rmcl_grad_ready_wait(int layer, void* stream);
 int rmcl_set_side_stream(void* stream);
+/* Stream of the stash prefetch (round 4, rmcl_tune_set(12, mask) != 0): rmcl_encoder_backward touches layer l - 1's cold stash buffers into
+ * the Infinity Cache from a few workgroups on this stream while layer l's backward chain runs.  NULL / never set: no prefetch.            */
+int rmcl_set_prefetch_stream(void* stream);
 
 /* Test hook: x[i] *= dropout_mask(site seed of (drop_seed, layer, site), i), i < n (x pre-filled with ones gives the mask).
  * sites: 0 proj, 1 mlp hidden, 2 fc2, 3 text embeddings, 4 image embeddings (layer 0 for the last two).   */

@@ -74,7 +74,7 @@ lib = _load()
 
 # every symbol include/rmcl.h declares (checked by tests/test_abi.py against the header text)
 EXPORTS = (
-    "rmcl_last_error", "rmcl_version", "rmcl_prof_begin", "rmcl_prof_end", "rmcl_tune_set", "rmcl_grad_ready_wait", "rmcl_set_side_stream", "rmcl_dropout_mask_apply", "rmcl_param_layout", "rmcl_ln_fold_elems", "rmcl_ln_fold", "rmcl_linear_rowstat", "rmcl_linear_lnfold", "rmcl_linear_rowstat_c", "rmcl_linear_lnfold_c", "rmcl_weight_transpose_bf16", "rmcl_stash_bytes", "rmcl_workspace_bytes",
+    "rmcl_last_error", "rmcl_version", "rmcl_prof_begin", "rmcl_prof_end", "rmcl_tune_set", "rmcl_grad_ready_wait", "rmcl_set_side_stream", "rmcl_set_prefetch_stream", "rmcl_dropout_mask_apply", "rmcl_param_layout", "rmcl_ln_fold_elems", "rmcl_ln_fold", "rmcl_linear_rowstat", "rmcl_linear_lnfold", "rmcl_linear_rowstat_c", "rmcl_linear_lnfold_c", "rmcl_weight_transpose_bf16", "rmcl_stash_bytes", "rmcl_workspace_bytes",
     "rmcl_heads_stash_bytes", "rmcl_im2patch_f32", "rmcl_patch_select", "rmcl_im2patch_sel", "rmcl_image_u8_to_patches", "rmcl_image_resize_u8", "rmcl_add_cast_f32", "rmcl_shard_sum", "rmcl_encoder_forward", "rmcl_encoder_backward",
     "rmcl_heads_forward", "rmcl_heads_forward2", "rmcl_heads_backward", "rmcl_infonce_ws_bytes", "rmcl_infonce_f32", "rmcl_infonce_split_bf16", "rmcl_pgd_step", "rmcl_pgd_step_fused",
     "rmcl_delta_channel_norm", "rmcl_ema_f32", "rmcl_enqueue_f32", "rmcl_cast_f32", "rmcl_adamw_f32", "rmcl_ipot_f32", "rmcl_gemm_batched", "rmcl_l2norm_rows_fwd", "rmcl_l2norm_rows_bwd",

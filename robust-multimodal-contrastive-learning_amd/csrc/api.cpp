@@ -113,8 +113,11 @@ extern int g_attn_bwd_persist;
 extern int g_attn_bwd_tpw;
 extern int g_gemm_share;
 extern bool g_lnfold_centred;
+extern int g_prefetch_mask, g_prefetch_wgs;
 int rmcl_tune_set(int key, int value) {
   if (key == 11) { g_lnfold_centred = value != 0; return 0; }
+  if (key == 12) { g_prefetch_mask = value & 7; return 0; }                                          // stash prefetch one layer ahead of the backward (encoder.cpp)
+  if (key == 13) { g_prefetch_wgs = value < 0 ? 0 : (value > 64 ? 64 : value); return 0; }       // (0: the event traffic only, no touch launches)
   if (key == 7) { g_dp_stagger = value < 0 ? 0 : value; return 0; }                                  // gemm_dp: start delay of every CU's second workgroup (10 ns ticks)
   if (key == 10) { g_gemm_share = value < 1 ? 1 : (value > 8 ? 8 : value); return 0; }                 // chains sharing the chip (GEMM routing sizes a launch against CUs / share)
   if (key == 9) { g_attn_bwd_tpw = value; return 0; }                                             // fused attention backward: key tiles per wave (1, 2, 3)

@@ -384,6 +384,44 @@ __global__ __launch_bounds__(256) void u8_to_patches_kernel(const unsigned char*
   for (int c = 0; c < 3; ++c) *reinterpret_cast<float4*>(row + c * 1024) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
 }
 // ---------------------------------------------------------------------------------------------
+// Stash prefetch (round 4): the backward reads every layer's stash (pre-activation u 72 MB, qkv 54 MB, attention output, residual
+// stream) long after the forward wrote it - HBM-cold inside GEMM epilogues and attention prologues, where the latency is exposed.  This
+// kernel only TOUCHES a buffer: a few workgroups on the CUs the persistent GEMMs leave free stream it through non-temporal loads one
+// layer ahead of the backward chain, so the bytes sit in the 256 MB Infinity Cache when their consumer arrives.  Nothing is written.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int tch_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void touch_kernel(const tch_u32x4* __restrict__ p, long n16, unsigned* __restrict__ sink) {
+  // 16 waves x 8 independent 16-byte loads per lane = 128 KiB in flight per CU: the rate of ONE workgroup with 4 loads per lane was
+  // latency-bound at a few GB/s (72 MB took over a millisecond: the touches trailed the backward they were meant to lead)
+  unsigned acc = 0;
+  const long stride = (long)gridDim.x * 1024;
+  long i = (long)blockIdx.x * 1024 + threadIdx.x;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    tch_u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(p + i + k * stride);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc ^= v[k].x;
+  }
+  for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(p + i).x;
+  if (acc == 0x9e3779b9u && sink) *sink = acc;                // (keeps the loads alive; practically never taken)
+}
+int rmcl_touch(const void* p, size_t bytes, int wgs, hipStream_t s) {
+  if (!p || bytes < 16 || wgs <= 0) return 0;
+  static unsigned* sink = nullptr;
+  if (!sink && hipMalloc(&sink, 64) != hipSuccess) sink = nullptr;
+  // the kernel asks for (almost) a whole CU's LDS although it uses none: a touch workgroup then never shares a CU with a GEMM workgroup
+  // (sharing made that CU the launch's straggler: 34.8 -> 37.6 ms per step with plain 8-workgroup touches), it takes one of the CUs the
+  // 248-workgroup GEMM rounds leave free
+  constexpr int HOG = 150 * 1024;
+  static RmclLdsOnce once;
+  RMCL_TRY(rmcl_set_max_lds(once, reinterpret_cast<const void*>(touch_kernel), HOG));
+  RMCL_LAUNCH(touch_kernel, dim3(wgs), dim3(1024), HOG, s, reinterpret_cast<const tch_u32x4*>(p), (long)(bytes / 16), sink);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // MinMaxResize on the device (row f3, round 4): PIL's 8-bit bicubic resize (the reference's vilt/transforms/utils.py:5-26 calls
 // Image.resize(size, BICUBIC)) as two passes over the decoded bytes of a zero-padded batch [B, Hs, Ws, 3] - horizontal into a uint8
 // intermediate [B, Hs, Wd, 3], then vertical into [B, Hd, Wd, 3] - with PIL's own integer tables (vilt/transforms/resample.py builds

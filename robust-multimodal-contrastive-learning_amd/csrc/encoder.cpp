@@ -227,6 +227,13 @@ int ensure_events() {
 
 }  // namespace
 
+// stash prefetch one layer ahead of the backward chain (rmcl_tune_set key 12: bit 0 = pre-activation u, bit 1 = qkv + attention output,
+// bit 2 = the two residual-stream stashes; key 13: workgroups of the touch kernel).  Runs on the stream set by rmcl_set_prefetch_stream.
+int g_prefetch_mask = 0, g_prefetch_wgs = 8;
+static hipStream_t g_pref = nullptr;
+static hipEvent_t g_pev[64];
+static int g_npev = 0;
+extern "C" int rmcl_set_prefetch_stream(void* stream) { g_pref = (hipStream_t)stream; return 0; }
 bool g_lnfold_centred = true;        // rmcl_tune_set key 11: 0 = the uncentred LayerNorm fold of round 2 (A/B, precision tests)
 bool rmcl_lnfold_centred() { return g_lnfold_centred; }
 bool g_dw_grouped = true;            // rmcl_tune_set key 3: 0 selects the per-GEMM weight-gradient path (A/B and parity tests)
@@ -578,6 +585,33 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   auto EV = [&](int kind, int l) { return g_ev[(kind * 32 + (l & 31)) & 127]; };   // kind 0: fork, 1: done1, 2: done2 / side done, 3: main done
   auto rep_slot = [&](int idx) { return grouped ? w.ln_rep + (size_t)idx * RMCL_LN_REP_FLOATS : nullptr; };   // 0: final norm, 1+2l: ln2, 2+2l: ln1
   if (grouped) HIP_TRY(hipMemsetAsync(w.ln_rep, 0, (size_t)(2 * Lr + 1) * RMCL_LN_REP_FLOATS * sizeof(float), s));
+  // stash prefetch: while layer l's backward runs, the idle CUs touch layer l - 1's cold operands into the Infinity Cache
+  const bool pref = g_prefetch_mask != 0 && g_pref != nullptr && dt == RMCL_BF16 && !d->exact && M >= 4096;
+  if (pref) {
+    while (g_npev < 64) {
+      HIP_TRY(hipEventCreateWithFlags(&g_pev[g_npev], hipEventDisableTiming));
+      ++g_npev;
+    }
+  }
+  static int pev_rot = 0;
+  auto prefetch_layer = [&](int l) -> int {
+    if (!pref || l < 0) return 0;
+    const LayerStash& q = st.layer[l];
+    hipEvent_t ev = g_pev[(pev_rot++) & 63];
+    HIP_TRY(hipEventRecord(ev, s));
+    HIP_TRY(hipStreamWaitEvent(g_pref, ev, 0));
+    const size_t e2 = esz(dt);
+    if (g_prefetch_mask & 1) RMCL_TRY(rmcl_touch(q.u, (size_t)M * mlp * e2, g_prefetch_wgs, g_pref));
+    if (g_prefetch_mask & 2) {
+      RMCL_TRY(rmcl_touch(q.qkv, (size_t)M * 3 * D * e2, g_prefetch_wgs, g_pref));
+      RMCL_TRY(rmcl_touch(q.ao, (size_t)M * D * e2, g_prefetch_wgs, g_pref));
+    }
+    if (g_prefetch_mask & 4) {
+      RMCL_TRY(rmcl_touch(q.x_mid, (size_t)M * D * 4, g_prefetch_wgs, g_pref));
+      RMCL_TRY(rmcl_touch(q.x_in, (size_t)M * D * 4, g_prefetch_wgs, g_pref));
+    }
+    return 0;
+  };
   int cur = 0;
   float* dxc = w.dxn_full;                       // tail: gradient of the B cls rows [B, D] f32
   if (tail) {
@@ -594,6 +628,7 @@ int rmcl_encoder_backward(const rmcl_dims* d, int mode, const float* params32, c
   const int dln_dt = lpm ? dt : RMCL_F32;
   for (int l = Lr - 1; l >= 0; --l) {
     const LayerStash& ls = st.layer[l];
+    RMCL_TRY(prefetch_layer(l - 1));
     void* du = DU[l & 1];
     void* dqkv = DQ[l & 1];
     const int ia = cur, ib = grouped ? (cur + 1) % 3 : cur ^ 1, ic = grouped ? (cur + 2) % 3 : cur;

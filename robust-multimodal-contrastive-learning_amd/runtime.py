@@ -271,6 +271,9 @@ class Engine:
         self.comm_stream = torch.cuda.Stream(device=self.device)     # gradient all-reduces (N > 1), gated on backward events
         if os.environ.get("RMCL_NO_DW_STREAM", "0") != "1":          # weight-gradient GEMMs concurrent with the dX chain
             lib.rmcl_set_side_stream(C.c_void_p(self.dw_stream.cuda_stream))
+        # stash prefetch of the backward (rmcl_tune_set(12, mask)): on the communication stream, idle outside the gradient reduction
+        pf = {"comm": self.comm_stream, "side": self.side_stream, "dw": self.dw_stream}[os.environ.get("RMCL_PREFETCH_STREAM", "comm")]
+        lib.rmcl_set_prefetch_stream(C.c_void_p(pf.cuda_stream))
 
     # ---- geometry ------------------------------------------------------------------------------
     def dims(self, B: int, dtype=None, P=None) -> L.Dims:
@@ -461,12 +464,17 @@ class Engine:
                                         ps, 0, stream_ptr()), "im2patch_sel")
         return pb
 
+    def _h2d(self, t: torch.Tensor) -> torch.Tensor:
+        """host -> device copy that is asynchronous only out of PINNED memory (a DataLoader with pin_memory): an asynchronous copy out of
+        pageable memory leaves it to the runtime when the source is read - blocking there costs microseconds and removes the question"""
+        return t.to(self.device, non_blocking=bool(t.device.type == "cpu" and t.is_pinned()))
+
     def resize_raw(self, raw):
         """``RawUint8Batch`` (decoded bytes at their original sizes) -> ``Uint8Batch`` on the device: MinMaxResize with PIL's integer
         arithmetic in two kernel passes (include/rmcl.h rmcl_image_resize_u8); the tables come from the host (cached per size pair)."""
         from .vilt.datasets.base_dataset import Uint8Batch
         tgt, hb, hk, vb, vk = raw.tables()
-        src = raw.data.to(self.device, non_blocking=True).contiguous()
+        src = self._h2d(raw.data).contiguous()
         B, Hs, Ws, _ = src.shape
         Hd, Wd = vb.shape[1], hb.shape[1]                               # (the batch extent the tables were packed for)
         # the tables are freshly built pageable host arrays that die with this call: BLOCKING copies (an asynchronous copy out of
@@ -485,7 +493,7 @@ class Engine:
         from .vilt.datasets.base_dataset import select_from_sizes
         from .vilt.transforms import normalize_lut
         ps, S = self.cfg["patch_size"], self.cfg["image_size"]
-        data = u8.data.to(self.device, non_blocking=True).contiguous()
+        data = self._h2d(u8.data).contiguous()
         B, Hh, Ww, _ = data.shape
         sz = torch.as_tensor(u8.sizes)
         if sz.dim() != 2 or tuple(sz.shape) != (B, 2):
@@ -526,7 +534,7 @@ class Engine:
         self._set_geometry(pb, geom)
         pb.text_ids = text_ids.to(self.device, torch.int64).contiguous()
         pb.text_mask = text_mask.to(self.device, torch.int64).contiguous()
-        sizes = u8.sizes.to(self.device, non_blocking=True)
+        sizes = self._h2d(u8.sizes)
         check(lib.rmcl_image_u8_to_patches(P(data), P(sizes), P(geom.sel) if geom else None, P(geom.counts) if geom else None,
                                            geom.sel.shape[1] if geom else 0, B, geom.n if geom else gh * gw, Hh, Ww, ps, P(self._lut),
                                            P(pb.patches32), stream_ptr()), "image_u8_to_patches")

@@ -221,7 +221,12 @@ def compute_moco_contrastive(pl_module, batch):
     eng.ema(pl_module.momentum)
     # PGD step 0 runs the query encoder on img + delta_0 = img: with dropout off that IS the clean query forward
     # (:267-275), so it is computed once (common sub-expression) and its logits give prediction_original.
-    fuse_clean = pl_module.image_view and not pl_module.text_view and not eng.dropout_on and not clean_view
+    # Under dropout the reference draws a fresh mask for the clean forward (:267) and another for PGD step 0's (pgd_attack_vilt.py:145), so
+    # the two are different computations and both run.  config["share_clean_forward"] = True (default False) lets PGD step 0's forward stand in
+    # for the clean one under dropout too: loss, gradients and the perturbation are untouched (the clean logits never enter the loss,
+    # SURVEY quirk 3) - only the LOGGED prediction_original / q_original then come from the forward that shares step 0's mask.
+    share = bool(pl_module.hparams.config.get("share_clean_forward", False))
+    fuse_clean = pl_module.image_view and not pl_module.text_view and (not eng.dropout_on or share) and not clean_view
     # two half-batch chains (Engine.lanes) where the PGD loop is the step's front: each lane runs its own K iterations, lane 0 on this
     # stream, lane 1 on the side stream.  With dropout ON the clean query forward cannot be shared with PGD step 0 (the reference draws
     # a fresh mask for each, objectives.py:267 vs pgd_attack_vilt.py:145): it then follows the key forward on the key stream, in its own

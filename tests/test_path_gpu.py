@@ -753,3 +753,32 @@ def test_half_batch_lanes_give_the_one_chain_step(monkeypatch):
     ref_noise = float((a["g"] - a2["g"]).norm() / a["g"].norm())                       # run-to-run (float atomics of the cls-row scatter)
     rel = float((a["g"] - b["g"]).norm() / a["g"].norm())
     assert rel < max(1e-5, 10 * ref_noise), (rel, ref_noise)
+
+
+def test_share_clean_forward_under_dropout_is_an_opt_in_that_drops_one_pass():
+    """config["share_clean_forward"] (default False): under dropout the reference draws one mask for the clean query forward
+    (objectives.py:267) and another for PGD step 0 (pgd_attack_vilt.py:145), so by default both passes run ((5 + 2K) F); with the
+    switch on, PGD step 0's forward also supplies the LOGGED clean prediction / q_original and the separate pass disappears - the
+    passes that feed the loss (key, K PGD steps, attacked view) are the same list, drawn in the same order."""
+    from rmcl_amd import _lib as L
+    K = 2
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=4, adv_steps_img=K)
+    logs = {}
+    for share in (False, True):
+        cfg = task_moco(num_layers=2, num_negative=1024, adv_steps_img=K, per_gpu_batchsize=4, drop_rate=0.1, image_view=True, text_view=False,
+                        num_gpus=1, num_nodes=1, share_clean_forward=share)
+        m = ViLTransformerSS(cfg, device=DEV, compute_dtype="bf16")
+        m.load_state_dict({n: t.to(DEV) for n, t in O.init_params(ocfg, 5).items()}, strict=False)
+        m.train()
+        m.engine.pass_log = []
+        from rmcl_amd.vilt.modules import vilt_utils
+        vilt_utils.set_task(m)
+        ret = m(dev_batch(O.synthetic_batch(ocfg, 4, 9)))
+        ret["moco_loss"].backward()
+        torch.cuda.synchronize()
+        logs[share] = [(e["key"], e["mode"]) for e in m.engine.pass_log]
+        assert torch.isfinite(ret["moco_loss"]) and ret["q_original"].shape == (4, 128) and all(e["p"] == 0.1 for e in m.engine.pass_log)
+        assert "moco_attack/PGD_success_rate" in m.logged
+    base = [(True, L.MODE_INFER)] + [(False, L.MODE_DATA)] * K + [(False, L.MODE_FULL)]
+    assert logs[True] == base, logs[True]
+    assert logs[False] == base[:1] + [(False, L.MODE_INFER)] + base[1:], logs[False]
