@@ -187,7 +187,7 @@ def traffic_record(kernel_key):
     return r, r.get("note")
 
 
-def realistic_leg(model, cfg, batch, args, device, ViLTransformerSS, steps=10, warmup=3):
+def realistic_leg(model, cfg, batch, args, device, ViLTransformerSS, steps=15, warmup=5):
     """The reference's real recipe beside the headline (SURVEY 8d "a separate training-realistic throughput line"): `task_moco` is
     trained from `load_path=...vilt_200k_mlm_itm.ckpt` (TRAIN.md:21) with `drop_rate = 0.1` (config.py:57).  The headline model's state
     is written to a checkpoint file and a SECOND module is constructed from it through config["load_path"] with drop_rate 0.1 - i.e.

@@ -771,12 +771,31 @@ __global__ __launch_bounds__(CMB_G * CW) void infonce_combine2_kernel(const floa
   // Z and dq: slice group grp, column cb * CW + cc
   const int grp = t / CW, cc = t - grp * CW, col = cb * CW + cc;
   float Z = 0.f, acc = 0.f;
+  if (nslice == 32 * CMB_G) {
+    // the step's shape (65 536 queue columns = 256 partials per row): all 32 (max, sum) pairs and all 32 dq values of this thread are
+    // fetched in ONE batch - with the loop unrolled by 8 the merge was four dependent rounds of L2 latency
+    float2 ms[32];
+    float dv[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const long sr = (long)(grp + k * CMB_G) * Bpad + i;
+      ms[k] = *reinterpret_cast<const float2*>(part + sr * NPART);
+      dv[k] = dq_part[sr * PD + col];
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float f = __expf(ms[k].x - M);
+      Z += ms[k].y * f;
+      acc += f * dv[k];
+    }
+  } else {
 #pragma unroll 8
-  for (int s = grp; s < nslice; s += CMB_G) {
-    const float* o = part + ((long)s * Bpad + i) * NPART;
-    const float f = __expf(o[0] - M);
-    Z += o[1] * f;
-    acc += f * dq_part[((long)s * Bpad + i) * PD + col];
+    for (int s = grp; s < nslice; s += CMB_G) {
+      const float* o = part + ((long)s * Bpad + i) * NPART;
+      const float f = __expf(o[0] - M);
+      Z += o[1] * f;
+      acc += f * dq_part[((long)s * Bpad + i) * PD + col];
+    }
   }
   accs[grp][cc] = acc;
   if (cc == 0) zs[grp] = Z;
