@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_ksplit_kernel(GemmArgs g)
   // register ring over 16-k steps, PD - 1 steps of loads in flight ahead of the MFMAs: the waves are few and every step is an L2 /
   // HBM round trip (64-byte row pieces of A), so with one step of lookahead the k-loop was a chain of 12 - 24 such round trips
   // (K = 3072, 8 waves: 41.8 us for 9 MB of weights).  The ring index is a compile-time constant (PD steps per trip).
-  constexpr int PD = 8;                                       // (round 4: 4 -> 8 steps of lookahead, 160 operand registers: tools/ab_bench.sh)
+  constexpr int PD = 4;                                       // (round 4: 8 steps of lookahead measured SLOWER in the step: 33.9 vs 33.6 ms, three alternating runs)
   float4 av[PD][4];
   float bv[PD][CT][4];
   auto load = [&](int buf, int k) {
