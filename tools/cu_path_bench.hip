@@ -125,21 +125,25 @@ template <int D, int WHO, int DEPTH = 2> static float run_shared(const char* src
 // optional 18 v_mfma_f32_16x16x32_bf16, barrier}.  MF / RD switch the MFMAs and the LDS reads on.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <bool MF, bool RD, int PH>
+// DM (round 4): where the three LDS-DMA pieces of a phase are issued - 0: in the read phase, ahead of the barrier (gemm_st today); 1: between the
+// MFMAs of the wave's own MFMA phase (one piece behind every sixth MFMA), so that the read phase - what the OTHER group's 18 MFMAs have to cover -
+// carries the nine ds_read_b128 only
+template <bool MF, bool RD, int PH, int DM = 0>
 __global__ __launch_bounds__(512) void k_skel(const char* __restrict__ src, int pool, int passes, float* __restrict__ sink) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wm = wave >> 2, wn = wave & 3;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, grp = j >> 2;
   const char* xbase = src + (long)xcd * pool * (long)PANEL_ROWS * ROWB;
   const int total = passes * NKT;
-  auto issue_half = [&](int i, const int st, const int half) {      // half 0: rows 0..191 ("A"), 1: rows 192..383 ("B")
+  auto issue_piece = [&](int i, const int st, const int half, const int q) {
     const int pass = i / NKT, kt = i - pass * NKT;
     const char* panel = xbase + (long)((grp + 8 * pass) % pool) * (long)PANEL_ROWS * ROWB;
+    const int inst = half * 24 + wave * 3 + q, row = inst * 8 + (lane >> 3), ch = (lane & 7) ^ (row & 7);
+    __builtin_amdgcn_global_load_lds((glb_void*)(panel + (long)row * ROWB + kt * 128 + ch * 16), (lds_void*)(lds + st * STAGE + inst * 1024), 16, 0, 0);
+  };
+  auto issue_half = [&](int i, const int st, const int half) {      // half 0: rows 0..191 ("A"), 1: rows 192..383 ("B")
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int inst = half * 24 + wave * 3 + q, row = inst * 8 + (lane >> 3), ch = (lane & 7) ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((glb_void*)(panel + (long)row * ROWB + kt * 128 + ch * 16), (lds_void*)(lds + st * STAGE + inst * 1024), 16, 0, 0);
-    }
+    for (int q = 0; q < 3; ++q) issue_piece(i, st, half, q);
   };
   f32x4 acc[6][3];
 #pragma unroll
@@ -180,8 +184,15 @@ __global__ __launch_bounds__(512) void k_skel(const char* __restrict__ src, int 
 #pragma unroll
             for (int a = 0; a < 6; ++a) fa[0][a] = *reinterpret_cast<const bf16x8*>(cur + a * 2048 + aoff[s2]);
           }
-          if (more) { issue_half(i + u + 2, (u + 2) % 3, s2); if (s2 == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-          else if (s2 == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (DM == 0) {
+            if (more) { issue_half(i + u + 2, (u + 2) % 3, s2); if (s2 == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else if (s2 == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          } else {
+            // the pieces of this phase go out between the MFMAs below; what must have landed before the NEXT k-tile is read was issued
+            // one k-tile ago: 6 pieces of tile t+2 (this k-tile's) may stay in flight... they are issued AFTER this wait, so vmcnt(0) here
+            // would wait for tile t+1 only if nothing younger is outstanding: k-step 0's three pieces are - hence vmcnt(3)
+            if (s2 == 1) { if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+          }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();
@@ -189,10 +200,18 @@ __global__ __launch_bounds__(512) void k_skel(const char* __restrict__ src, int 
           if (MF) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
+            for (int a = 0; a < 6; ++a) {
 #pragma unroll
               for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][b], fa[0][a], acc[a][b], 0, 0, 0);
+              if (DM == 1 && more && (a & 1)) {                  // one piece behind MFMAs 6, 12, 18
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece(i + u + 2, (u + 2) % 3, s2, a >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
             __builtin_amdgcn_s_setprio(0);
+          } else if (DM == 1 && more) {
+            issue_half(i + u + 2, (u + 2) % 3, s2);
           }
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();
@@ -335,12 +354,12 @@ template <int ILV> static float run_pipe(const char* src, int pool, int passes, 
   return ms;
 }
 
-template <bool MF, bool RD, int PH> static float run_skel(const char* src, int pool, int passes, uint32_t* sink) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel<MF, RD, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE);
+template <bool MF, bool RD, int PH, int DM = 0> static float run_skel(const char* src, int pool, int passes, uint32_t* sink) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_skel<MF, RD, PH, DM>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k_skel<MF, RD, PH><<<256, 512, 3 * STAGE>>>(src, pool, 3, (float*)sink);
+  k_skel<MF, RD, PH, DM><<<256, 512, 3 * STAGE>>>(src, pool, 3, (float*)sink);
   hipEventRecord(e0);
-  k_skel<MF, RD, PH><<<256, 512, 3 * STAGE>>>(src, pool, passes, (float*)sink);
+  k_skel<MF, RD, PH, DM><<<256, 512, 3 * STAGE>>>(src, pool, passes, (float*)sink);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   return ms;
@@ -384,6 +403,8 @@ int main() {
     printf("   gemm_st loop skeleton, us per k-tile (MFMA alone = 0.48): two phases per k-tile: loads only %.3f | + MFMA %.3f | + LDS reads %.3f | + both %.3f\n",
            us(run_skel<false, false, 2>(src, pool, passes, sink)), us(run_skel<true, false, 2>(src, pool, passes, sink)),
            us(run_skel<false, true, 2>(src, pool, passes, sink)), us(run_skel<true, true, 2>(src, pool, passes, sink)));
+    printf("   two phases, LDS-DMA pieces issued BETWEEN the MFMAs of the wave's own MFMA phase (round 4): + MFMA %.3f | + both %.3f\n",
+           us(run_skel<true, false, 2, 1>(src, pool, passes, sink)), us(run_skel<true, true, 2, 1>(src, pool, passes, sink)));
     printf("   one phase per k-tile: loads only %.3f | + MFMA %.3f | + LDS reads %.3f | + both %.3f\n",
            us(run_skel<false, false, 1>(src, pool, passes, sink)), us(run_skel<true, false, 1>(src, pool, passes, sink)),
            us(run_skel<false, true, 1>(src, pool, passes, sink)), us(run_skel<true, true, 1>(src, pool, passes, sink)));
