@@ -119,7 +119,7 @@ def cpu_baseline(K_adv, config="rmcl_pgd"):
         pass
     threads = min(threads, 32)
     torch.set_num_threads(threads)
-    Bc, nsteps = 4, 7
+    Bc, nsteps = 8, 3                              # B = 8, 1 warm-up + 3 timed steps
     clean = config == "itm_clean"
     ocfg = O.default_config(per_gpu_batchsize=Bc, adv_steps_img=K_adv, image_view=not clean, clean_view=clean)
     labels = (torch.arange(Bc) % 2).float()
