@@ -150,7 +150,12 @@ int rmcl_version(void);
 /* Tuning knobs (developer use).  key 0: bf16 GEMM tile/pipeline configuration (-1 = automatic).
  * key 1: number of CUs the persistent activation GEMMs leave to other kernels (default 8, so that RCCL's
  * channel workgroups and small side-stream kernels do not displace GEMM workgroups - at M = 64*185 the 62 x {4,12,16} tiles
- * are whole multiples of a 248-workgroup grid, so this costs nothing).                                                     */
+ * are whole multiples of a 248-workgroup grid, so this costs nothing).
+ * Further keys (csrc/api.cpp rmcl_tune_set has the list): 2 two-kernel attention backward, 3 per-GEMM weight gradients, 4 waves of the attention
+ * forward, 5 InfoNCE form, 6 skinny-GEMM form, 7 gemm_dp stagger, 8 / 9 attention-backward experiments, 10 chains sharing the chip (half-batch
+ * lanes), 11 (round 4) 0 = the UNCENTRED LayerNorm fold of round 2, 12 / 13 (round 4) stash prefetch of the backward: buffer mask / touch
+ * workgroups - measured negative, 0 by default.  These are process-global: callers that change one around a region restore it in a finally
+ * block (attack/pgd_attack_vilt.py, vilt/modules/objectives.py).                                                                          */
 int rmcl_tune_set(int key, int value);
 
 /* Optional second HIP stream: the weight-gradient GEMMs of rmcl_encoder_backward (mode FULL, bf16) then run
