@@ -148,6 +148,8 @@ class PGDAttack_moco(PGDAttack):
     def pgd_attack(self, pl_module, batch, k_modality=None):
         eng = pl_module.engine
         img_init = batch["image"][0]
+        if hasattr(img_init, "tables"):                      # decoded bytes (collate_raw_uint8): MinMaxResize on the device first
+            img_init = eng.resize_raw(img_init)
         if hasattr(img_init, "float_image"):                 # byte batch (collate_uint8): this public API returns / leaves behind images
             img_init = img_init.to(eng.device).float_image()
         pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], img_init)
@@ -194,6 +196,8 @@ class PGDAttack_bartlowtwins(PGDAttack):
     def pgd_attack(self, pl_module, batch, k_modality=None):
         eng = pl_module.engine
         img_init = batch["image"][0]
+        if hasattr(img_init, "tables"):
+            img_init = eng.resize_raw(img_init)
         if hasattr(img_init, "float_image"):
             img_init = img_init.to(eng.device).float_image()
         pb = eng.bind_batch(batch["text_ids"], batch["text_masks"], img_init, tag="bt")

@@ -113,6 +113,8 @@ def compute_itm_wpa(pl_module, batch):
     forced = getattr(pl_module, "itm_labels_override", None)            # test hook: fix the 50/50 draw
     itm_labels = forced.to(dev).float() if forced is not None else itm_labels[torch.randperm(Bn, device=dev)]
     img, fimg = batch["image"][0].to(dev), batch["false_image_0"][0].to(dev)
+    if hasattr(img, "tables"):                                          # decoded bytes (collate_raw_uint8): MinMaxResize on the device first
+        img, fimg = eng.resize_raw(img), eng.resize_raw(fimg)
     if hasattr(img, "float_image"):                                     # byte batches (collate_uint8): the mix of the two views needs pixels
         img, fimg = img.float_image(), fimg.float_image()
     images = torch.where(itm_labels.view(-1, 1, 1, 1) == 1, img, fimg)                 # :722-730

@@ -142,3 +142,33 @@ def test_training_step_on_decoded_bytes_equals_the_host_resized_batch():
         res.append((float(loss), m.engine.g32.clone(), m.proj_queue.clone()))
     assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and torch.equal(res[0][2], res[1][2])
     assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 1e-6
+
+
+def test_itm_step_on_decoded_bytes_uses_the_device_resize():
+    """The ITM + word-patch-alignment objective mixes "image" and "false_image_0" pixel by pixel (objectives.py:722-730), so both must share
+    ONE extent: collate_raw_uint8's batch-wide extent, honoured by the device resize.  Raw batches against the same batches resized on the
+    host with PIL: identical ITM / WPA losses."""
+    from rmcl_amd.vilt.datasets import RawUint8Batch
+    sizes, fsizes = [(480, 640), (640, 480), (427, 640), (375, 500)], [(375, 500), (480, 640), (640, 480), (427, 640)]
+    ocfg = O.default_config(num_layers=2, num_negative=1024, per_gpu_batchsize=4, adv_steps_img=1)
+    batch = O.synthetic_batch(ocfg, 4, 4, ragged_text=True)
+    raw, fraw = raw_batch(sizes, 21), raw_batch(fsizes, 22)
+    ext = tuple(max(a, b) for a, b in zip(raw.out_hw(), fraw.out_hw()))
+    raw, fraw = RawUint8Batch(raw.data, raw.sizes, 384, 640, ext), RawUint8Batch(fraw.data, fraw.sizes, 384, 640, ext)
+    labels = torch.tensor([1, 0, 1, 0])
+    res = []
+    for kind in ("host", "device"):
+        m, _ = make_module(ocfg, 5, "bf16", k_seed=6, itm=1)
+        m.itm_labels_override = labels
+        m.current_tasks = ["itm"]
+        b = dev_batch(dict(batch))
+        b["image"] = [raw.resized_on_host() if kind == "host" else raw]
+        b["false_image_0"] = [fraw.resized_on_host() if kind == "host" else fraw]
+        torch.manual_seed(7)                                         # (384 x 576 = 216 patches > max_image_len: the subset is drawn on the host)
+        from rmcl_amd.vilt.modules import objectives
+        m.engine.dropout_on = False
+        m.step_sync.begin_step()
+        ret = objectives.compute_itm_wpa(m, b)
+        torch.cuda.synchronize()
+        res.append((float(ret["itm_loss"]), float(ret["itm_wpa_loss"])))
+    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and abs(res[0][1] - res[1][1]) <= 1e-6 * max(abs(res[0][1]), 1e-3), res
