@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dp_kernel(GemmArgs g, int tiles_m
 bool rmcl_gemm_dp_supported(const GemmArgs& g, int a_kc, int b_kc) {
   if (!a_kc || !b_kc || g.nb1 > 1 || g.nb2 > 1 || g.splitk > 1) return false;
   if (g.N % ST_T != 0 || g.K % 32 != 0 || g.K < 64) return false;
-  if ((long)g.M * g.lda >= (1L << 31) || (long)g.N * g.ldb >= (1L << 31)) return false;
+  if ((long)g.M * g.lda >= (1L << 31) || (long)g.N * g.ldb >= (1L << 31) || (long)g.M * g.ldc >= (1L << 31)) return false;
   if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_RESIDUAL | EPI_DGELU | EPI_LNFOLD | EPI_ROWSTAT)) return false;
   if ((g.epi & EPI_RESIDUAL) && (g.epi & EPI_DGELU)) return false;
   if (g.epi & EPI_LNFOLD) {

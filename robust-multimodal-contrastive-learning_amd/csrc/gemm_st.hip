@@ -539,6 +539,7 @@ bool rmcl_gemm_st_supported(const GemmArgs& g, int a_kc, int b_kc) {
   if (g.N % ST_T != 0 || g.K % 64 != 0 || g.K < 128) return false;
   if ((long)(a_kc ? g.M : g.K) * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
   if (g.splitk > 1) return false;                                // (split-K: rmcl_launch_gemm_st_slab)
+  if ((long)g.M * g.ldc >= (1L << 31)) return false;             // (the LDS epilogue's row stores use 32-bit element offsets)
   if (!a_kc) {                                                   // [K][M] x [K][N] (weight gradients): plain or slab output only
     if (b_kc || g.M % ST_T != 0 || (g.epi & ~EPI_ACCUM)) return false;
     return true;

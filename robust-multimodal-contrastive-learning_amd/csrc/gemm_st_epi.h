@@ -143,19 +143,50 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
   // Inside the store loop every iteration was "LDS read, global load, wait, add, store": 18 serial HBM round trips per tile = 22 us of
   // epilogue behind a 176 us k-loop (tools/st_trace.py dw); one batch per chunk: 13 us.
   constexpr int NIT = (ROWS * PIECES + 255) / 256;
+  // Addresses of the epilogue, once per tile (round 4: recomputed per value group / per store they were, with the divisions by PIECES and the
+  // 64-bit pointer arithmetic, about a third of the epilogue's VALU instructions - MFMAs idle).  Image writes: row il*16 + lane%16 has the
+  // same (row & 7) for every il: one offset per j, the row block as an immediate.  Read-back + row stores: work item q = tg + 256 k ->
+  // (row, piece) = (q / PIECES, q % PIECES); 768 = ROWS3 * PIECES, so k and k + 3 differ by exactly ROWS3 rows: three (row, piece) pairs.
+  // Computed from the per-call opaque `lane`, so that they are not hoisted out of the persistent tile loop as live registers of the k-loop.
+  constexpr int RSTEP = 256 / PIECES, ROWS3 = 768 / PIECES, NT3 = (NIT + 2) / 3;
+  int woff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int r = lane & 15;
+    if constexpr (ESZ == 2) {
+      const int e8 = wn * 12 + j * 4 + (lane >> 4);          // 8-byte unit (4 bf16) in the row
+      woff[j] = r * ROWB + (((e8 >> 1) ^ (r & 7)) * 16) + (e8 & 1) * 8;
+    } else {
+      woff[j] = r * ROWB + (((wn * 12 + j * 4 + (lane >> 4)) ^ (r & 7)) * 16);
+    }
+  }
+  int rb_row[3], rb_lds[3];
+  uint32_t rb_dst[3];
+  {
+    const int tg = (wave & 3) * 64 + lane, row0 = tg / PIECES, cp0 = tg - row0 * PIECES;   // lane id inside the group
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) {
+      const int t16 = cp0 + 16 * kk, wrap = (t16 >= PIECES ? 1 : 0) + (t16 >= 2 * PIECES ? 1 : 0), cp = t16 - wrap * PIECES;
+      const int row = row0 + RSTEP * kk + wrap;              // physical chunk cp holds logical chunk cp ^ (row & 7)
+      rb_row[kk] = row;
+      rb_lds[kk] = row * ROWB + cp * 16;
+      rb_dst[kk] = (uint32_t)row * (uint32_t)g.ldc + (uint32_t)((cp ^ (row & 7)) * (16 / ESZ));
+    }
+  }
   float4 oldv[ACCPRE ? NCH : 1][ACCPRE ? NIT : 1];
   if constexpr (ACCPRE && ESZ == 4) {
-    const int tg0 = (wave & 3) * 64 + lane;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch)
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int mrow = T.m0 + wm * 96 + ch * ROWS, lim = min(ROWS, T.m_end - mrow);
+      const uint32_t cbase = (uint32_t)mrow * (uint32_t)g.ldc + (uint32_t)T.n0;
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int q = it * 256 + tg0, row = q / PIECES, cp = q - row * PIECES;
-        const int m = T.m0 + wm * 96 + ch * ROWS + row;
+        const int kk = it % 3, t3 = it / 3;
         oldv[ch][it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < ROWS * PIECES && m < T.m_end)
-          oldv[ch][it] = *reinterpret_cast<const float4*>(C + (long)m * g.ldc + T.n0 + (cp ^ (row & 7)) * 4);
+        if (rb_row[kk] + t3 * ROWS3 < lim)
+          oldv[ch][it] = *reinterpret_cast<const float4*>(C + (size_t)(cbase + (uint32_t)(t3 * ROWS3) * (uint32_t)g.ldc + rb_dst[kk]));
       }
+    }
   }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -171,48 +202,53 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       if constexpr (LNF == 1) { mean_m = rs[i].x; rstd_m = rs[i].y; }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        float v[4] = {g.alpha * acc[i][j][0] + bias[j].x, g.alpha * acc[i][j][1] + bias[j].y, g.alpha * acc[i][j][2] + bias[j].z,
-                      g.alpha * acc[i][j][3] + bias[j].w};
+        // (pairs (0, 1) / (2, 3) named here: rmcl_common.h, "Two-wide forms")
+        const f32x2 a01 = {acc[i][j][0], acc[i][j][1]}, a23 = {acc[i][j][2], acc[i][j][3]};
+        const f32x2 b01 = {bias[j].x, bias[j].y}, b23 = {bias[j].z, bias[j].w};
+        f32x2 v01, v23;
         if constexpr (LNF == 1) {
-          v[0] = fmaf(rstd_m, acc[i][j][0] - mean_m * lns[j].x, bias[j].x); v[1] = fmaf(rstd_m, acc[i][j][1] - mean_m * lns[j].y, bias[j].y);
-          v[2] = fmaf(rstd_m, acc[i][j][2] - mean_m * lns[j].z, bias[j].z); v[3] = fmaf(rstd_m, acc[i][j][3] - mean_m * lns[j].w, bias[j].w);
+          const f32x2 l01 = {lns[j].x, lns[j].y}, l23 = {lns[j].z, lns[j].w};
+          v01 = rstd_m * (a01 - mean_m * l01) + b01;
+          v23 = rstd_m * (a23 - mean_m * l23) + b23;
+        } else {
+          v01 = g.alpha * a01 + b01;
+          v23 = g.alpha * a23 + b23;
         }
         if (DROP && (epi & EPI_DROP_BWD)) {
           const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
-          drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
+          drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v01, v23);
         }
         if (AUX == ST_AUX_DGELU) {
           const uint2 u = pre[il][j];
-          v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
-          v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
+          v01 *= gelu_poly_grad2(bf2f2(u.x));
+          v23 *= gelu_poly_grad2(bf2f2(u.y));
         }
         const long ci = (long)m * g.ldc + nb + j * 16;
-        if ((epi & EPI_SAVE_PREACT) && live) st_store4<TO>(C2 + ci, v);
+        if ((epi & EPI_SAVE_PREACT) && live) {
+          const float t[4] = {v01.x, v01.y, v23.x, v23.y};
+          st_store4<TO>(C2 + ci, t);
+        }
         if (epi & EPI_GELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+          v01 = gelu_poly2(v01);
+          v23 = gelu_poly2(v23);
         }
         if (DROP && (epi & EPI_DROPOUT)) {
-          drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
+          drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v01, v23);
         }
-        if (AUX == ST_AUX_RES) { v[0] += res[il][j].x; v[1] += res[il][j].y; v[2] += res[il][j].z; v[3] += res[il][j].w; }
+        if (AUX == ST_AUX_RES) {
+          v01 += f32x2{res[il][j].x, res[il][j].y};
+          v23 += f32x2{res[il][j].z, res[il][j].w};
+        }
         if constexpr (LNF == 2) {
-          const float c0 = cen6[i], d0 = v[0] - c0, d1 = v[1] - c0, d2 = v[2] - c0, d3 = v[3] - c0;
+          const float c0 = cen6[i], d0 = v01.x - c0, d1 = v01.y - c0, d2 = v23.x - c0, d3 = v23.y - c0;
           ps1 += (d0 + d1) + (d2 + d3);
           ps2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
         // image: row il*16 + lane%16, element column wn*48 + j*16 + 4*(lane/16); 16-byte chunk index XOR (row & 7)
-        const int row = il * 16 + (lane & 15);
         if constexpr (ESZ == 2) {
-          const int e8 = wn * 12 + j * 4 + (lane >> 4);      // 8-byte unit (4 bf16) in the row
-          const int c16 = (e8 >> 1) ^ (row & 7);
-          uint2 pk;
-          pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(scratch + row * ROWB + c16 * 16 + (e8 & 1) * 8) = pk;
+          *reinterpret_cast<uint2*>(scratch + woff[j] + il * 16 * ROWB) = make_uint2(f2bf2(v01), f2bf2(v23));
         } else {
-          const int c16 = (wn * 12 + j * 4 + (lane >> 4)) ^ (row & 7);
-          *reinterpret_cast<float4*>(scratch + row * ROWB + c16 * 16) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(scratch + woff[j] + il * 16 * ROWB) = make_float4(v01.x, v01.y, v23.x, v23.y);
         }
       }
       if constexpr (LNF == 2) {                                // this wave's 48 columns of row m: sum over the 4 lane groups
@@ -225,39 +261,37 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
     ST_STAMP(5 + 4 * ch);
     __builtin_amdgcn_s_barrier();                            // the group's image of this chunk is complete
     ST_STAMP(6 + 4 * ch);
-    int tg = (wave & 3) * 64 + lane;                         // lane id inside the group
-    asm volatile("" : "+v"(tg));                             // (keeps the read-back addresses from being hoisted out of the tile loop as live registers)
+    {
+      const int mrow = T.m0 + wm * 96 + ch * ROWS, lim = min(ROWS, T.m_end - mrow);   // (uniform) first row of this group's chunk, live rows in it
+      const uint32_t cbase = (uint32_t)mrow * (uint32_t)g.ldc + (uint32_t)T.n0;
 #pragma unroll
-    for (int q0 = 0; q0 < ROWS * PIECES; q0 += 256) {
-      const int q = q0 + tg;
-      if (q < ROWS * PIECES) {
-        const int row = q / PIECES, cp = q - row * PIECES;   // physical chunk cp holds logical chunk cp ^ (row & 7)
-        const int m = T.m0 + wm * 96 + ch * ROWS + row;
-        if (m < T.m_end) {
-          const float4 w = *reinterpret_cast<const float4*>(scratch + row * ROWB + cp * 16);
-          TO* dst = C + (long)m * g.ldc + T.n0 + (cp ^ (row & 7)) * (16 / ESZ);
-          if constexpr (ESZ == 4) {
-            float4 o = w;
-            if constexpr (ACCPRE) {
-              const float4 old = oldv[ch][q0 / 256];
-              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-            } else if (epi & EPI_ACCUM) {
-              const float4 old = *reinterpret_cast<const float4*>(dst);
-              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      for (int t3 = 0; t3 < NT3; ++t3)
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          if (kk + 3 * t3 < NIT && rb_row[kk] + t3 * ROWS3 < lim) {
+            const float4 w = *reinterpret_cast<const float4*>(scratch + rb_lds[kk] + t3 * ROWS3 * ROWB);
+            const size_t off = (size_t)(cbase + (uint32_t)(t3 * ROWS3) * (uint32_t)g.ldc + rb_dst[kk]);
+            TO* dst = C + off;
+            if constexpr (ESZ == 4) {
+              float4 o = w;
+              if constexpr (ACCPRE) {
+                const float4 old = oldv[ch][kk + 3 * t3];
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+              } else if (epi & EPI_ACCUM) {
+                const float4 old = *reinterpret_cast<const float4*>(dst);
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+              }
+              *reinterpret_cast<float4*>(dst) = o;
+              if constexpr (LNF == 2) {                        // bf16 copy of the (centred) residual stream: the next GEMM's A operand
+                const float c0 = rowstat[wm * 96 + ch * ROWS + rb_row[kk] + t3 * ROWS3];
+                const uint2 pk = make_uint2(f2bf2(f32x2{o.x, o.y} - c0), f2bf2(f32x2{o.z, o.w} - c0));
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C2) + off) = pk;
+              }
+            } else {
+              *reinterpret_cast<float4*>(dst) = w;
             }
-            *reinterpret_cast<float4*>(dst) = o;
-            if constexpr (LNF == 2) {                          // bf16 copy of the (centred) residual stream: the next GEMM's A operand
-              const float c0 = rowstat[wm * 96 + ch * ROWS + row];
-              uint2 pk;
-              pk.x = (uint32_t)f2bf(o.x - c0) | ((uint32_t)f2bf(o.y - c0) << 16);
-              pk.y = (uint32_t)f2bf(o.z - c0) | ((uint32_t)f2bf(o.w - c0) << 16);
-              *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C2) + (long)m * g.ldc + T.n0 + (cp ^ (row & 7)) * 4) = pk;
-            }
-          } else {
-            *reinterpret_cast<float4*>(dst) = w;
           }
         }
-      }
     }
     ST_STAMP(7 + 4 * ch);
     __builtin_amdgcn_s_barrier();                            // image consumed: the next chunk may overwrite it

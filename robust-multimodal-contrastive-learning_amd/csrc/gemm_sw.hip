@@ -370,6 +370,32 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
 #pragma unroll
       for (int i = 0; i < 6; ++i) rs6[i] = *reinterpret_cast<const float2*>(rowstat + 2 * (wm * 96 + i * 16 + (lane & 15)));
     }
+    // Addresses of the epilogue, once per tile (they were recomputed per value group / per store: with the integer divisions and 64-bit
+    // pointer arithmetic about a third of the epilogue's VALU instructions, MFMAs idle).  Image writes: row il*16 + lane%16 has the same
+    // (row & 7) for every il, so one offset per (column half, j) and the row block as an immediate.  Read-back + row stores: work item
+    // q = tg + 256 k -> (row, piece) = (q / 48, q % 48); 256 = 5 * 48 + 16, so k and k + 3 differ by exactly 16 rows: three (row, piece) pairs.
+    int woff[2][3];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int r = lane & 15, e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);     // 8-byte unit (4 bf16) in the 384-column row
+        woff[hb][j] = r * ROWB + (((e8 >> 1) ^ (r & 7)) * 16) + (e8 & 1) * 8;
+        asm volatile("" : "+v"(woff[hb][j]));
+      }
+    int rb_row[3], rb_lds[3];
+    uint32_t rb_dst[3];
+    {
+      const int tg = (wave & 3) * 64 + lane, row0 = tg / PIECES, cp0 = tg - row0 * PIECES;
+#pragma unroll
+      for (int kk = 0; kk < 3; ++kk) {
+        const int t16 = cp0 + 16 * kk, wrap = t16 >= PIECES ? 1 : 0, cp = t16 - wrap * PIECES, row = row0 + 5 * kk + wrap;
+        rb_row[kk] = row;
+        rb_lds[kk] = row * ROWB + cp * 16;
+        rb_dst[kk] = (uint32_t)row * (uint32_t)g.ldc + (uint32_t)((cp ^ (row & 7)) * 8);
+        asm volatile("" : "+v"(rb_row[kk]), "+v"(rb_lds[kk]), "+v"(rb_dst[kk]));
+      }
+    }
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
 #pragma unroll
@@ -400,49 +426,47 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
 #pragma unroll
         for (int il = 0; il < 3; ++il) {
           const int i = ch * 3 + il;
-          const int row = il * 16 + (lane & 15);
           float mean_m = 0.f, rstd_m = 1.f;
           if constexpr (LNF == 1) { mean_m = rs6[i].x; rstd_m = rs6[i].y; }
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
+            // (pairs (0, 1) / (2, 3) named here: rmcl_common.h, "Two-wide forms")
             const f32x4 av = acc[i][hb * 3 + j];
-            float v[4] = {g.alpha * av[0] + bias[j].x, g.alpha * av[1] + bias[j].y, g.alpha * av[2] + bias[j].z, g.alpha * av[3] + bias[j].w};
+            const f32x2 a01 = {av[0], av[1]}, a23 = {av[2], av[3]};
+            const f32x2 b01 = {bias[j].x, bias[j].y}, b23 = {bias[j].z, bias[j].w};
+            f32x2 v01, v23;
             if constexpr (LNF == 1) {
-              v[0] = fmaf(rstd_m, av[0] - mean_m * lns[j].x, bias[j].x); v[1] = fmaf(rstd_m, av[1] - mean_m * lns[j].y, bias[j].y);
-              v[2] = fmaf(rstd_m, av[2] - mean_m * lns[j].z, bias[j].z); v[3] = fmaf(rstd_m, av[3] - mean_m * lns[j].w, bias[j].w);
+              const f32x2 l01 = {lns[j].x, lns[j].y}, l23 = {lns[j].z, lns[j].w};
+              v01 = rstd_m * (a01 - mean_m * l01) + b01;
+              v23 = rstd_m * (a23 - mean_m * l23) + b23;
+            } else {
+              v01 = g.alpha * a01 + b01;
+              v23 = g.alpha * a23 + b23;
             }
             if (AUX == SW_AUX_DGELU) {
               const uint2 u = pre[il][j];
-              v[0] *= gelu_poly_grad(__uint_as_float(u.x << 16)); v[1] *= gelu_poly_grad(__uint_as_float(u.x & 0xffff0000u));
-              v[2] *= gelu_poly_grad(__uint_as_float(u.y << 16)); v[3] *= gelu_poly_grad(__uint_as_float(u.y & 0xffff0000u));
+              v01 *= gelu_poly_grad2(bf2f2(u.x));
+              v23 *= gelu_poly_grad2(bf2f2(u.y));
             }
             if constexpr (DROP) {
               if (epi & EPI_DROP_BWD) {                              // mask of the forward's hidden dropout, indexed like the stash
                 const uint32_t di = (uint32_t)((long)(mb + i * 16) * g.ld_aux + nb + j * 16);
-                drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
+                drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v01, v23);
               }
             }
-            const int e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);        // 8-byte unit (4 bf16) in the 384-column row
-            const int off = row * ROWB + (((e8 >> 1) ^ (row & 7)) * 16) + (e8 & 1) * 8;
-            if (stash) {
-              uint2 pk;
-              pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-              pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-              *reinterpret_cast<uint2*>(img + IMG + off) = pk;
-            }
+            const int off = woff[hb][j] + il * 16 * ROWB;
+            if (stash) *reinterpret_cast<uint2*>(img + IMG + off) = make_uint2(f2bf2(v01), f2bf2(v23));
             if (epi & EPI_GELU) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = gelu_poly(v[r]);
+              v01 = gelu_poly2(v01);
+              v23 = gelu_poly2(v23);
             }
             if constexpr (DROP) {
               if (epi & EPI_DROPOUT) {
                 const uint32_t ci = (uint32_t)((long)(mb + i * 16) * g.ldc + nb + j * 16);
-                drop_scale4(g.drop_seed, ci, g.drop_thresh, g.drop_inv_keep, v[0], v[1], v[2], v[3]);
+                drop_scale4(g.drop_seed, ci, g.drop_thresh, g.drop_inv_keep, v01, v23);
               }
             }
-            uint2 pk;
-            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            const uint2 pk = make_uint2(f2bf2(v01), f2bf2(v23));
             *reinterpret_cast<uint2*>(img + off) = pk;
           }
         }
@@ -455,18 +479,19 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
           for (int u = 0; u < 3; ++u) sw_stage_aux(ax, 1, u, aux_area, wave, lane);
         }
       }
-      int tg = (wave & 3) * 64 + lane;
-      asm volatile("" : "+v"(tg));
+      {
+        const int mrow = m0 + wm * 96 + ch * ROWS, lim = m_end - mrow;          // (uniform) first row of this group's chunk, live rows in it
+        const uint32_t cbase = (uint32_t)mrow * (uint32_t)g.ldc + (uint32_t)n0;
 #pragma unroll
-      for (int q0 = 0; q0 < ROWS * PIECES; q0 += 256) {
-        const int q = q0 + tg;
-        const int row = q / PIECES, cp = q - row * PIECES;
-        const int m = m0 + wm * 96 + ch * ROWS + row;
-        if (m < m_end) {
-          const long dst = (long)m * g.ldc + n0 + (cp ^ (row & 7)) * 8;
-          *reinterpret_cast<float4*>(C + dst) = *reinterpret_cast<const float4*>(img + row * ROWB + cp * 16);
-          if (stash) *reinterpret_cast<float4*>(C2 + dst) = *reinterpret_cast<const float4*>(img + IMG + row * ROWB + cp * 16);
-        }
+        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            if (rb_row[kk] + 16 * t3 < lim) {
+              const size_t dst = (size_t)(cbase + (uint32_t)(16 * t3) * (uint32_t)g.ldc + rb_dst[kk]);
+              *reinterpret_cast<float4*>(C + dst) = *reinterpret_cast<const float4*>(img + rb_lds[kk] + t3 * 16 * ROWB);
+              if (stash) *reinterpret_cast<float4*>(C2 + dst) = *reinterpret_cast<const float4*>(img + IMG + rb_lds[kk] + t3 * 16 * ROWB);
+            }
+          }
       }
       if constexpr (AUX_LDS) {
         // chunk 1's aux DMA (3 instructions per wave) was issued BEFORE this chunk's 9 row stores and vmcnt retires in issue order:
@@ -528,6 +553,7 @@ bool rmcl_gemm_sw_supported(const GemmArgs& g, int a_kc, int b_kc) {
   if (!a_kc || g.nb1 > 1 || g.nb2 > 1 || g.splitk > 1) return false;
   if (g.N % 384 != 0 || g.K % 64 != 0 || g.K < 128) return false;
   if ((long)g.M * g.lda >= (1L << 31) || (long)(b_kc ? g.N : g.K) * g.ldb >= (1L << 31)) return false;
+  if ((long)g.M * g.ldc >= (1L << 31)) return false;                          // (the bf16 epilogue's row stores use 32-bit element offsets)
   if (g.epi & ~(EPI_BIAS | EPI_GELU | EPI_SAVE_PREACT | EPI_DGELU | EPI_LNFOLD | EPI_DROPOUT | EPI_DROP_BWD)) return false;   // (residual epilogue: 72 more live registers spill; N = 768 anyway)
   if ((g.epi & EPI_DROP_BWD) && !(g.epi & EPI_DGELU)) return false;          // (dropout epilogues: bf16 outputs only - the router checks dt_out)
   if (g.epi & EPI_LNFOLD) {

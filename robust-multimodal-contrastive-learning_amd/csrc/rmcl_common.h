@@ -72,6 +72,40 @@ __device__ __forceinline__ float gelu_poly_grad(float x) {
   const float cdf = fmaf(0.5f, erf_poly(x * 0.70710678118654752f), 0.5f);
   return fmaf(x * 0.39894228040143268f, __expf(-0.5f * x * x), cdf);
 }
+// Two-wide forms of the same arithmetic (identical operations per component, so bit-identical results): the epilogues hold four consecutive
+// columns per accumulator and name the pairs (0, 1) / (2, 3) themselves - left to the SLP vectoriser the pairs came out as (0, 2) / (1, 3), which
+// cost six register moves in and four fix-up instructions out per four values around v_pk_fma_f32 / v_cvt_pk_bf16_f32 (round 4, fc1's epilogue:
+// 2 400 VALU instructions per lane and tile with the MFMAs idle).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 erf_poly2(f32x2 y) {
+  y.x = __builtin_amdgcn_fmed3f(y.x, -3.2f, 3.2f);
+  y.y = __builtin_amdgcn_fmed3f(y.y, -3.2f, 3.2f);
+  const f32x2 s = y * y;
+  f32x2 p = 2.517738551e-08f;
+  p = p * s + -1.349064178e-06f;
+  p = p * s + 3.169231059e-05f;
+  p = p * s + -4.330864467e-04f;
+  p = p * s + 3.867269494e-03f;
+  p = p * s + -2.412052080e-02f;
+  p = p * s + 1.096963063e-01f;
+  p = p * s + -3.744460344e-01f;
+  p = p * s + 1.128110409e+00f;
+  return p * y;
+}
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+  const f32x2 h = 0.5f * x;
+  return h * erf_poly2(x * 0.70710678118654752f) + h;
+}
+__device__ __forceinline__ f32x2 gelu_poly_grad2(f32x2 x) {
+  const f32x2 cdf = 0.5f * erf_poly2(x * 0.70710678118654752f) + 0.5f;
+  const f32x2 q = -0.5f * x * x;
+  const f32x2 e = {__expf(q.x), __expf(q.y)};
+  return (x * 0.39894228040143268f) * e + cdf;
+}
+// two fp32 -> one dword of two bf16 (RNE; v_cvt_pk_bf16_f32)
+typedef __bf16 rmcl_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f2bf2(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rmcl_bf16x2)); }
+__device__ __forceinline__ f32x2 bf2f2(uint32_t u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 __device__ __forceinline__ float gelu_fast(float x) {
   float c, e;
   gelu_fast_parts(x, c, e);
@@ -110,6 +144,12 @@ __device__ __forceinline__ void drop_scale4(uint32_t seed, uint32_t idx, uint32_
   v1 *= (h0 >> 16) >= t ? inv_keep : 0.f;
   v2 *= (h1 & 0xffffu) >= t ? inv_keep : 0.f;
   v3 *= (h1 >> 16) >= t ? inv_keep : 0.f;
+}
+__device__ __forceinline__ void drop_scale4(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep, f32x2& v01, f32x2& v23) {
+  float t0 = v01.x, t1 = v01.y, t2 = v23.x, t3 = v23.y;
+  drop_scale4(seed, idx, thresh, inv_keep, t0, t1, t2, t3);
+  v01 = f32x2{t0, t1};
+  v23 = f32x2{t2, t3};
 }
 enum { DROP_SITE_PROJ = 0, DROP_SITE_HIDDEN = 1, DROP_SITE_FC2 = 2, DROP_SITE_TEXT = 3, DROP_SITE_IMAGE = 4 };
 
