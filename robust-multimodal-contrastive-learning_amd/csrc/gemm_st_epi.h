@@ -202,53 +202,34 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       if constexpr (LNF == 1) { mean_m = rs[i].x; rstd_m = rs[i].y; }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        // (pairs (0, 1) / (2, 3) named here: rmcl_common.h, "Two-wide forms")
-        const f32x2 a01 = {acc[i][j][0], acc[i][j][1]}, a23 = {acc[i][j][2], acc[i][j][3]};
-        const f32x2 b01 = {bias[j].x, bias[j].y}, b23 = {bias[j].z, bias[j].w};
-        f32x2 v01, v23;
-        if constexpr (LNF == 1) {
-          const f32x2 l01 = {lns[j].x, lns[j].y}, l23 = {lns[j].z, lns[j].w};
-          v01 = rstd_m * (a01 - mean_m * l01) + b01;
-          v23 = rstd_m * (a23 - mean_m * l23) + b23;
-        } else {
-          v01 = g.alpha * a01 + b01;
-          v23 = g.alpha * a23 + b23;
-        }
+        // (all four values of the accumulator at once: rmcl_common.h, "Four-wide forms")
+        const f32x4 av = acc[i][j], bv = f4v(bias[j]);
+        f32x4 v;
+        if constexpr (LNF == 1) v = rstd_m * (av - mean_m * f4v(lns[j])) + bv;
+        else v = g.alpha * av + bv;
         if (DROP && (epi & EPI_DROP_BWD)) {
           const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
-          drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v01, v23);
+          drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
         }
-        if (AUX == ST_AUX_DGELU) {
-          const uint2 u = pre[il][j];
-          v01 *= gelu_poly_grad2(bf2f2(u.x));
-          v23 *= gelu_poly_grad2(bf2f2(u.y));
-        }
+        if (AUX == ST_AUX_DGELU) v *= gelu_poly_grad4(bf2f4(pre[il][j]));
         const long ci = (long)m * g.ldc + nb + j * 16;
         if ((epi & EPI_SAVE_PREACT) && live) {
-          const float t[4] = {v01.x, v01.y, v23.x, v23.y};
+          const float t[4] = {v.x, v.y, v.z, v.w};
           st_store4<TO>(C2 + ci, t);
         }
-        if (epi & EPI_GELU) {
-          v01 = gelu_poly2(v01);
-          v23 = gelu_poly2(v23);
-        }
-        if (DROP && (epi & EPI_DROPOUT)) {
-          drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v01, v23);
-        }
-        if (AUX == ST_AUX_RES) {
-          v01 += f32x2{res[il][j].x, res[il][j].y};
-          v23 += f32x2{res[il][j].z, res[il][j].w};
-        }
+        if (epi & EPI_GELU) v = gelu_poly4(v);
+        if (DROP && (epi & EPI_DROPOUT)) drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v);
+        if (AUX == ST_AUX_RES) v += f4v(res[il][j]);
         if constexpr (LNF == 2) {
-          const float c0 = cen6[i], d0 = v01.x - c0, d1 = v01.y - c0, d2 = v23.x - c0, d3 = v23.y - c0;
+          const float c0 = cen6[i], d0 = v.x - c0, d1 = v.y - c0, d2 = v.z - c0, d3 = v.w - c0;
           ps1 += (d0 + d1) + (d2 + d3);
           ps2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
         // image: row il*16 + lane%16, element column wn*48 + j*16 + 4*(lane/16); 16-byte chunk index XOR (row & 7)
         if constexpr (ESZ == 2) {
-          *reinterpret_cast<uint2*>(scratch + woff[j] + il * 16 * ROWB) = make_uint2(f2bf2(v01), f2bf2(v23));
+          *reinterpret_cast<uint2*>(scratch + woff[j] + il * 16 * ROWB) = f2bf4(v);
         } else {
-          *reinterpret_cast<float4*>(scratch + woff[j] + il * 16 * ROWB) = make_float4(v01.x, v01.y, v23.x, v23.y);
+          *reinterpret_cast<float4*>(scratch + woff[j] + il * 16 * ROWB) = make_float4(v.x, v.y, v.z, v.w);
         }
       }
       if constexpr (LNF == 2) {                                // this wave's 48 columns of row m: sum over the 4 lane groups

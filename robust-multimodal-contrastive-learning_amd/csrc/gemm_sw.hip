@@ -326,7 +326,15 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     sw_ktile<B_KC, true>(acc, c, last_cur, nullptr, 0);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();
-  if constexpr (AUX_LDS) __builtin_amdgcn_s_barrier();         // every wave's aux DMA has landed
+  if constexpr (AUX_LDS) {
+    __builtin_amdgcn_s_barrier();                              // every wave's aux DMA has landed, every wave is done with the last k-tile
+    // chunk 1 of the aux operand goes into the buffer the last k-tile was read from, NOW: each chunk's output image is written IN PLACE
+    // over its aux image (a lane reads exactly the 8-byte units it writes), so chunk 0 lives in one operand buffer and chunk 1 in the
+    // other and this DMA has the whole of chunk 0 to land (fetched after chunk 0's barrier it cost ~4 us of HBM latency per tile:
+    // tools/st_trace.py fc2dx, "chunk0: barrier + read-back + stores issued" 7.4 us against 3.3 for chunk 1)
+#pragma unroll
+    for (int u = 0; u < 3; ++u) sw_stage_aux(ax, 1, u, last_cur, wave, lane);
+  }
 
   SW_STAMP(2);
   // epilogue (order as gemm_st.hip: alpha, bias, gelu'(aux), stash, gelu, residual)
@@ -340,9 +348,9 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     // group: 48 rows x 768 B images of the output and, when stashed, of the pre-activation; 16-byte chunk c of row r at
     // c ^ (r & 7).  (Both groups are barrier-aligned here; every wave executes the same 4 barriers.)
     constexpr int ROWB = 768, PIECES = 48, ROWS = 48, IMG = ROWS * ROWB;   // 36 KiB per image
-    // (AUX_LDS: no stash image exists - the two output images live in the buffer the last k-tile was read from, the aux
-    // image in the other one)
-    char* img = AUX_LDS ? last_cur + wm * IMG : smem + wm * (2 * IMG);
+    // (AUX_LDS: no stash image exists - chunk ch's aux image AND, in place, its output image live in one operand buffer each:
+    // chunk 0 in the one that was idle during the last k-tile, chunk 1 in the one the last k-tile was read from)
+    char* img0 = AUX_LDS ? aux_area + wm * IMG : smem + wm * (2 * IMG);
     const bool stash = !AUX_LDS && (epi & EPI_SAVE_PREACT) != 0;
     float* rowstat = reinterpret_cast<float*>(smem + SW_LDS);  // LNF: 192 x (mean, rstd), beyond the two operand buffers (filled at kernel start)
     // per-column vectors of both column halves and (LNF) the statistics of this lane's six rows: fetched ONCE, ahead of the chunk
@@ -398,6 +406,8 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     }
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
+      char* aux_ch = ch == 0 ? aux_area : last_cur;           // (AUX_LDS only)
+      char* img = AUX_LDS ? aux_ch + wm * IMG : img0;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
           for (int j = 0; j < 3; ++j) {
             if constexpr (AUX_LDS) {
               const int e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);
-              pre[il][j] = *reinterpret_cast<const uint2*>(aux_area + arow * ROWB + (((e8 >> 1) ^ (arow & 7)) * 16) + (e8 & 1) * 8);
+              pre[il][j] = *reinterpret_cast<const uint2*>(aux_ch + arow * ROWB + (((e8 >> 1) ^ (arow & 7)) * 16) + (e8 & 1) * 8);
             } else if (AUX == SW_AUX_DGELU) {
               pre[il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
             }
@@ -430,55 +440,34 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
           if constexpr (LNF == 1) { mean_m = rs6[i].x; rstd_m = rs6[i].y; }
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            // (pairs (0, 1) / (2, 3) named here: rmcl_common.h, "Two-wide forms")
-            const f32x4 av = acc[i][hb * 3 + j];
-            const f32x2 a01 = {av[0], av[1]}, a23 = {av[2], av[3]};
-            const f32x2 b01 = {bias[j].x, bias[j].y}, b23 = {bias[j].z, bias[j].w};
-            f32x2 v01, v23;
-            if constexpr (LNF == 1) {
-              const f32x2 l01 = {lns[j].x, lns[j].y}, l23 = {lns[j].z, lns[j].w};
-              v01 = rstd_m * (a01 - mean_m * l01) + b01;
-              v23 = rstd_m * (a23 - mean_m * l23) + b23;
-            } else {
-              v01 = g.alpha * a01 + b01;
-              v23 = g.alpha * a23 + b23;
-            }
-            if (AUX == SW_AUX_DGELU) {
-              const uint2 u = pre[il][j];
-              v01 *= gelu_poly_grad2(bf2f2(u.x));
-              v23 *= gelu_poly_grad2(bf2f2(u.y));
-            }
+            // (all four values of the accumulator at once: rmcl_common.h, "Four-wide forms")
+            const f32x4 av = acc[i][hb * 3 + j], bv = f4v(bias[j]);
+            f32x4 v;
+            if constexpr (LNF == 1) v = rstd_m * (av - mean_m * f4v(lns[j])) + bv;
+            else v = g.alpha * av + bv;
+            if (AUX == SW_AUX_DGELU) v *= gelu_poly_grad4(bf2f4(pre[il][j]));
             if constexpr (DROP) {
               if (epi & EPI_DROP_BWD) {                              // mask of the forward's hidden dropout, indexed like the stash
                 const uint32_t di = (uint32_t)((long)(mb + i * 16) * g.ld_aux + nb + j * 16);
-                drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v01, v23);
+                drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
               }
             }
             const int off = woff[hb][j] + il * 16 * ROWB;
-            if (stash) *reinterpret_cast<uint2*>(img + IMG + off) = make_uint2(f2bf2(v01), f2bf2(v23));
-            if (epi & EPI_GELU) {
-              v01 = gelu_poly2(v01);
-              v23 = gelu_poly2(v23);
-            }
+            if (stash) *reinterpret_cast<uint2*>(img + IMG + off) = f2bf4(v);
+            if (epi & EPI_GELU) v = gelu_poly4(v);
             if constexpr (DROP) {
               if (epi & EPI_DROPOUT) {
                 const uint32_t ci = (uint32_t)((long)(mb + i * 16) * g.ldc + nb + j * 16);
-                drop_scale4(g.drop_seed, ci, g.drop_thresh, g.drop_inv_keep, v01, v23);
+                drop_scale4(g.drop_seed, ci, g.drop_thresh, g.drop_inv_keep, v);
               }
             }
-            const uint2 pk = make_uint2(f2bf2(v01), f2bf2(v23));
+            const uint2 pk = f2bf4(v);
             *reinterpret_cast<uint2*>(img + off) = pk;
           }
         }
       }
       SW_STAMP(4 + 3 * ch);
       __builtin_amdgcn_s_barrier();                          // the group's images of this chunk are complete
-      if constexpr (AUX_LDS) {                                 // (both groups are past their aux reads of chunk 0: fetch chunk 1)
-        if (ch == 0) {
-#pragma unroll
-          for (int u = 0; u < 3; ++u) sw_stage_aux(ax, 1, u, aux_area, wave, lane);
-        }
-      }
       {
         const int mrow = m0 + wm * 96 + ch * ROWS, lim = m_end - mrow;          // (uniform) first row of this group's chunk, live rows in it
         const uint32_t cbase = (uint32_t)mrow * (uint32_t)g.ldc + (uint32_t)n0;

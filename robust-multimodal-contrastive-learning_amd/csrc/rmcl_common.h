@@ -108,9 +108,43 @@ __device__ __forceinline__ f32x2 gelu_poly_grad2(f32x2 x) {
   const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
   return (x * 0.39894228040143268f) * e + phi_poly2(x);
 }
+// Four-wide forms: the same operations again, written on all four values of an accumulator at once so that every polynomial step is
+// issued for the pair (0, 1) and then for the pair (2, 3) - two INDEPENDENT v_pk_fma_f32 chains interleaved.  A dependent v_pk_fma_f32
+// cannot issue back to back (the compiler pads one chain with s_nop), and in the epilogue a wave has its SIMD to itself (the other
+// wave group is one barrier away, storing): one chain after the other ran at ~8 cycles per instruction (tools/st_trace.py fc1: 2.7 us
+// for the 820 VALU instructions of a chunk).
+__device__ __forceinline__ f32x4 phi_poly4(f32x4 x) {
+  f32x4 xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, -RMCL_PHI_CLAMP, RMCL_PHI_CLAMP);
+  xc.y = __builtin_amdgcn_fmed3f(x.y, -RMCL_PHI_CLAMP, RMCL_PHI_CLAMP);
+  xc.z = __builtin_amdgcn_fmed3f(x.z, -RMCL_PHI_CLAMP, RMCL_PHI_CLAMP);
+  xc.w = __builtin_amdgcn_fmed3f(x.w, -RMCL_PHI_CLAMP, RMCL_PHI_CLAMP);
+  const f32x4 s = xc * xc;
+  f32x4 q = RMCL_PHI_Q8;
+  q = q * s + RMCL_PHI_Q7;
+  q = q * s + RMCL_PHI_Q6;
+  q = q * s + RMCL_PHI_Q5;
+  q = q * s + RMCL_PHI_Q4;
+  q = q * s + RMCL_PHI_Q3;
+  q = q * s + RMCL_PHI_Q2;
+  q = q * s + RMCL_PHI_Q1;
+  q = q * s + RMCL_PHI_Q0;
+  return xc * q + 0.5f;
+}
+__device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) { return x * phi_poly4(x); }
+__device__ __forceinline__ f32x4 gelu_poly_grad4(f32x4 x) {
+  const f32x4 t = (x * -0.72134752044448170f) * x;
+  const f32x4 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y), __builtin_amdgcn_exp2f(t.z), __builtin_amdgcn_exp2f(t.w)};
+  return (x * 0.39894228040143268f) * e + phi_poly4(x);
+}
 // two fp32 -> one dword of two bf16 (RNE; v_cvt_pk_bf16_f32)
 typedef __bf16 rmcl_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t f2bf2(f32x2 v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rmcl_bf16x2)); }
+__device__ __forceinline__ uint2 f2bf4(f32x4 v) { return make_uint2(f2bf2(f32x2{v.x, v.y}), f2bf2(f32x2{v.z, v.w})); }
+__device__ __forceinline__ f32x4 bf2f4(uint2 u) {
+  return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 f4v(float4 a) { return f32x4{a.x, a.y, a.z, a.w}; }
 __device__ __forceinline__ f32x2 bf2f2(uint32_t u) { return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 __device__ __forceinline__ float gelu_fast(float x) {
   float c, e;
@@ -156,6 +190,11 @@ __device__ __forceinline__ void drop_scale4(uint32_t seed, uint32_t idx, uint32_
   drop_scale4(seed, idx, thresh, inv_keep, t0, t1, t2, t3);
   v01 = f32x2{t0, t1};
   v23 = f32x2{t2, t3};
+}
+__device__ __forceinline__ void drop_scale4(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep, f32x4& v) {
+  float t0 = v.x, t1 = v.y, t2 = v.z, t3 = v.w;
+  drop_scale4(seed, idx, thresh, inv_keep, t0, t1, t2, t3);
+  v = f32x4{t0, t1, t2, t3};
 }
 enum { DROP_SITE_PROJ = 0, DROP_SITE_HIDDEN = 1, DROP_SITE_FC2 = 2, DROP_SITE_TEXT = 3, DROP_SITE_IMAGE = 4 };
 
