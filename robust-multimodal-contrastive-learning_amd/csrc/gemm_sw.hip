@@ -13,6 +13,7 @@
 //        P4: rows-hi x B0   (reads B0 6)           -
 //     every unit is staged >= 2 phases after the last read of the buffer it overwrites and waited for (counted vmcnt(3):
 //     only the youngest unit may be in flight) one phase before its first read.
+#include <type_traits>
 #include "rmcl_common.h"
 #include "kernels.h"
 
@@ -404,93 +405,112 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
         asm volatile("" : "+v"(rb_row[kk]), "+v"(rb_lds[kk]), "+v"(rb_dst[kk]));
       }
     }
+    // The chunk loop, once per (GELU, stash) combination and chosen here: tested per value group inside the loops the two flags cost a scalar
+    // branch + mask set-up per four values and cut the loop body into basic blocks that each re-materialised the polynomial's constants
+    // (~600 scalar instructions per tile, which a wave that has its SIMD to itself issues one at a time like the VALU ones).
+    auto chunk_loop = [&](auto gelu_c, auto stash_c) {
+      constexpr bool GELU = decltype(gelu_c)::value, STASH = decltype(stash_c)::value;
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      char* aux_ch = ch == 0 ? aux_area : last_cur;           // (AUX_LDS only)
-      char* img = AUX_LDS ? aux_ch + wm * IMG : img0;
+      for (int ch = 0; ch < 2; ++ch) {
+        char* aux_ch = ch == 0 ? aux_area : last_cur;           // (AUX_LDS only)
+        char* img = AUX_LDS ? aux_ch + wm * IMG : img0;
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
-        float4 bias_l[3];
-        if constexpr (!HOIST) {
+        for (int hb = 0; hb < 2; ++hb) {
+          const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
+          float4 bias_l[3];
+          if constexpr (!HOIST) {
 #pragma unroll
-          for (int j = 0; j < 3; ++j) bias_l[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        auto& bias = HOIST ? bias2[HOIST ? hb : 0] : bias_l;
-        auto& lns = lns2[hb];
-        uint2 pre[AUX == SW_AUX_DGELU ? 3 : 1][3];
-#pragma unroll
-        for (int il = 0; il < 3; ++il) {
-          const long mr = min(mb + (ch * 3 + il) * 16, g.M - 1);
-          const int arow = wm * 48 + il * 16 + (lane & 15);      // row of the aux image
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            if constexpr (AUX_LDS) {
-              const int e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);
-              pre[il][j] = *reinterpret_cast<const uint2*>(aux_ch + arow * ROWB + (((e8 >> 1) ^ (arow & 7)) * 16) + (e8 & 1) * 8);
-            } else if (AUX == SW_AUX_DGELU) {
-              pre[il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
-            }
+            for (int j = 0; j < 3; ++j) bias_l[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
-        }
+          auto& bias = HOIST ? bias2[HOIST ? hb : 0] : bias_l;
+          auto& lns = lns2[hb];
+          uint2 pre[AUX == SW_AUX_DGELU ? 3 : 1][3];
 #pragma unroll
-        for (int il = 0; il < 3; ++il) {
-          const int i = ch * 3 + il;
-          float mean_m = 0.f, rstd_m = 1.f;
-          if constexpr (LNF == 1) { mean_m = rs6[i].x; rstd_m = rs6[i].y; }
+          for (int il = 0; il < 3; ++il) {
+            const long mr = min(mb + (ch * 3 + il) * 16, g.M - 1);
+            const int arow = wm * 48 + il * 16 + (lane & 15);      // row of the aux image
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            // (all four values of the accumulator at once: rmcl_common.h, "Four-wide forms")
-            const f32x4 av = acc[i][hb * 3 + j], bv = f4v(bias[j]);
-            f32x4 v;
-            if constexpr (LNF == 1) v = rstd_m * (av - mean_m * f4v(lns[j])) + bv;
-            else v = g.alpha * av + bv;
-            if (AUX == SW_AUX_DGELU) v *= gelu_poly_grad4(bf2f4(pre[il][j]));
-            if constexpr (DROP) {
-              if (epi & EPI_DROP_BWD) {                              // mask of the forward's hidden dropout, indexed like the stash
-                const uint32_t di = (uint32_t)((long)(mb + i * 16) * g.ld_aux + nb + j * 16);
-                drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
+            for (int j = 0; j < 3; ++j) {
+              if constexpr (AUX_LDS) {
+                const int e8 = hb * 48 + wn * 12 + j * 4 + (lane >> 4);
+                pre[il][j] = *reinterpret_cast<const uint2*>(aux_ch + arow * ROWB + (((e8 >> 1) ^ (arow & 7)) * 16) + (e8 & 1) * 8);
+              } else if (AUX == SW_AUX_DGELU) {
+                pre[il][j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(g.aux) + mr * g.ld_aux + nb + j * 16);
               }
             }
-            const int off = woff[hb][j] + il * 16 * ROWB;
-            if (stash) *reinterpret_cast<uint2*>(img + IMG + off) = f2bf4(v);
-            if (epi & EPI_GELU) v = gelu_poly4(v);
-            if constexpr (DROP) {
-              if (epi & EPI_DROPOUT) {
-                const uint32_t ci = (uint32_t)((long)(mb + i * 16) * g.ldc + nb + j * 16);
-                drop_scale4(g.drop_seed, ci, g.drop_thresh, g.drop_inv_keep, v);
+          }
+#pragma unroll
+          for (int il = 0; il < 3; ++il) {
+            const int i = ch * 3 + il;
+            float mean_m = 0.f, rstd_m = 1.f;
+            if constexpr (LNF == 1) { mean_m = rs6[i].x; rstd_m = rs6[i].y; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              // (all four values of the accumulator at once: rmcl_common.h, "Four-wide forms")
+              const f32x4 av = acc[i][hb * 3 + j], bv = f4v(bias[j]);
+              f32x4 v;
+              if constexpr (LNF == 1) v = rstd_m * (av - mean_m * f4v(lns[j])) + bv;
+              else v = g.alpha * av + bv;
+              if (AUX == SW_AUX_DGELU) v *= gelu_poly_grad4(bf2f4(pre[il][j]));
+              if constexpr (DROP) {
+                if (epi & EPI_DROP_BWD) {                              // mask of the forward's hidden dropout, indexed like the stash
+                  const uint32_t di = (uint32_t)((long)(mb + i * 16) * g.ld_aux + nb + j * 16);
+                  drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
+                }
               }
+              const int off = woff[hb][j] + il * 16 * ROWB;
+              if constexpr (STASH) *reinterpret_cast<uint2*>(img + IMG + off) = f2bf4(v);
+              if constexpr (GELU) v = gelu_poly4(v);
+              if constexpr (DROP) {
+                if (epi & EPI_DROPOUT) {
+                  const uint32_t ci = (uint32_t)((long)(mb + i * 16) * g.ldc + nb + j * 16);
+                  drop_scale4(g.drop_seed, ci, g.drop_thresh, g.drop_inv_keep, v);
+                }
+              }
+              const uint2 pk = f2bf4(v);
+              *reinterpret_cast<uint2*>(img + off) = pk;
             }
-            const uint2 pk = f2bf4(v);
-            *reinterpret_cast<uint2*>(img + off) = pk;
           }
         }
-      }
-      SW_STAMP(4 + 3 * ch);
-      __builtin_amdgcn_s_barrier();                          // the group's images of this chunk are complete
-      {
-        const int mrow = m0 + wm * 96 + ch * ROWS, lim = m_end - mrow;          // (uniform) first row of this group's chunk, live rows in it
-        const uint32_t cbase = (uint32_t)mrow * (uint32_t)g.ldc + (uint32_t)n0;
+        SW_STAMP(4 + 3 * ch);
+        __builtin_amdgcn_s_barrier();                          // the group's images of this chunk are complete
+        {
+          const int mrow = m0 + wm * 96 + ch * ROWS, lim = m_end - mrow;          // (uniform) first row of this group's chunk, live rows in it
+          const uint32_t cbase = (uint32_t)mrow * (uint32_t)g.ldc + (uint32_t)n0;
 #pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3)
+          for (int t3 = 0; t3 < 3; ++t3)
 #pragma unroll
-          for (int kk = 0; kk < 3; ++kk) {
-            if (rb_row[kk] + 16 * t3 < lim) {
-              const size_t dst = (size_t)(cbase + (uint32_t)(16 * t3) * (uint32_t)g.ldc + rb_dst[kk]);
-              *reinterpret_cast<float4*>(C + dst) = *reinterpret_cast<const float4*>(img + rb_lds[kk] + t3 * 16 * ROWB);
-              if (stash) *reinterpret_cast<float4*>(C2 + dst) = *reinterpret_cast<const float4*>(img + IMG + rb_lds[kk] + t3 * 16 * ROWB);
+            for (int kk = 0; kk < 3; ++kk) {
+              if (rb_row[kk] + 16 * t3 < lim) {
+                const size_t dst = (size_t)(cbase + (uint32_t)(16 * t3) * (uint32_t)g.ldc + rb_dst[kk]);
+                *reinterpret_cast<float4*>(C + dst) = *reinterpret_cast<const float4*>(img + rb_lds[kk] + t3 * 16 * ROWB);
+                if constexpr (STASH) *reinterpret_cast<float4*>(C2 + dst) = *reinterpret_cast<const float4*>(img + IMG + rb_lds[kk] + t3 * 16 * ROWB);
+              }
             }
-          }
+        }
+        if constexpr (AUX_LDS) {
+          // chunk 1's aux DMA (3 instructions per wave) was issued BEFORE this chunk's 9 row stores and vmcnt retires in issue order:
+          // vmcnt(9) proves the DMA without waiting for the stores to drain (tools/st_trace.py: 9.3 us here with vmcnt(0)).  Only
+          // when every row of chunk 0 is live - otherwise a wave may skip store instructions and the count would not hold.
+          if (ch == 0) { if (m0 + 144 <= m_end) sw_wait_vm<9>(); else sw_wait_vm<0>(); }
+        }
+        SW_STAMP(5 + 3 * ch);
+        __builtin_amdgcn_s_barrier();                          // images consumed (AUX_LDS: and chunk 1's aux has landed)
+        SW_STAMP(6 + 3 * ch);
       }
+    };
+    {
+      using T1 = std::integral_constant<bool, true>;
+      using T0 = std::integral_constant<bool, false>;
+      const bool gelu = (epi & EPI_GELU) != 0;
       if constexpr (AUX_LDS) {
-        // chunk 1's aux DMA (3 instructions per wave) was issued BEFORE this chunk's 9 row stores and vmcnt retires in issue order:
-        // vmcnt(9) proves the DMA without waiting for the stores to drain (tools/st_trace.py: 9.3 us here with vmcnt(0)).  Only
-        // when every row of chunk 0 is live - otherwise a wave may skip store instructions and the count would not hold.
-        if (ch == 0) { if (m0 + 144 <= m_end) sw_wait_vm<9>(); else sw_wait_vm<0>(); }
+        if (gelu) chunk_loop(T1{}, T0{}); else chunk_loop(T0{}, T0{});
+      } else {
+        if (gelu && stash) chunk_loop(T1{}, T1{});
+        else if (gelu) chunk_loop(T1{}, T0{});
+        else if (stash) chunk_loop(T0{}, T1{});
+        else chunk_loop(T0{}, T0{});
       }
-      SW_STAMP(5 + 3 * ch);
-      __builtin_amdgcn_s_barrier();                          // images consumed (AUX_LDS: and chunk 1's aux has landed)
-      SW_STAMP(6 + 3 * ch);
     }
   } else {
 #pragma unroll
