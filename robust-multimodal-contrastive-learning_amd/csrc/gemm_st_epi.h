@@ -1,6 +1,7 @@
 // Shared pieces of the 192-row tile GEMM kernels (gemm_st.hip: one 8-wave workgroup per CU; gemm_dp.hip: two 4-wave
 // workgroups per CU): tile descriptor, XCD-aware tile order, and the epilogue that leaves through LDS as whole rows.
 #pragma once
+#include <type_traits>
 #include "rmcl_common.h"
 #include "kernels.h"
 
@@ -188,95 +189,102 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       }
     }
   }
+  // The chunk loop twice: PLAIN (no GELU, no pre-activation stash, no += into C: every launch of the step but the odd-shaped ones) without
+  // the per-value-group tests of those flags - each was a scalar branch + mask set-up per four values and a basic-block boundary.
+  auto chunk_loop = [&](auto plain_c) {
+    constexpr bool PLAIN = decltype(plain_c)::value;
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    if constexpr (AUX != ST_AUX_NONE) { if (ch + 1 < NCH) aux_fetch(ch + 1, (ch + 1) & 1); }
-    auto& res = resb[ch & 1];
-    auto& pre = preb[ch & 1];
+    for (int ch = 0; ch < NCH; ++ch) {
+      if constexpr (AUX != ST_AUX_NONE) { if (ch + 1 < NCH) aux_fetch(ch + 1, (ch + 1) & 1); }
+      auto& res = resb[ch & 1];
+      auto& pre = preb[ch & 1];
 #pragma unroll
-    for (int il = 0; il < RI; ++il) {
-      const int i = ch * RI + il;
-      const int m = mb + i * 16;
-      const bool live = m < T.m_end;
-      float mean_m = 0.f, rstd_m = 1.f, ps1 = 0.f, ps2 = 0.f;
-      if constexpr (LNF == 1) { mean_m = rs[i].x; rstd_m = rs[i].y; }
+      for (int il = 0; il < RI; ++il) {
+        const int i = ch * RI + il;
+        const int m = mb + i * 16;
+        const bool live = m < T.m_end;
+        float mean_m = 0.f, rstd_m = 1.f, ps1 = 0.f, ps2 = 0.f;
+        if constexpr (LNF == 1) { mean_m = rs[i].x; rstd_m = rs[i].y; }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        // (all four values of the accumulator at once: rmcl_common.h, "Four-wide forms")
-        const f32x4 av = acc[i][j], bv = f4v(bias[j]);
-        f32x4 v;
-        if constexpr (LNF == 1) v = rstd_m * (av - mean_m * f4v(lns[j])) + bv;
-        else v = g.alpha * av + bv;
-        if (DROP && (epi & EPI_DROP_BWD)) {
-          const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
-          drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
-        }
-        if (AUX == ST_AUX_DGELU) v *= gelu_poly_grad4(bf2f4(pre[il][j]));
-        const long ci = (long)m * g.ldc + nb + j * 16;
-        if ((epi & EPI_SAVE_PREACT) && live) {
-          const float t[4] = {v.x, v.y, v.z, v.w};
-          st_store4<TO>(C2 + ci, t);
-        }
-        if (epi & EPI_GELU) v = gelu_poly4(v);
-        if (DROP && (epi & EPI_DROPOUT)) drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v);
-        if (AUX == ST_AUX_RES) v += f4v(res[il][j]);
-        if constexpr (LNF == 2) {
-          const float c0 = cen6[i], d0 = v.x - c0, d1 = v.y - c0, d2 = v.z - c0, d3 = v.w - c0;
-          ps1 += (d0 + d1) + (d2 + d3);
-          ps2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-        // image: row il*16 + lane%16, element column wn*48 + j*16 + 4*(lane/16); 16-byte chunk index XOR (row & 7)
-        if constexpr (ESZ == 2) {
-          *reinterpret_cast<uint2*>(scratch + woff[j] + il * 16 * ROWB) = f2bf4(v);
-        } else {
-          *reinterpret_cast<float4*>(scratch + woff[j] + il * 16 * ROWB) = make_float4(v.x, v.y, v.z, v.w);
-        }
-      }
-      if constexpr (LNF == 2) {                                // this wave's 48 columns of row m: sum over the 4 lane groups
-        ps1 += __shfl_xor(ps1, 16, 64); ps1 += __shfl_xor(ps1, 32, 64);
-        ps2 += __shfl_xor(ps2, 16, 64); ps2 += __shfl_xor(ps2, 32, 64);
-        if (lane < 16 && live)
-          *reinterpret_cast<float2*>(g.ln_part + ((long)m * g.ln_nparts + (T.n0 / ST_T) * 4 + wn) * 2) = make_float2(ps1, ps2);
-      }
-    }
-    ST_STAMP(5 + 4 * ch);
-    __builtin_amdgcn_s_barrier();                            // the group's image of this chunk is complete
-    ST_STAMP(6 + 4 * ch);
-    {
-      const int mrow = T.m0 + wm * 96 + ch * ROWS, lim = min(ROWS, T.m_end - mrow);   // (uniform) first row of this group's chunk, live rows in it
-      const uint32_t cbase = (uint32_t)mrow * (uint32_t)g.ldc + (uint32_t)T.n0;
-#pragma unroll
-      for (int t3 = 0; t3 < NT3; ++t3)
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          if (kk + 3 * t3 < NIT && rb_row[kk] + t3 * ROWS3 < lim) {
-            const float4 w = *reinterpret_cast<const float4*>(scratch + rb_lds[kk] + t3 * ROWS3 * ROWB);
-            const size_t off = (size_t)(cbase + (uint32_t)(t3 * ROWS3) * (uint32_t)g.ldc + rb_dst[kk]);
-            TO* dst = C + off;
-            if constexpr (ESZ == 4) {
-              float4 o = w;
-              if constexpr (ACCPRE) {
-                const float4 old = oldv[ch][kk + 3 * t3];
-                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-              } else if (epi & EPI_ACCUM) {
-                const float4 old = *reinterpret_cast<const float4*>(dst);
-                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-              }
-              *reinterpret_cast<float4*>(dst) = o;
-              if constexpr (LNF == 2) {                        // bf16 copy of the (centred) residual stream: the next GEMM's A operand
-                const float c0 = rowstat[wm * 96 + ch * ROWS + rb_row[kk] + t3 * ROWS3];
-                const uint2 pk = make_uint2(f2bf2(f32x2{o.x, o.y} - c0), f2bf2(f32x2{o.z, o.w} - c0));
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C2) + off) = pk;
-              }
-            } else {
-              *reinterpret_cast<float4*>(dst) = w;
-            }
+        for (int j = 0; j < 3; ++j) {
+          // (all four values of the accumulator at once: rmcl_common.h, "Four-wide forms")
+          const f32x4 av = acc[i][j], bv = f4v(bias[j]);
+          f32x4 v;
+          if constexpr (LNF == 1) v = rstd_m * (av - mean_m * f4v(lns[j])) + bv;
+          else v = g.alpha * av + bv;
+          if (DROP && (epi & EPI_DROP_BWD)) {
+            const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
+            drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
+          }
+          if (AUX == ST_AUX_DGELU) v *= gelu_poly_grad4(bf2f4(pre[il][j]));
+          const long ci = (long)m * g.ldc + nb + j * 16;
+          if (!PLAIN && (epi & EPI_SAVE_PREACT) && live) {
+            const float t[4] = {v.x, v.y, v.z, v.w};
+            st_store4<TO>(C2 + ci, t);
+          }
+          if (!PLAIN && (epi & EPI_GELU)) v = gelu_poly4(v);
+          if (DROP && (epi & EPI_DROPOUT)) drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v);
+          if (AUX == ST_AUX_RES) v += f4v(res[il][j]);
+          if constexpr (LNF == 2) {
+            const float c0 = cen6[i], d0 = v.x - c0, d1 = v.y - c0, d2 = v.z - c0, d3 = v.w - c0;
+            ps1 += (d0 + d1) + (d2 + d3);
+            ps2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          }
+          // image: row il*16 + lane%16, element column wn*48 + j*16 + 4*(lane/16); 16-byte chunk index XOR (row & 7)
+          if constexpr (ESZ == 2) {
+            *reinterpret_cast<uint2*>(scratch + woff[j] + il * 16 * ROWB) = f2bf4(v);
+          } else {
+            *reinterpret_cast<float4*>(scratch + woff[j] + il * 16 * ROWB) = make_float4(v.x, v.y, v.z, v.w);
           }
         }
+        if constexpr (LNF == 2) {                                // this wave's 48 columns of row m: sum over the 4 lane groups
+          ps1 += __shfl_xor(ps1, 16, 64); ps1 += __shfl_xor(ps1, 32, 64);
+          ps2 += __shfl_xor(ps2, 16, 64); ps2 += __shfl_xor(ps2, 32, 64);
+          if (lane < 16 && live)
+            *reinterpret_cast<float2*>(g.ln_part + ((long)m * g.ln_nparts + (T.n0 / ST_T) * 4 + wn) * 2) = make_float2(ps1, ps2);
+        }
+      }
+      ST_STAMP(5 + 4 * ch);
+      __builtin_amdgcn_s_barrier();                            // the group's image of this chunk is complete
+      ST_STAMP(6 + 4 * ch);
+      {
+        const int mrow = T.m0 + wm * 96 + ch * ROWS, lim = min(ROWS, T.m_end - mrow);   // (uniform) first row of this group's chunk, live rows in it
+        const uint32_t cbase = (uint32_t)mrow * (uint32_t)g.ldc + (uint32_t)T.n0;
+#pragma unroll
+        for (int t3 = 0; t3 < NT3; ++t3)
+#pragma unroll
+          for (int kk = 0; kk < 3; ++kk) {
+            if (kk + 3 * t3 < NIT && rb_row[kk] + t3 * ROWS3 < lim) {
+              const float4 w = *reinterpret_cast<const float4*>(scratch + rb_lds[kk] + t3 * ROWS3 * ROWB);
+              const size_t off = (size_t)(cbase + (uint32_t)(t3 * ROWS3) * (uint32_t)g.ldc + rb_dst[kk]);
+              TO* dst = C + off;
+              if constexpr (ESZ == 4) {
+                float4 o = w;
+                if constexpr (ACCPRE) {
+                  const float4 old = oldv[ch][kk + 3 * t3];
+                  o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                } else if (!PLAIN && (epi & EPI_ACCUM)) {
+                  const float4 old = *reinterpret_cast<const float4*>(dst);
+                  o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+                }
+                *reinterpret_cast<float4*>(dst) = o;
+                if constexpr (LNF == 2) {                        // bf16 copy of the (centred) residual stream: the next GEMM's A operand
+                  const float c0 = rowstat[wm * 96 + ch * ROWS + rb_row[kk] + t3 * ROWS3];
+                  const uint2 pk = make_uint2(f2bf2(f32x2{o.x, o.y} - c0), f2bf2(f32x2{o.z, o.w} - c0));
+                  *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(g.C2) + off) = pk;
+                }
+              } else {
+                *reinterpret_cast<float4*>(dst) = w;
+              }
+            }
+          }
+      }
+      ST_STAMP(7 + 4 * ch);
+      __builtin_amdgcn_s_barrier();                            // image consumed: the next chunk may overwrite it
+      ST_STAMP(8 + 4 * ch);
     }
-    ST_STAMP(7 + 4 * ch);
-    __builtin_amdgcn_s_barrier();                            // image consumed: the next chunk may overwrite it
-    ST_STAMP(8 + 4 * ch);
-  }
+  };
+  if (epi & (EPI_GELU | EPI_SAVE_PREACT | EPI_ACCUM)) chunk_loop(std::integral_constant<bool, false>{});
+  else chunk_loop(std::integral_constant<bool, true>{});
   __builtin_amdgcn_s_barrier();                              // the OTHER group (one barrier behind) has consumed its last image too:
 }                                                            // the next tile's LDS-DMA may now target this stage
