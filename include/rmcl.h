@@ -126,6 +126,16 @@ typedef struct rmcl_chain_stage {
 int rmcl_gemm_chain(const rmcl_chain_stage* stages, int n, int M, uint32_t* tickets, uint32_t epoch, int flags, int32_t* xcc, int64_t* stamps,
                     int stamp_wg, void* stream);
 
+/* EXPERIMENT (round 4, tools/l2_prefetch_bench.py): an L2 prefetch agent beside a 192-row-tile GEMM C[M,N] = A[M,K] W[N,K]^T - `wgs`
+ * single-wave workgroups, of which the first `per_xcd` to arrive on each XCD (hardware XCC_ID; `counter`: 8 int32 zeroed by the caller) pull
+ * one dword of every 128-byte line of the k-tiles the XCD's GEMM workgroups are about to stream (A rows of its row panels: tile ids
+ * xcd * tiles_per_xcd ..., `col_tiles` column tiles per row panel; all nB rows of W), `lead` k-tiles ahead of a clock-paced schedule of
+ * `tick` 10-ns ticks per k-tile.  Nothing is written but `stamps` ([8][2] int64 start / end wall clock, optional).  Not used by the
+ * encoder passes; DESIGN.md section 3 records what it measured.                                                                        */
+int rmcl_l2_prefetch_experiment(const void* A, int64_t lda_bytes, int M, int rows_per_tile, int tiles_per_xcd, int col_tiles, const void* W,
+                                int64_t ldw_bytes, int nB, int nk, int tick, int lead, int per_xcd, int wgs, int* counter, int64_t* stamps,
+                                void* stream);
+
 /* Element offsets into a parameter arena.  Names follow the reference state dict. */
 typedef struct rmcl_layout {
   int64_t word, pos, btype, eln_w, eln_b;      /* text_embeddings.{word,position,token_type}_embeddings, LayerNorm */

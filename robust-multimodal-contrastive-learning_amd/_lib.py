@@ -79,7 +79,7 @@ EXPORTS = (
     "rmcl_heads_forward", "rmcl_heads_forward2", "rmcl_heads_backward", "rmcl_infonce_ws_bytes", "rmcl_infonce_f32", "rmcl_infonce_split_bf16", "rmcl_pgd_step", "rmcl_pgd_step_fused",
     "rmcl_delta_channel_norm", "rmcl_ema_f32", "rmcl_enqueue_f32", "rmcl_cast_f32", "rmcl_adamw_f32", "rmcl_ipot_f32", "rmcl_gemm_batched", "rmcl_l2norm_rows_fwd", "rmcl_l2norm_rows_bwd",
     "rmcl_wpa_cost_finish", "rmcl_wpa_distance", "rmcl_itm_fwd", "rmcl_itm_bwd",
-    "rmcl_gemm", "rmcl_gemm_chain", "rmcl_gemm_route", "rmcl_gemm_kblk", "rmcl_layernorm_fwd", "rmcl_layernorm_bwd", "rmcl_attention_scratch_elems", "rmcl_attention_fwd",
+    "rmcl_gemm", "rmcl_gemm_chain", "rmcl_l2_prefetch_experiment", "rmcl_gemm_route", "rmcl_gemm_kblk", "rmcl_layernorm_fwd", "rmcl_layernorm_bwd", "rmcl_attention_scratch_elems", "rmcl_attention_fwd",
     "rmcl_attention_bwd",
     "rmcl_bt_stash_floats", "rmcl_bt_head_forward", "rmcl_bt_head_backward", "rmcl_bt_corr", "rmcl_bt_loss_ws_floats", "rmcl_bt_loss",
     "rmcl_bt_dz", "rmcl_bt_pair_metrics",

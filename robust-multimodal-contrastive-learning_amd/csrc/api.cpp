@@ -114,6 +114,12 @@ extern int g_attn_bwd_tpw;
 extern int g_gemm_share;
 extern bool g_lnfold_centred;
 extern int g_prefetch_mask, g_prefetch_wgs;
+int rmcl_l2_prefetch_experiment(const void* A, int64_t lda_bytes, int M, int rows_per_tile, int tiles_per_xcd, int col_tiles, const void* B,
+                                int64_t ldb_bytes, int nB, int nk, int tick, int lead, int per_xcd, int wgs, int* counter, int64_t* stamps, void* stream) {
+  RMCL_REQUIRE(A && B && counter && M > 0 && nk > 0 && per_xcd > 0 && wgs > 0 && col_tiles > 0, "l2_prefetch_experiment: bad argument");
+  return rmcl_debug_l2_prefetch(A, (long)lda_bytes, M, rows_per_tile, tiles_per_xcd, col_tiles, B, (long)ldb_bytes, nB, nk, tick, lead, per_xcd, wgs, counter,
+                                reinterpret_cast<long long*>(stamps), (hipStream_t)stream);
+}
 int rmcl_tune_set(int key, int value) {
   if (key == 11) { g_lnfold_centred = value != 0; return 0; }
   if (key == 12) { g_prefetch_mask = value & 7; return 0; }                                          // stash prefetch one layer ahead of the backward (encoder.cpp)

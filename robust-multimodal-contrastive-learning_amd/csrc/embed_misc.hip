@@ -422,6 +422,54 @@ int rmcl_touch(const void* p, size_t bytes, int wgs, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// L2 prefetch agent (round 4, EXPERIMENT behind tools/l2_prefetch_bench.py): the GEMM k-loops run at 0.71 us per k-tile on operands that sit
+// in their XCD's L2 and at ~1.0 in the step, where the first reader of every activation line misses to the Infinity Cache / HBM and the
+// loop's two k-tiles of LDS-DMA lookahead do not cover that latency; the compute waves cannot look further ahead themselves (LDS is full,
+// and a touch load of their own sits in the same in-order vmcnt queue as the LDS-DMA).  One single-wave workgroup per XCD - its own vmcnt,
+// no LDS, a handful of registers, so it fits beside a GEMM workgroup - walks the k-tiles `lead` ahead of a clock-paced schedule and pulls
+// one dword of every 128-byte line the XCD's workgroups are about to stream: the A rows of that XCD's row panels and the B rows
+// of all column tiles.  Which XCD a workgroup runs on is read from the hardware (XCC_ID); the first `per_xcd` arrivals on an XCD work.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void l2_prefetch_kernel(const char* __restrict__ A, long lda_b, int M, int rows_per_tile, int tiles_per_xcd,
+                                                         int col_tiles, const char* __restrict__ B, long ldb_b, int nB, int nk, int tick,
+                                                         int lead, int per_xcd, int* __restrict__ counter, long long* __restrict__ stamps) {
+  const int lane = threadIdx.x;
+  uint32_t xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+  int slot = 0;
+  if (lane == 0) slot = atomicAdd(counter + xcc, 1);
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  if (slot >= per_xcd) return;
+  const int id0 = (int)xcc * tiles_per_xcd, id1 = id0 + tiles_per_xcd - 1;
+  const int r_lo = (id0 / col_tiles) * rows_per_tile, r_hi = min(M, (id1 / col_tiles + 1) * rows_per_tile);
+  const long long t0 = wall_clock64();
+  if (stamps && lane == 0) stamps[xcc * 2] = t0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const long kb = (long)kt * 128;
+    for (int r = r_lo + slot * 64 + lane; r < r_hi; r += per_xcd * 64) {
+      uint32_t tmp;
+      const char* ptr = A + (long)r * lda_b + kb;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(ptr) : "memory");
+    }
+    for (int n = slot * 64 + lane; n < nB; n += per_xcd * 64) {
+      uint32_t tmp;
+      const char* ptr = B + (long)n * ldb_b + kb;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(ptr) : "memory");
+    }
+    while (wall_clock64() - t0 < (long long)(kt + 1 - lead) * tick) __builtin_amdgcn_s_sleep(2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (stamps && lane == 0) stamps[xcc * 2 + 1] = wall_clock64();
+}
+int rmcl_debug_l2_prefetch(const void* A, long lda_b, int M, int rows_per_tile, int tiles_per_xcd, int col_tiles, const void* B, long ldb_b, int nB,
+                           int nk, int tick, int lead, int per_xcd, int wgs, int* counter, long long* stamps, hipStream_t s) {
+  RMCL_LAUNCH(l2_prefetch_kernel, dim3(wgs), dim3(64), 0, s, (const char*)A, lda_b, M, rows_per_tile, tiles_per_xcd, col_tiles, (const char*)B, ldb_b,
+              nB, nk, tick, lead, per_xcd, counter, stamps);
+  RMCL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // MinMaxResize on the device (row f3, round 4): PIL's 8-bit bicubic resize (the reference's vilt/transforms/utils.py:5-26 calls
 // Image.resize(size, BICUBIC)) as two passes over the decoded bytes of a zero-padded batch [B, Hs, Ws, 3] - horizontal into a uint8
 // intermediate [B, Hs, Wd, 3], then vertical into [B, Hd, Wd, 3] - with PIL's own integer tables (vilt/transforms/resample.py builds

@@ -80,6 +80,8 @@ int rmcl_dropout_apply(float* x, long n, uint32_t dseed, uint32_t dthresh, float
 int rmcl_resize_u8(const unsigned char* src, const int* src_sizes, int B, int Hs, int Ws, const int* dst_sizes, int Hd, int Wd, const int* hb,
                    const int* hk, int ksh, const int* vb, const int* vk, int ksv, unsigned char* tmp, unsigned char* dst, hipStream_t s);
 int rmcl_touch(const void* p, size_t bytes, int wgs, hipStream_t s);
+int rmcl_debug_l2_prefetch(const void* A, long lda_b, int M, int rows_per_tile, int tiles_per_xcd, int col_tiles, const void* B, long ldb_b, int nB,
+                           int nk, int tick, int lead, int per_xcd, int wgs, int* counter, long long* stamps, hipStream_t s);
 int rmcl_dropout_rows(const float* in, float* out, int rows, int cols, long row_mul, uint32_t dseed, uint32_t dthresh, float dinv, hipStream_t s);
 int rmcl_text_embed_scatter(const long* ids, const float* de, float* dword, float* dpos, float* dbtype0, int B, int L, int D,
                             long pad_id, hipStream_t s);
