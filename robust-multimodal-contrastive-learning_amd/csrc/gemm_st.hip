@@ -171,9 +171,15 @@ __device__ __forceinline__ void st_tile_setup(STTile& T, const GemmArgs& g, int 
                                               int xflags) {
   asm volatile("" : "+v"(lane));   // recompute the lane-derived offsets per tile instead of keeping them live across the k-loops
   // split-K: item = split * tiles + tile; each split owns `per` k-tiles (the last one the remainder, >= 2 by construction)
-  const int ntile = tiles_m * tiles_n, split = item / ntile, id = item - split * ntile;
-  {
-    const int kts = g.K / 64, per = (kts + max(g.splitk, 1) - 1) / max(g.splitk, 1);
+  // (the integer divisions of this set-up sit in front of a launch's first LDS-DMA: the common cases - no split-K, one band - skip theirs)
+  int id = item;
+  T.kt0 = 0;
+  T.nk = g.K / 64;
+  T.zoff = 0;
+  if (g.splitk > 1) {
+    const int ntile = tiles_m * tiles_n, split = item / ntile;
+    id = item - split * ntile;
+    const int kts = g.K / 64, per = (kts + g.splitk - 1) / g.splitk;
     T.kt0 = split * per;
     T.nk = min(per, kts - T.kt0);
     T.zoff = (long)split * g.M * g.ldc;
@@ -181,7 +187,10 @@ __device__ __forceinline__ void st_tile_setup(STTile& T, const GemmArgs& g, int 
   // tile order: bands of 4 column tiles, row tiles inside a band, the band's 4 column tiles innermost - the 32 consecutive
   // tiles one XCD works on in a round are 8 A panels x 4 B panels (12 x 192 x K x 2 B: fits its 4 MiB L2 for K = 768)
   int tr, tc;
-  if (!(xflags & 2) && tiles_n % 4 == 0) {
+  if (!(xflags & 2) && tiles_n == 4) {
+    tr = id >> 2;
+    tc = id & 3;
+  } else if (!(xflags & 2) && tiles_n % 4 == 0) {
     const int band = id / (tiles_m * 4), rem = id - band * (tiles_m * 4);
     tr = rem >> 2;
     tc = band * 4 + (rem & 3);
