@@ -89,7 +89,25 @@ int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float 
 // WG: accumulate dgamma/dbeta (weight-gradient backward only); RELU: mask dy with the ReLU after the LN (MoCo head).
 // The data-gradient-only instantiation (PGD backward, 3/4 of all calls) carries 32 fewer accumulator registers.
 // NV = float4 per lane (row width <= 256 * NV): 3 for the encoder width 768, LN_MAXV otherwise.
-template <typename TG, bool WG, bool RELU, int NV>
+// Round 4: every load of a row - x, dy, the old dx when accumulating - is issued before the first one is consumed, and the two row sums
+// are taken with DPP row operations.  Before, each of the three column chunks was its own guarded block (load x, load dy, wait, compute)
+// and the accumulate form loaded the old value per chunk behind the reductions: six serial memory round trips per row, plus twelve
+// ds_bpermute round trips for the two sums - the kernel ran at 3.5-4.4 TB/s with 6 % of its cycles issuing.  FULL: D == 256 * NV, no
+// column guards (the encoder's 768).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ln_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += ln_dpp<0xB1, 0xf>(v);     // quad_perm [1, 0, 3, 2]
+  v += ln_dpp<0x4E, 0xf>(v);     // quad_perm [2, 3, 0, 1]
+  v += ln_dpp<0x141, 0xf>(v);    // row_half_mirror
+  v += ln_dpp<0x140, 0xf>(v);    // row_mirror: every lane of a 16-lane row holds the row's sum
+  v += ln_dpp<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3
+  v += ln_dpp<0x143, 0xc>(v);    // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <typename TG, bool WG, bool RELU, int NV, bool FULL, int ADD = -1>   // ADD: 0 / 1 known at compile time (no branch around the old-value loads), -1 run time
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const float* __restrict__ b,
@@ -104,33 +122,65 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
   for (int i = 0; i < NV; ++i) {
     gw[i] = make_float4(0, 0, 0, 0);
     gb[i] = make_float4(0, 0, 0, 0);
+    ww[i] = make_float4(0, 0, 0, 0);
+    bb[i] = make_float4(0, 0, 0, 0);
     const int c = (lane + 64 * i) * 4;
-    if (c < D) {
+    if (FULL || c < D) {
       ww[i] = *reinterpret_cast<const float4*>(w + c);
-      bb[i] = RELU ? *reinterpret_cast<const float4*>(b + c) : make_float4(0, 0, 0, 0);
+      if (RELU) bb[i] = *reinterpret_cast<const float4*>(b + c);
     }
   }
+  const bool addv = ADD < 0 ? add != 0 : ADD != 0;
   for (int it = 0; it < LNB_ITERS(WG); ++it) {
-    const int row = (blockIdx.x * LNB_ITERS(WG) + it) * 4 + wave;
+    int row = (blockIdx.x * LNB_ITERS(WG) + it) * 4 + wave;
     if (row >= M) break;
+    // the old values (accumulate form) are loaded by inline assembly, FIRST, and the row index every later address is computed from passes
+    // through that assembly: as plain loads the compiler sank them below the two reductions, to their use (a second, serial memory round
+    // trip per row), and as free-standing assembly it moved all the arithmetic above them; their registers are handed back to the compiler
+    // by the s_waitcnt assembly behind the reductions
+    f32x4 oldr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      oldr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (addv && (FULL || c < D)) {
+        const float* po = dx + (long)row * lddx + c;
+        asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(oldr[i]), "+v"(row) : "v"(po) : "memory");
+      }
+    }
+    // ---- every load of the row
     const float mu = mean[row], rs = rstd[row];
+    float4 xv[NV], dyf[NV];
+    uint2 dyb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      xv[i] = make_float4(0, 0, 0, 0);
+      dyf[i] = make_float4(0, 0, 0, 0);
+      dyb[i] = make_uint2(0, 0);
+      if (FULL || c < D) {
+        xv[i] = *reinterpret_cast<const float4*>(x + (long)row * ldx + c);
+        if constexpr (sizeof(TG) == 4) dyf[i] = *reinterpret_cast<const float4*>(dy + (long)row * lddy + c);
+        else dyb[i] = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + c);
+      }
+    }
+    // ---- dy * w, the two row sums
     float4 xh[NV], g[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
-      if (c < D) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (long)row * ldx + c);
+      xh[i] = make_float4(0, 0, 0, 0);
+      g[i] = make_float4(0, 0, 0, 0);
+      if (FULL || c < D) {
         float d[4];
         if constexpr (sizeof(TG) == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(dy + (long)row * lddy + c);
-          d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+          d[0] = dyf[i].x; d[1] = dyf[i].y; d[2] = dyf[i].z; d[3] = dyf[i].w;
         } else {
-          const uint2 t = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + c);
-          d[0] = __uint_as_float(t.x << 16); d[1] = __uint_as_float(t.x & 0xffff0000u);
-          d[2] = __uint_as_float(t.y << 16); d[3] = __uint_as_float(t.y & 0xffff0000u);
+          d[0] = __uint_as_float(dyb[i].x << 16); d[1] = __uint_as_float(dyb[i].x & 0xffff0000u);
+          d[2] = __uint_as_float(dyb[i].y << 16); d[3] = __uint_as_float(dyb[i].y & 0xffff0000u);
         }
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
         if (RELU) {
           if (xh[i].x * ww[i].x + bb[i].x <= 0.f) d[0] = 0.f;
           if (xh[i].y * ww[i].y + bb[i].y <= 0.f) d[1] = 0.f;
@@ -146,19 +196,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
         s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
       }
     }
-    s1 = wave_sum(s1) / D;
-    s2 = wave_sum(s2) / D;
+    s1 = wave_sum_dpp(s1) / D;
+    s2 = wave_sum_dpp(s2) / D;
+    if (addv) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(oldr[i]), "+v"(s2) : : "memory");   // (s2: keeps the wait BEHIND the reductions)
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
-      if (c < D) {
+      if (FULL || c < D) {
         float4 o = make_float4(rs * (g[i].x - s1 - xh[i].x * s2), rs * (g[i].y - s1 - xh[i].y * s2),
                                rs * (g[i].z - s1 - xh[i].z * s2), rs * (g[i].w - s1 - xh[i].w * s2));
         float* p = dx + (long)row * lddx + c;
-        if (add) {
-          const float4 old = *reinterpret_cast<const float4*>(p);
-          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-        }
+        if (addv) { o.x += oldr[i].x; o.y += oldr[i].y; o.z += oldr[i].z; o.w += oldr[i].w; }
         *reinterpret_cast<float4*>(p) = o;
         if (dx_copy) {   // copy of the updated residual-stream gradient = A operand of the next dX / dW GEMMs,
                          // already multiplied by the dropout mask of the branch output it flows into
@@ -178,11 +229,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
       }
     }
   }
-  if (WG && dgamma) {
+  if constexpr (WG) if (dgamma) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
-      if (c < D) {
+      if (FULL || c < D) {
         *reinterpret_cast<float4*>(&red[0][wave][c]) = gw[i];
         *reinterpret_cast<float4*>(&red[1][wave][c]) = gb[i];
       }
@@ -248,9 +299,13 @@ int rmcl_ln_bwd_lp(const void* dy, long lddy, int dt_dy, const float* x, long ld
   RMCL_REQUIRE(!rep_slot || (wg && D <= LN_REP_LD), "layernorm bwd: replica slot needs dgamma and D <= 1024");
   float* rep = rep_slot ? rep_slot : ((wg && D <= LN_REP_LD && grid.x >= 4 * LN_REP) ? ln_rep_buffer() : nullptr);
 #define LN_BWD_LAUNCH(TG, WGv, RLv) \
-  do { if (D <= 768) RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, 3>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
+  do { if (D == 768 && add) RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, 3, true, 1>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
               dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv, rep); \
-       else RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, LN_MAXV>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
+       else if (D == 768) RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, 3, true, 0>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
+              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv, rep); \
+       else if (D < 768) RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, 3, false>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
+              dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv, rep); \
+       else RMCL_LAUNCH((ln_bwd_kernel<TG, WGv, RLv, LN_MAXV, false>), grid, dim3(256), 0, s, (const TG*)dy, lddy, x, ldx, mean, rstd, w, b, dx, lddx, add, dgamma, \
               dbeta, M, D, relu, dx_copy, copy_dt == RMCL_F32, dseed, dthresh, dinv, rep); } while (0)
   if (dt_dy == RMCL_F32) {
     if (relu) { if (wg) LN_BWD_LAUNCH(float, true, true); else LN_BWD_LAUNCH(float, false, true); }
