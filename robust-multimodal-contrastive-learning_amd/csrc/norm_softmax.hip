@@ -5,10 +5,27 @@
 
 #define LN_MAXV 4  // float4 per lane -> D <= 1024
 
+// wave sum by DPP row operations (all 64 lanes must be active); every lane receives lane 63's total
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ln_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += ln_dpp<0xB1, 0xf>(v);     // quad_perm [1, 0, 3, 2]
+  v += ln_dpp<0x4E, 0xf>(v);     // quad_perm [2, 3, 0, 1]
+  v += ln_dpp<0x141, 0xf>(v);    // row_half_mirror
+  v += ln_dpp<0x140, 0xf>(v);    // row_mirror: every lane of a 16-lane row holds the row's sum
+  v += ln_dpp<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3
+  v += ln_dpp<0x143, 0xc>(v);    // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm forward: y = (x - mean) * rstd * w + b  (optionally ReLU), x f32 [M,D], y TO [M,D]
 // ---------------------------------------------------------------------------------------------
-template <typename TO>
+// NV = float4 per lane; FULL: D == 256 * NV (the encoder's 768: no column guards).  The weight / bias vectors are loaded with the row (they
+// sat behind the two reductions: a second round trip per row) and the row sums are DPP row operations instead of twelve ds_bpermute.
+template <typename TO, int NV, bool FULL>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ w,
                                                      const float* __restrict__ b, float eps, TO* __restrict__ y, long ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
@@ -16,36 +33,41 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* xr = x + (long)row * ldx;
-  float4 v[LN_MAXV];
+  float4 v[NV], ww[NV], bb[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
-    if (c < D) {
+    v[i] = make_float4(0, 0, 0, 0);
+    ww[i] = make_float4(0, 0, 0, 0);
+    bb[i] = make_float4(0, 0, 0, 0);
+    if (FULL || c < D) {
       v[i] = *reinterpret_cast<const float4*>(xr + c);
-      s += v[i].x + v[i].y + v[i].z + v[i].w;
+      ww[i] = *reinterpret_cast<const float4*>(w + c);
+      bb[i] = *reinterpret_cast<const float4*>(b + c);
     }
   }
-  const float mu = wave_sum(s) / D;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+  const float mu = wave_sum_dpp(s) / D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
-    if (c < D) {
-      const float a = v[i].x - mu, bb = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
-      q += a * a + bb * bb + cc * cc + d * d;
+    if (FULL || c < D) {
+      const float a = v[i].x - mu, b2 = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+      q += a * a + b2 * b2 + cc * cc + d * d;
     }
   }
-  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  const float rs = rsqrtf(wave_sum_dpp(q) / D + eps);
   if (lane == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
   TO* yr = y + (long)row * ldy;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (lane + 64 * i) * 4;
-    if (c < D) {
-      const float4 ww = *reinterpret_cast<const float4*>(w + c), bb = *reinterpret_cast<const float4*>(b + c);
-      float o[4] = {(v[i].x - mu) * rs * ww.x + bb.x, (v[i].y - mu) * rs * ww.y + bb.y,
-                    (v[i].z - mu) * rs * ww.z + bb.z, (v[i].w - mu) * rs * ww.w + bb.w};
+    if (FULL || c < D) {
+      float o[4] = {(v[i].x - mu) * rs * ww[i].x + bb[i].x, (v[i].y - mu) * rs * ww[i].y + bb[i].y,
+                    (v[i].z - mu) * rs * ww[i].z + bb[i].z, (v[i].w - mu) * rs * ww[i].w + bb[i].w};
       if (relu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
@@ -67,10 +89,14 @@ int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float 
   RMCL_REQUIRE(D % 4 == 0 && D <= 256 * LN_MAXV && ldx % 4 == 0 && ldy % 4 == 0, "layernorm: D must be a multiple of 4 and <= 1024");
   if (M <= 0) return 0;
   dim3 grid(cdiv(M, 4));
-  if (dt_out == RMCL_F32)
-    RMCL_LAUNCH(ln_fwd_kernel<float>, grid, dim3(256), 0, s, x, ldx, w, b, eps, (float*)y, ldy, mean, rstd, M, D, relu);
-  else
-    RMCL_LAUNCH(ln_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, x, ldx, w, b, eps, (bf16_t*)y, ldy, mean, rstd, M, D, relu);
+#define LN_FWD_LAUNCH(TO)                                                                                                                      \
+  do {                                                                                                                                         \
+    if (D == 768) RMCL_LAUNCH((ln_fwd_kernel<TO, 3, true>), grid, dim3(256), 0, s, x, ldx, w, b, eps, (TO*)y, ldy, mean, rstd, M, D, relu);         \
+    else RMCL_LAUNCH((ln_fwd_kernel<TO, LN_MAXV, false>), grid, dim3(256), 0, s, x, ldx, w, b, eps, (TO*)y, ldy, mean, rstd, M, D, relu);          \
+  } while (0)
+  if (dt_out == RMCL_F32) LN_FWD_LAUNCH(float);
+  else LN_FWD_LAUNCH(bf16_t);
+#undef LN_FWD_LAUNCH
   RMCL_CHECK_LAUNCH();
   return 0;
 }
@@ -94,19 +120,6 @@ int rmcl_ln_fwd(const float* x, long ldx, const float* w, const float* b, float 
 // and the accumulate form loaded the old value per chunk behind the reductions: six serial memory round trips per row, plus twelve
 // ds_bpermute round trips for the two sums - the kernel ran at 3.5-4.4 TB/s with 6 % of its cycles issuing.  FULL: D == 256 * NV, no
 // column guards (the encoder's 768).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float ln_dpp(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += ln_dpp<0xB1, 0xf>(v);     // quad_perm [1, 0, 3, 2]
-  v += ln_dpp<0x4E, 0xf>(v);     // quad_perm [2, 3, 0, 1]
-  v += ln_dpp<0x141, 0xf>(v);    // row_half_mirror
-  v += ln_dpp<0x140, 0xf>(v);    // row_mirror: every lane of a 16-lane row holds the row's sum
-  v += ln_dpp<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3
-  v += ln_dpp<0x143, 0xc>(v);    // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 template <typename TG, bool WG, bool RELU, int NV, bool FULL, int ADD = -1>   // ADD: 0 / 1 known at compile time (no branch around the old-value loads), -1 run time
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
