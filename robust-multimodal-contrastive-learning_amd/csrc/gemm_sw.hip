@@ -357,8 +357,10 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     // per-column vectors of both column halves and (LNF) the statistics of this lane's six rows: fetched ONCE, ahead of the chunk
     // loop (inside it every (chunk, half) paid an L2 / LDS round trip before its first FMA)
     // (the GELU' form carries no bias - fc2-dX - and has no registers to spare: its zero "bias" stays a constant)
-    constexpr bool HOIST = AUX != SW_AUX_DGELU;
-    float4 bias2[HOIST ? 2 : 1][3], lns2[2][LNF == 1 ? 3 : 1];
+    // (the dropout instantiations keep them per (chunk, half) too: with both halves' vectors live beside the mask state the folded fc1
+    // form spilled - 256 VGPRs + scratch - and its epilogue gained nothing from the round-4 rework: 90 us against 76 without dropout)
+    constexpr bool HOIST = AUX != SW_AUX_DGELU && !DROP;
+    float4 bias2[HOIST ? 2 : 1][3], lns2[HOIST ? 2 : 1][LNF == 1 ? 3 : 1];
     if constexpr (HOIST) {
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
@@ -417,13 +419,20 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
           const int nb = n0 + hb * 192 + wn * 48 + 4 * (lane >> 4);
-          float4 bias_l[3];
+          float4 bias_l[3], lns_l[LNF == 1 ? 3 : 1];
           if constexpr (!HOIST) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bias_l[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 3; ++j) {
+              if constexpr (LNF == 1) {
+                bias_l[j] = *reinterpret_cast<const float4*>(g.ln_c + nb + j * 16);
+                lns_l[j] = *reinterpret_cast<const float4*>(g.ln_s + nb + j * 16);
+              } else {
+                bias_l[j] = (epi & EPI_BIAS) ? *reinterpret_cast<const float4*>(g.bias + nb + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+              }
+            }
           }
           auto& bias = HOIST ? bias2[HOIST ? hb : 0] : bias_l;
-          auto& lns = lns2[hb];
+          auto& lns = HOIST ? lns2[HOIST ? hb : 0] : lns_l;
           uint2 pre[AUX == SW_AUX_DGELU ? 3 : 1][3];
 #pragma unroll
           for (int il = 0; il < 3; ++il) {

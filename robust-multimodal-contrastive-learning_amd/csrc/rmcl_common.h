@@ -167,19 +167,34 @@ __host__ __device__ __forceinline__ uint32_t rmcl_rng_hash(uint32_t seed, uint32
 __host__ __device__ __forceinline__ uint32_t rmcl_site_seed(uint32_t seed, int layer, int site) {
   return rmcl_rng_hash(seed ^ 0xA511E9B3u, (uint32_t)(layer * 8 + site + 1));
 }
-// Round 4: ONE 32-bit hash serves the element PAIR (idx >> 1): element idx is kept iff its 16-bit half of the hash is >= thresh >> 16
-// (p resolved to 2^-16: 0.1 -> 0.09999).  The integer multiplies of the hash were what the dropout epilogues cost (fc1 +10 us per launch
-// for 144 elements per lane); epilogues that hold four consecutive elements call drop_scale4 - two hashes instead of four.
+// Round 4: the mask of FOUR consecutive elements (idx >> 2) comes from two 32-bit words - a two-multiply mix of (seed, idx >> 2) and one more
+// multiply + shift of that word - and element idx is kept iff its 16-bit quarter is >= thresh >> 16 (p resolved to 2^-16: 0.1 -> 0.09999).
+// v_mul_lo_u32 runs at a quarter of the VALU rate: with one three-multiply hash per element the dropout epilogues cost fc1 +10 us per
+// launch (144 elements per lane), with one per pair +14 us on a 76 us launch after the epilogue rework; three multiplies per four elements
+// now.  Keep rates 0.8998-0.9002 and |pairwise correlation| <= 1.2e-3 over 4 M groups (inside a group, between neighbouring groups, one
+// row apart) for the seeds tried.  The mask is a pure function of (site seed, element index) wherever it is evaluated.
+__host__ __device__ __forceinline__ void rmcl_drop_words(uint32_t seed, uint32_t group, uint32_t& h0, uint32_t& h1) {
+  uint32_t x = group * 0x9E3779B1u ^ seed;
+  x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13;
+  uint32_t y = x * 0xC2B2AE35u;
+  y ^= y >> 16;
+  h0 = x;
+  h1 = y;
+}
 __host__ __device__ __forceinline__ bool rmcl_drop_keep(uint32_t seed, uint32_t idx, uint32_t thresh) {
-  const uint32_t h = rmcl_rng_hash(seed, idx >> 1);
-  return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= (thresh >> 16);
+  uint32_t h0, h1;
+  rmcl_drop_words(seed, idx >> 2, h0, h1);
+  const uint32_t w = (idx & 2u) ? h1 : h0;
+  return ((idx & 1u) ? (w >> 16) : (w & 0xffffu)) >= (thresh >> 16);
 }
 __device__ __forceinline__ float drop_scale(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
   return rmcl_drop_keep(seed, idx, thresh) ? inv_keep : 0.f;
 }
 // v[0..3] *= mask of elements idx .. idx + 3, idx a multiple of 4 (every caller: column offsets and leading dimensions are multiples of 4)
 __device__ __forceinline__ void drop_scale4(uint32_t seed, uint32_t idx, uint32_t thresh, float inv_keep, float& v0, float& v1, float& v2, float& v3) {
-  const uint32_t h0 = rmcl_rng_hash(seed, idx >> 1), h1 = rmcl_rng_hash(seed, (idx >> 1) + 1u), t = thresh >> 16;
+  uint32_t h0, h1;
+  rmcl_drop_words(seed, idx >> 2, h0, h1);
+  const uint32_t t = thresh >> 16;
   v0 *= (h0 & 0xffffu) >= t ? inv_keep : 0.f;
   v1 *= (h0 >> 16) >= t ? inv_keep : 0.f;
   v2 *= (h1 & 0xffffu) >= t ? inv_keep : 0.f;
