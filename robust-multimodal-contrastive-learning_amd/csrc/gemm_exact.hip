@@ -542,7 +542,8 @@ void rmcl_gemm_skinny_set_form(int v) { g_skinny_form = v; }
 int rmcl_launch_gemm_skinny(const GemmArgs& g, int b_kc, hipStream_t s) {
   if (g_skinny_form != 0 && g.K % 64 == 0 && g.K >= 128) {
     // 8 waves (K split 8 ways) where the reduction is long and the grid small; 32-column tiles for very wide outputs
-    const bool w8 = g.K % 128 == 0 && g.K >= 2048 && g.N < 4096;
+    // (round 4: from K = 512 on, not 2048 - a K = 768 launch is a chain of 4 operand round trips with 4 waves, 2 with 8: -0.05 ms per step over six alternating runs)
+    const bool w8 = g.K % 128 == 0 && g.K >= 512 && g.N < 4096;
     if (g.N >= 4096) {
       dim3 grid(cdiv(g.N, 32), cdiv(g.M, 64));
       if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 32, 4>), grid, dim3(256), 0, s, g);
