@@ -542,8 +542,9 @@ void rmcl_gemm_skinny_set_form(int v) { g_skinny_form = v; }
 int rmcl_launch_gemm_skinny(const GemmArgs& g, int b_kc, hipStream_t s) {
   if (g_skinny_form != 0 && g.K % 64 == 0 && g.K >= 128) {
     // 8 waves (K split 8 ways) where the reduction is long and the grid small; 32-column tiles for very wide outputs
-    // (round 4: from K = 512 on, not 2048 - a K = 768 launch is a chain of 4 operand round trips with 4 waves, 2 with 8: -0.05 ms per step over six alternating runs)
-    const bool w8 = g.K % 128 == 0 && g.K >= 512 && g.N < 4096;
+    // (round 4: 8 waves from K = 512 on measured -0.05 ms per step over six alternating runs, but the different fp32 summation order moved the
+    // 4-sample BatchNorm golden of the Barlow-Twins step from 0.9 % to 1.03 % on one gradient norm - bound 1 % - so the threshold stays)
+    const bool w8 = g.K % 128 == 0 && g.K >= 2048 && g.N < 4096;
     if (g.N >= 4096) {
       dim3 grid(cdiv(g.N, 32), cdiv(g.M, 64));
       if (b_kc) RMCL_LAUNCH((gemm_skinny_ksplit_kernel<true, 32, 4>), grid, dim3(256), 0, s, g);
