@@ -191,8 +191,12 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
   }
   // The chunk loop twice: PLAIN (no GELU, no pre-activation stash, no += into C: every launch of the step but the odd-shaped ones) without
   // the per-value-group tests of those flags - each was a scalar branch + mask set-up per four values and a basic-block boundary.
-  auto chunk_loop = [&](auto plain_c) {
+  // (dropout instantiations: the mask that applies - 1 the output's, 2 the forward's on the way back, 3 both tested at run time - is a second
+  // parameter; the element index of a group is a 32-bit add to a per-lane base)
+  const uint32_t dbase_aux = DROP ? (uint32_t)mb * (uint32_t)g.ld_aux + (uint32_t)nb : 0u, dbase_c = DROP ? (uint32_t)mb * (uint32_t)g.ldc + (uint32_t)nb : 0u;
+  auto chunk_loop = [&](auto plain_c, auto dm_c) {
     constexpr bool PLAIN = decltype(plain_c)::value;
+    constexpr int DM = decltype(dm_c)::value;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       if constexpr (AUX != ST_AUX_NONE) { if (ch + 1 < NCH) aux_fetch(ch + 1, (ch + 1) & 1); }
@@ -212,9 +216,11 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
           f32x4 v;
           if constexpr (LNF == 1) v = rstd_m * (av - mean_m * f4v(lns[j])) + bv;
           else v = g.alpha * av + bv;
-          if (DROP && (epi & EPI_DROP_BWD)) {
-            const uint32_t di = (uint32_t)((long)m * g.ld_aux + nb + j * 16);
-            drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
+          if constexpr (DROP && (DM & 2) != 0) {
+            if (DM == 2 || (epi & EPI_DROP_BWD)) {
+              const uint32_t di = dbase_aux + (uint32_t)(i * 16) * (uint32_t)g.ld_aux + (uint32_t)(j * 16);
+              drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
+            }
           }
           if (AUX == ST_AUX_DGELU) v *= gelu_poly_grad4(bf2f4(pre[il][j]));
           const long ci = (long)m * g.ldc + nb + j * 16;
@@ -223,7 +229,10 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
             st_store4<TO>(C2 + ci, t);
           }
           if (!PLAIN && (epi & EPI_GELU)) v = gelu_poly4(v);
-          if (DROP && (epi & EPI_DROPOUT)) drop_scale4(g.drop_seed, (uint32_t)ci, g.drop_thresh, g.drop_inv_keep, v);
+          if constexpr (DROP && (DM & 1) != 0) {
+            if (DM == 1 || (epi & EPI_DROPOUT))
+              drop_scale4(g.drop_seed, dbase_c + (uint32_t)(i * 16) * (uint32_t)g.ldc + (uint32_t)(j * 16), g.drop_thresh, g.drop_inv_keep, v);
+          }
           if (AUX == ST_AUX_RES) v += f4v(res[il][j]);
           if constexpr (LNF == 2) {
             const float c0 = cen6[i], d0 = v.x - c0, d1 = v.y - c0, d2 = v.z - c0, d3 = v.w - c0;
@@ -284,7 +293,19 @@ __device__ __forceinline__ void st_epilogue_lds(const f32x4 (&acc)[6][3], const 
       ST_STAMP(8 + 4 * ch);
     }
   };
-  if (epi & (EPI_GELU | EPI_SAVE_PREACT | EPI_ACCUM)) chunk_loop(std::integral_constant<bool, false>{});
-  else chunk_loop(std::integral_constant<bool, true>{});
+  {
+    using P0 = std::integral_constant<bool, false>;
+    using P1 = std::integral_constant<bool, true>;
+    const bool plain = !(epi & (EPI_GELU | EPI_SAVE_PREACT | EPI_ACCUM));
+    if constexpr (!DROP) {
+      if (plain) chunk_loop(P1{}, std::integral_constant<int, 0>{}); else chunk_loop(P0{}, std::integral_constant<int, 0>{});
+    } else {
+      const int dm = ((epi & EPI_DROPOUT) ? 1 : 0) | ((epi & EPI_DROP_BWD) ? 2 : 0);
+      if (plain && dm == 1) chunk_loop(P1{}, std::integral_constant<int, 1>{});
+      else if (plain && dm == 2) chunk_loop(P1{}, std::integral_constant<int, 2>{});
+      else if (plain) chunk_loop(P1{}, std::integral_constant<int, 3>{});
+      else chunk_loop(P0{}, std::integral_constant<int, 3>{});
+    }
+  }
   __builtin_amdgcn_s_barrier();                              // the OTHER group (one barrier behind) has consumed its last image too:
 }                                                            // the next tile's LDS-DMA may now target this stage

@@ -410,8 +410,12 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     // The chunk loop, once per (GELU, stash) combination and chosen here: tested per value group inside the loops the two flags cost a scalar
     // branch + mask set-up per four values and cut the loop body into basic blocks that each re-materialised the polynomial's constants
     // (~600 scalar instructions per tile, which a wave that has its SIMD to itself issues one at a time like the VALU ones).
-    auto chunk_loop = [&](auto gelu_c, auto stash_c) {
+    // (dropout instantiations: which mask applies - 1 the output's, 2 the forward's hidden one on the way back, 3 decided per group at run
+    // time - is a third parameter for the step's own combinations; the element index of a group is a 32-bit add to a per-lane base)
+    const uint32_t dbase_aux = DROP ? (uint32_t)mb * (uint32_t)g.ld_aux : 0u, dbase_c = DROP ? (uint32_t)mb * (uint32_t)g.ldc : 0u;
+    auto chunk_loop = [&](auto gelu_c, auto stash_c, auto dm_c) {
       constexpr bool GELU = decltype(gelu_c)::value, STASH = decltype(stash_c)::value;
+      constexpr int DM = decltype(dm_c)::value;
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
         char* aux_ch = ch == 0 ? aux_area : last_cur;           // (AUX_LDS only)
@@ -461,18 +465,18 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
               if constexpr (LNF == 1) v = rstd_m * (av - mean_m * f4v(lns[j])) + bv;
               else v = g.alpha * av + bv;
               if (AUX == SW_AUX_DGELU) v *= gelu_poly_grad4(bf2f4(pre[il][j]));
-              if constexpr (DROP) {
-                if (epi & EPI_DROP_BWD) {                              // mask of the forward's hidden dropout, indexed like the stash
-                  const uint32_t di = (uint32_t)((long)(mb + i * 16) * g.ld_aux + nb + j * 16);
+              if constexpr (DROP && (DM & 2) != 0) {
+                if (DM == 2 || (epi & EPI_DROP_BWD)) {                 // mask of the forward's hidden dropout, indexed like the stash
+                  const uint32_t di = dbase_aux + (uint32_t)(i * 16) * (uint32_t)g.ld_aux + (uint32_t)(nb + j * 16);
                   drop_scale4(g.drop_seed, di, g.drop_thresh, g.drop_inv_keep, v);
                 }
               }
               const int off = woff[hb][j] + il * 16 * ROWB;
               if constexpr (STASH) *reinterpret_cast<uint2*>(img + IMG + off) = f2bf4(v);
               if constexpr (GELU) v = gelu_poly4(v);
-              if constexpr (DROP) {
-                if (epi & EPI_DROPOUT) {
-                  const uint32_t ci = (uint32_t)((long)(mb + i * 16) * g.ldc + nb + j * 16);
+              if constexpr (DROP && (DM & 1) != 0) {
+                if (DM == 1 || (epi & EPI_DROPOUT)) {
+                  const uint32_t ci = dbase_c + (uint32_t)(i * 16) * (uint32_t)g.ldc + (uint32_t)(nb + j * 16);
                   drop_scale4(g.drop_seed, ci, g.drop_thresh, g.drop_inv_keep, v);
                 }
               }
@@ -511,14 +515,32 @@ __global__ __launch_bounds__(512) void gemm_sw_kernel(GemmArgs g, int tiles_m, i
     {
       using T1 = std::integral_constant<bool, true>;
       using T0 = std::integral_constant<bool, false>;
+      using D0 = std::integral_constant<int, 0>;
+      using D1 = std::integral_constant<int, 1>;
+      using D2 = std::integral_constant<int, 2>;
+      using D3 = std::integral_constant<int, 3>;
       const bool gelu = (epi & EPI_GELU) != 0;
-      if constexpr (AUX_LDS) {
-        if (gelu) chunk_loop(T1{}, T0{}); else chunk_loop(T0{}, T0{});
-      } else {
-        if (gelu && stash) chunk_loop(T1{}, T1{});
-        else if (gelu) chunk_loop(T1{}, T0{});
-        else if (stash) chunk_loop(T0{}, T1{});
-        else chunk_loop(T0{}, T0{});
+      const int dm = DROP ? (((epi & EPI_DROPOUT) ? 1 : 0) | ((epi & EPI_DROP_BWD) ? 2 : 0)) : 0;
+      if constexpr (!DROP) {
+        if constexpr (AUX_LDS) {
+          if (gelu) chunk_loop(T1{}, T0{}, D0{}); else chunk_loop(T0{}, T0{}, D0{});
+        } else {
+          if (gelu && stash) chunk_loop(T1{}, T1{}, D0{});
+          else if (gelu) chunk_loop(T1{}, T0{}, D0{});
+          else if (stash) chunk_loop(T0{}, T1{}, D0{});
+          else chunk_loop(T0{}, T0{}, D0{});
+        }
+      } else if constexpr (AUX_LDS) {                            // fc2-dX under dropout: the hidden mask on the way back
+        if (!gelu && dm == 2) chunk_loop(T0{}, T0{}, D2{});
+        else if (gelu) chunk_loop(T1{}, T0{}, D3{});
+        else chunk_loop(T0{}, T0{}, D3{});
+      } else {                                                   // fc1 under dropout: GELU, then the hidden mask (with / without the stash)
+        if (gelu && stash && dm == 1) chunk_loop(T1{}, T1{}, D1{});
+        else if (gelu && !stash && dm == 1) chunk_loop(T1{}, T0{}, D1{});
+        else if (gelu && stash) chunk_loop(T1{}, T1{}, D3{});
+        else if (gelu) chunk_loop(T1{}, T0{}, D3{});
+        else if (stash) chunk_loop(T0{}, T1{}, D3{});
+        else chunk_loop(T0{}, T0{}, D3{});
       }
     }
   } else {
