@@ -145,37 +145,54 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
   }
   const bool addv = ADD < 0 ? add != 0 : ADD != 0;
   for (int it = 0; it < LNB_ITERS(WG); ++it) {
-    int row = (blockIdx.x * LNB_ITERS(WG) + it) * 4 + wave;
+    const int row = (blockIdx.x * LNB_ITERS(WG) + it) * 4 + wave;
     if (row >= M) break;
-    // the old values (accumulate form) are loaded by inline assembly, FIRST, and the row index every later address is computed from passes
-    // through that assembly: as plain loads the compiler sank them below the two reductions, to their use (a second, serial memory round
-    // trip per row), and as free-standing assembly it moved all the arithmetic above them; their registers are handed back to the compiler
-    // by the s_waitcnt assembly behind the reductions
-    f32x4 oldr[NV];
+    // ---- every load of the row, the old values (accumulate form) first.  As plain loads the compiler sank the old values below the two
+    // reductions, to their use - a second, serial memory round trip per row.  They stay plain loads (a first version issued them by inline
+    // assembly and handed the registers back behind the reductions: the register allocator is free to copy such a register before the data
+    // has landed - one instantiation faulted); what keeps them up here is the empty assembly statement below, which "uses" every register
+    // the loads of the row write: all of them are issued, in this order, before it, and nothing is sunk past it.
+    typedef unsigned int ln_u32x2 __attribute__((ext_vector_type(2)));
+    f32x4 oldr[NV], xr[NV], dyr[NV];
+    ln_u32x2 dyb[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
       oldr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (addv && (FULL || c < D)) {
-        const float* po = dx + (long)row * lddx + c;
-        asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(oldr[i]), "+v"(row) : "v"(po) : "memory");
-      }
+      if (addv && (FULL || c < D)) oldr[i] = *reinterpret_cast<const f32x4*>(dx + (long)row * lddx + c);
     }
-    // ---- every load of the row
-    const float mu = mean[row], rs = rstd[row];
-    float4 xv[NV], dyf[NV];
-    uint2 dyb[NV];
+    float mu = mean[row], rs = rstd[row];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;
-      xv[i] = make_float4(0, 0, 0, 0);
-      dyf[i] = make_float4(0, 0, 0, 0);
-      dyb[i] = make_uint2(0, 0);
+      xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dyr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dyb[i] = ln_u32x2{0u, 0u};
       if (FULL || c < D) {
-        xv[i] = *reinterpret_cast<const float4*>(x + (long)row * ldx + c);
-        if constexpr (sizeof(TG) == 4) dyf[i] = *reinterpret_cast<const float4*>(dy + (long)row * lddy + c);
-        else dyb[i] = *reinterpret_cast<const uint2*>(dy + (long)row * lddy + c);
+        xr[i] = *reinterpret_cast<const f32x4*>(x + (long)row * ldx + c);
+        if constexpr (sizeof(TG) == 4) dyr[i] = *reinterpret_cast<const f32x4*>(dy + (long)row * lddy + c);
+        else dyb[i] = *reinterpret_cast<const ln_u32x2*>(dy + (long)row * lddy + c);
       }
+    }
+    if constexpr (NV == 3) {
+      if constexpr (sizeof(TG) == 4)
+        asm volatile("" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(dyr[0]), "+v"(dyr[1]), "+v"(dyr[2]), "+v"(mu), "+v"(rs));
+      else
+        asm volatile("" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(dyb[0]), "+v"(dyb[1]), "+v"(dyb[2]), "+v"(mu), "+v"(rs));
+    } else {
+      static_assert(NV == 4, "ln_bwd: NV is 3 or 4");
+      if constexpr (sizeof(TG) == 4)
+        asm volatile("" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(oldr[3]), "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(dyr[0]), "+v"(dyr[1]),
+                     "+v"(dyr[2]), "+v"(dyr[3]), "+v"(mu), "+v"(rs));
+      else
+        asm volatile("" : "+v"(oldr[0]), "+v"(oldr[1]), "+v"(oldr[2]), "+v"(oldr[3]), "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(dyb[0]), "+v"(dyb[1]),
+                     "+v"(dyb[2]), "+v"(dyb[3]), "+v"(mu), "+v"(rs));
+    }
+    float4 xv[NV], dyf[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      xv[i] = make_float4(xr[i].x, xr[i].y, xr[i].z, xr[i].w);
+      dyf[i] = make_float4(dyr[i].x, dyr[i].y, dyr[i].z, dyr[i].w);
     }
     // ---- dy * w, the two row sums
     float4 xh[NV], g[NV];
@@ -211,10 +228,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TG* __restrict__ dy, 
     }
     s1 = wave_sum_dpp(s1) / D;
     s2 = wave_sum_dpp(s2) / D;
-    if (addv) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(oldr[i]), "+v"(s2) : : "memory");   // (s2: keeps the wait BEHIND the reductions)
-    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (lane + 64 * i) * 4;

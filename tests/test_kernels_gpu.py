@@ -97,6 +97,33 @@ def test_layernorm_fwd_bwd(relu):
     assert rel_err(dg, wd.grad) < 2e-5 and rel_err(db, bd.grad) < 2e-5
 
 
+@pytest.mark.parametrize("D", [768, 512, 1024])
+@pytest.mark.parametrize("add", [0, 1])
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("wgrad", [0, 1])
+def test_layernorm_bwd_variants(D, add, dt, wgrad):
+    """Every instantiation family of the row kernel (round 4: loads of a row issued up front - the old values by inline assembly -, DPP row
+    sums, guard-free D = 768 form): D = 768 / guarded widths, accumulate or overwrite, fp32 / bf16 dy, with / without dgamma-dbeta; M is not
+    a multiple of the rows per workgroup.  Reference: torch autograd of F.layer_norm in fp64 on the values the kernel reads."""
+    M = 203
+    x, w, b = rnd(M, D, seed=11) * 2 + 0.5, 1 + 0.1 * rnd(D, seed=12), 0.1 * rnd(D, seed=13)
+    dy = rnd(M, D, seed=14).to(tdt(dt))
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    torch.nn.functional.layer_norm(xd, (D,), wd, bd, 1e-6).backward(dy.double())
+    y = torch.empty(M, D, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    check(lib.rmcl_layernorm_fwd(P(x), P(w), P(b), F(1e-6), P(y), L.F32, P(mean), P(rstd), M, D, 0, stream()))
+    dx0 = rnd(M, D, seed=15)
+    dx = dx0.clone()
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    check(lib.rmcl_layernorm_bwd(P(dy), dt, P(x), P(mean), P(rstd), P(w), P(b), P(dx), add, P(dg) if wgrad else None, P(db) if wgrad else None,
+                                 M, D, 0, stream()))
+    got = dx - dx0 if add else dx
+    assert rel_err(got, xd.grad) < 2e-5
+    if wgrad:
+        assert rel_err(dg, wd.grad) < 2e-5 and rel_err(db, bd.grad) < 2e-5
+
+
 # ------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("dt,exact", [(L.F32, 1), (L.BF16, 1), (L.BF16, 0)])
 @pytest.mark.parametrize("BN", [(3, 185), (2, 64), (1, 241), (2, 130)])
