@@ -442,19 +442,23 @@ __global__ __launch_bounds__(64) void l2_prefetch_kernel(const char* __restrict_
   if (slot >= per_xcd) return;
   const int id0 = (int)xcc * tiles_per_xcd, id1 = id0 + tiles_per_xcd - 1;
   const int r_lo = (id0 / col_tiles) * rows_per_tile, r_hi = min(M, (id1 / col_tiles + 1) * rows_per_tile);
+  // the touches are LDS-DMA dwords into a 256-byte sink nobody reads: no register destination, so nothing has to stay reserved while one is in
+  // flight (a first version loaded into a dead VGPR by inline assembly - the allocator is free to reuse such a register at once)
+  __shared__ uint32_t sink[64];
+  const uint32_t sink_addr = (uint32_t)(uintptr_t)sink;
   const long long t0 = wall_clock64();
   if (stamps && lane == 0) stamps[xcc * 2] = t0;
   for (int kt = 0; kt < nk; ++kt) {
     const long kb = (long)kt * 128;
     for (int r = r_lo + slot * 64 + lane; r < r_hi; r += per_xcd * 64) {
-      uint32_t tmp;
       const char* ptr = A + (long)r * lda_b + kb;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(ptr) : "memory");
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(ptr), "s"(sink_addr) : "memory");
     }
     for (int n = slot * 64 + lane; n < nB; n += per_xcd * 64) {
-      uint32_t tmp;
       const char* ptr = B + (long)n * ldb_b + kb;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(ptr) : "memory");
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(ptr), "s"(sink_addr) : "memory");
     }
     while (wall_clock64() - t0 < (long long)(kt + 1 - lead) * tick) __builtin_amdgcn_s_sleep(2);
   }
